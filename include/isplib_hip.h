@@ -1,0 +1,145 @@
+/*
+ * isplib_hip.h -- C ABI of the MI355X (gfx950) SpMM aggregation backend.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch types.
+ * Every pointer marked [dev] is a DEVICE pointer (HBM); every entry point is
+ * asynchronous on `stream` (a hipStream_t passed as void*; NULL = the default
+ * stream) and returns a FusedMM status code.  Nothing here allocates, frees or
+ * synchronises, so all of it is hipGraph-capturable; entry points that need
+ * scratch take a caller-owned workspace whose size a *_workspace_bytes query
+ * reports.
+ *
+ * Reference interfaces replaced (paths relative to the iSpLib tree):
+ *   fusedMM_csr_hip            <- fusedMM_csr, csrc/fusedMM.h:77-99, called at
+ *                                 csrc/fusedmm.cpp:198; it takes the place of
+ *                                 the never-linked fusedmm_cuda() stub at
+ *                                 csrc/fusedmm.cpp:89-110,191-196 and of the
+ *                                 thread-per-row prototype gpu/fusedmm.cu:18-51.
+ *   performDummySpMM_hip       <- performDummySpMM, csrc/fusedmm.cpp:61,570.
+ *   isplib_spmm_minmax_bw_hip  <- the ATen gather/mul/masked_fill/scatter_add_
+ *                                 chain of FusedMM_SPMMMax/Min::backward,
+ *                                 csrc/fusedmm.cpp:410-451 and 477-517.
+ *   isplib_sddmm_csr_hip       <- the commented-out spmm_value_bw call,
+ *                                 csrc/fusedmm.cpp:270,351 (dA for sum/mean).
+ *   isplib_csr_* (graph prep)  <- torch_sparse storage getters the wrapper
+ *                                 forces at isplib/__init__.py:67-73 and the two
+ *                                 nnz-sized gathers it caches at :79-80,:86-99.
+ */
+#ifndef ISPLIB_HIP_H
+#define ISPLIB_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ISPLIB_HIP_ABI_VERSION 1
+
+/* ---- FusedMM op message (values fixed by csrc/fusedMM.h:18-74) ---------- */
+#define ISPLIB_VOP_COPY_RHS 0x2
+#define ISPLIB_ROP_NOOP     0x00
+#define ISPLIB_SOP_COPY     0x100
+#define ISPLIB_VSC_MUL      0x1000
+#define ISPLIB_VSC_MEAN     0x3000
+#define ISPLIB_AOP_ADD      0x10000
+#define ISPLIB_AOP_MAX      0x20000
+#define ISPLIB_AOP_MIN      0x30000
+/* the four messages the reference sends, csrc/fusedmm.cpp:168-186 */
+#define ISPLIB_MSG_SPMM_SUM  (ISPLIB_VOP_COPY_RHS | ISPLIB_ROP_NOOP | ISPLIB_SOP_COPY | ISPLIB_VSC_MUL  | ISPLIB_AOP_ADD)
+#define ISPLIB_MSG_SPMM_MEAN (ISPLIB_VOP_COPY_RHS | ISPLIB_ROP_NOOP | ISPLIB_SOP_COPY | ISPLIB_VSC_MEAN | ISPLIB_AOP_ADD)
+#define ISPLIB_MSG_SPMM_MAX  (ISPLIB_VOP_COPY_RHS | ISPLIB_ROP_NOOP | ISPLIB_SOP_COPY | ISPLIB_VSC_MUL  | ISPLIB_AOP_MAX)
+#define ISPLIB_MSG_SPMM_MIN  (ISPLIB_VOP_COPY_RHS | ISPLIB_ROP_NOOP | ISPLIB_SOP_COPY | ISPLIB_VSC_MUL  | ISPLIB_AOP_MIN)
+
+/* ---- status codes (csrc/fusedMM.h:105-114) + one for HIP runtime errors -- */
+#define ISPLIB_SUCCESS         0
+#define ISPLIB_FAIL            1    /* bad argument                            */
+#define ISPLIB_NOT_ENOUGH_MEM (-1)  /* workspace too small                      */
+#define ISPLIB_NO_OPT_IMPL     128  /* message outside the SpMM set             */
+#define ISPLIB_HIP_ERROR       256  /* a HIP call failed; see isplib_hip_last_error */
+
+int         isplib_hip_abi_version(void);
+const char *isplib_hip_last_error(void);   /* thread-local, "" if none */
+
+/*
+ * SpMM with the reference's 20-argument FusedMM signature, device pointers.
+ *
+ *   z[i,:] = REDUCE_{j in [pntrb[i], pntre[i])}  val[j] * y[indx[j], :]
+ *
+ * REDUCE/scale from `imessage` (one of ISPLIB_MSG_SPMM_*).  Differences from
+ * the host ABI, all consequences of running on the device:
+ *   - z and z_arg are WRITE-ONLY: the kernel writes the value the reference
+ *     gets by pre-filling z with 0 / -FLT_MAX / +FLT_MAX (csrc/fusedmm.cpp:
+ *     147-152) and z_arg with nnz (:171,177) and then accumulating.  beta must
+ *     be 0 (the only value the reference passes, :117).  This folds two
+ *     M*K-sized fill passes into the kernel's write-back.
+ *   - val may be NULL = unit weights (what isplib/__init__.py:51-57
+ *     materialises as a ones vector); the stream is then never read.
+ *   - MAX/MIN: strict compare in CSR order (lowest CSR position wins ties, NaN
+ *     never wins); empty row -> value 0, z_arg = nnz.  z_arg (int64, same
+ *     leading dimension as z) holds ABSOLUTE CSR positions; may be NULL.
+ *   - x/ldx/alpha/rows/cols are accepted and ignored, as in the reference.
+ * Requirements: n < 2^31, every row's degree < 2^31, ldy >= k, ldz >= k.
+ */
+int fusedMM_csr_hip(int32_t imessage, int64_t m, int64_t n, int64_t k,
+                    float alpha, int64_t nnz, int64_t rows, int64_t cols,
+                    const float *val /*[dev] nnz | NULL*/,
+                    const int64_t *indx /*[dev] nnz*/,
+                    const int64_t *pntrb /*[dev] m*/,
+                    const int64_t *pntre /*[dev] m*/,
+                    const float *x /*ignored*/, int64_t ldx,
+                    const float *y /*[dev] n x ldy*/, int64_t ldy, float beta,
+                    float *z /*[dev] m x ldz*/, int64_t ldz,
+                    int64_t *z_arg /*[dev] m x ldz | NULL*/, void *stream);
+
+/* Warm-up hook with the reference's name; launches one empty kernel. */
+void performDummySpMM_hip(int64_t flag, void *stream);
+
+/*
+ * Fused backward of SpMM-max/min (one pass, float atomics):
+ *   for every (i,c) with a = arg[i,c] != nnz, j = indx[a]:
+ *     grad_mat[j,c]  += (val ? val[a] : 1) * grad_out[i,c]      (if grad_mat)
+ *     grad_val[a]    += mat[j,c] * grad_out[i,c]                (if grad_val)
+ * grad_mat (n x k) and grad_val (nnz) are zero-filled by this call first.
+ * All dense operands contiguous with leading dimension k.
+ */
+int isplib_spmm_minmax_bw_hip(int64_t m, int64_t n, int64_t k, int64_t nnz,
+                              const int64_t *indx, const float *val,
+                              const float *mat, const int64_t *arg,
+                              const float *grad_out, float *grad_mat,
+                              float *grad_val, void *stream);
+
+/*
+ * SDDMM-style value gradient of SpMM-sum / SpMM-mean:
+ *   dval[j] = < y[indx[j], :], g[i, :] > * (mean ? 1/max(deg_i,1) : 1),  j in row i
+ */
+int isplib_sddmm_csr_hip(int64_t m, int64_t k, const int64_t *indx,
+                         const int64_t *pntrb, const int64_t *pntre,
+                         const float *y, int64_t ldy, const float *g,
+                         int64_t ldg, int mean, float *dval, void *stream);
+
+/*
+ * Graph preparation on the device (the step immediately before the path).
+ *   isplib_csr_row_ids_hip : row[j] = i for j in [rowptr[i], rowptr[i+1])
+ *   isplib_csr2csc_hip     : stable counting sort of the CSR entries by column:
+ *        colptr[n+1], csr2csc[nnz] (CSC position -> CSR position),
+ *        row_t[nnz] = row[csr2csc], and, when val_t != NULL,
+ *        val_t[nnz] = (val ? val[csr2csc] : 1) / (mean_scale ? max(deg(row),1) : 1)
+ *     i.e. exactly the cached operands of isplib/__init__.py:79-80 (sum) and the
+ *     intended form of :86-99 (mean; csrc/fusedmm.cpp:357-364).
+ *     Deterministic (no atomics decide placement).  Workspace: see query.
+ */
+int    isplib_csr_row_ids_hip(int64_t m, int64_t nnz, const int64_t *rowptr,
+                              int64_t *row, void *stream);
+size_t isplib_csr2csc_workspace_bytes(int64_t m, int64_t n, int64_t nnz);
+int    isplib_csr2csc_hip(int64_t m, int64_t n, int64_t nnz,
+                          const int64_t *rowptr, const int64_t *col,
+                          const float *val, int mean_scale, int64_t *colptr,
+                          int64_t *csr2csc, int64_t *row_t, float *val_t,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ISPLIB_HIP_H */

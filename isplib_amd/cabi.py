@@ -1,0 +1,189 @@
+"""ctypes view of the C ABI (include/isplib_hip.h) for device tensors.
+
+This is the binding a non-torch host (the reference's own launcher,
+csrc/fusedmm.cpp:198) would use; here it lets the GPU parity tests and
+``bench.py`` call the library exactly at the drop-in boundary, bypassing the
+torch operator layer.  Torch is used only to own device memory and name the
+stream.  Every function raises ``RuntimeError`` on a non-zero status.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+# values of include/isplib_hip.h
+MSG_SPMM_SUM = 0x2 | 0x00 | 0x100 | 0x1000 | 0x10000
+MSG_SPMM_MEAN = 0x2 | 0x00 | 0x100 | 0x3000 | 0x10000
+MSG_SPMM_MAX = 0x2 | 0x00 | 0x100 | 0x1000 | 0x20000
+MSG_SPMM_MIN = 0x2 | 0x00 | 0x100 | 0x1000 | 0x30000
+MESSAGE = {"sum": MSG_SPMM_SUM, "add": MSG_SPMM_SUM, "mean": MSG_SPMM_MEAN, "max": MSG_SPMM_MAX, "min": MSG_SPMM_MIN}
+
+SUCCESS, FAIL, NOT_ENOUGH_MEM, NO_OPT_IMPL, HIP_ERROR = 0, 1, -1, 128, 256
+
+EXPORTS = (
+    "isplib_hip_abi_version", "isplib_hip_last_error", "fusedMM_csr_hip", "performDummySpMM_hip",
+    "isplib_spmm_minmax_bw_hip", "isplib_sddmm_csr_hip", "isplib_csr_row_ids_hip",
+    "isplib_csr2csc_workspace_bytes", "isplib_csr2csc_hip",
+)
+
+_i64, _f32, _vp, _i32 = ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_int32
+_sigs_set = False
+
+
+def lib() -> ctypes.CDLL:
+    global _sigs_set
+    L = _lib.cdll()
+    if not _sigs_set:
+        L.isplib_hip_abi_version.restype = ctypes.c_int
+        L.isplib_hip_last_error.restype = ctypes.c_char_p
+        L.fusedMM_csr_hip.restype = ctypes.c_int
+        L.fusedMM_csr_hip.argtypes = [_i32, _i64, _i64, _i64, _f32, _i64, _i64, _i64, _vp, _vp, _vp, _vp,
+                                      _vp, _i64, _vp, _i64, _f32, _vp, _i64, _vp, _vp]
+        L.performDummySpMM_hip.restype = None
+        L.performDummySpMM_hip.argtypes = [_i64, _vp]
+        L.isplib_spmm_minmax_bw_hip.restype = ctypes.c_int
+        L.isplib_spmm_minmax_bw_hip.argtypes = [_i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+        L.isplib_sddmm_csr_hip.restype = ctypes.c_int
+        L.isplib_sddmm_csr_hip.argtypes = [_i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, ctypes.c_int, _vp, _vp]
+        L.isplib_csr_row_ids_hip.restype = ctypes.c_int
+        L.isplib_csr_row_ids_hip.argtypes = [_i64, _i64, _vp, _vp, _vp]
+        L.isplib_csr2csc_workspace_bytes.restype = ctypes.c_size_t
+        L.isplib_csr2csc_workspace_bytes.argtypes = [_i64, _i64, _i64]
+        L.isplib_csr2csc_hip.restype = ctypes.c_int
+        L.isplib_csr2csc_hip.argtypes = [_i64, _i64, _i64, _vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp,
+                                         _vp, ctypes.c_size_t, _vp]
+        _sigs_set = True
+    return L
+
+
+def last_error() -> str:
+    return lib().isplib_hip_last_error().decode()
+
+
+def _check(status: int, what: str) -> None:
+    if status != 0:
+        raise RuntimeError(f"{what} failed with status {status}: {last_error()}")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(device) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _dev(t: torch.Tensor, name: str, dtype) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"isplib_amd: `{name}` must be a GPU tensor -- there is no CPU path")
+    if t.dtype != dtype:
+        raise TypeError(f"isplib_amd: `{name}` must be {dtype}, got {t.dtype}")
+    return t.contiguous()
+
+
+def fusedMM_csr_hip(imessage: int, rowptr: torch.Tensor, col: torch.Tensor, val: Optional[torch.Tensor],
+                    y: torch.Tensor, z: torch.Tensor, z_arg: Optional[torch.Tensor] = None, *, beta: float = 0.0,
+                    check: bool = True) -> int:
+    """Raw boundary call with the reference's argument pattern (csrc/fusedmm.cpp:198):
+    pntrb = rowptr, pntre = rowptr + 1, ldy/ldz = row strides of y/z."""
+    rowptr = _dev(rowptr, "rowptr", torch.int64)
+    col = _dev(col, "col", torch.int64)
+    if val is not None:
+        val = _dev(val, "val", torch.float32)
+    assert y.is_cuda and z.is_cuda and y.dtype == torch.float32 and z.dtype == torch.float32
+    assert y.dim() == 2 and z.dim() == 2 and y.stride(1) == 1 and z.stride(1) == 1
+    m, n, k = rowptr.numel() - 1, y.size(0), y.size(1)
+    assert z.size(0) == m and z.size(1) == k
+    rp = rowptr.data_ptr()
+    with torch.cuda.device(y.device):
+        st = lib().fusedMM_csr_hip(int(imessage), m, n, k, 1.0, col.numel(), m, n, _ptr(val), _ptr(col),
+                                   ctypes.c_void_p(rp), ctypes.c_void_p(rp + 8), None, k, _ptr(y),
+                                   y.stride(0) if n > 1 else max(k, y.stride(0)), beta, _ptr(z),
+                                   z.stride(0) if m > 1 else max(k, z.stride(0)), _ptr(z_arg), _stream(y.device))
+    if check:
+        _check(st, "fusedMM_csr_hip")
+    return st
+
+
+def spmm(rowptr, col, val, y, reduce: str = "sum"):
+    """Allocate outputs and call the boundary; returns (out, arg|None)."""
+    m, k = rowptr.numel() - 1, y.size(1)
+    y = y.contiguous()
+    out = torch.empty((m, k), dtype=torch.float32, device=y.device)
+    arg = torch.empty((m, k), dtype=torch.int64, device=y.device) if reduce in ("max", "min") else None
+    fusedMM_csr_hip(MESSAGE[reduce], rowptr, col, val, y, out, arg)
+    return out, arg
+
+
+def perform_dummy_spmm(flag: int = 0) -> None:
+    lib().performDummySpMM_hip(int(flag), _stream(None))
+
+
+def spmm_minmax_bw(col, val, mat, arg, grad_out, need_mat=True, need_val=True):
+    col = _dev(col, "col", torch.int64)
+    mat = _dev(mat, "mat", torch.float32)
+    arg = _dev(arg, "arg", torch.int64)
+    grad_out = _dev(grad_out, "grad_out", torch.float32)
+    if val is not None:
+        val = _dev(val, "val", torch.float32)
+    m, k = arg.shape
+    n, nnz = mat.size(0), col.numel()
+    grad_mat = torch.empty_like(mat) if need_mat else None
+    grad_val = torch.empty(nnz, dtype=torch.float32, device=mat.device) if need_val else None
+    with torch.cuda.device(mat.device):
+        st = lib().isplib_spmm_minmax_bw_hip(m, n, k, nnz, _ptr(col), _ptr(val), _ptr(mat), _ptr(arg), _ptr(grad_out),
+                                             _ptr(grad_mat), _ptr(grad_val), _stream(mat.device))
+    _check(st, "isplib_spmm_minmax_bw_hip")
+    return grad_val, grad_mat
+
+
+def sddmm(rowptr, col, y, g, mean: bool = False):
+    rowptr = _dev(rowptr, "rowptr", torch.int64)
+    col = _dev(col, "col", torch.int64)
+    y = _dev(y, "y", torch.float32)
+    g = _dev(g, "g", torch.float32)
+    m, k = rowptr.numel() - 1, y.size(1)
+    dval = torch.empty(col.numel(), dtype=torch.float32, device=y.device)
+    rp = rowptr.data_ptr()
+    with torch.cuda.device(y.device):
+        st = lib().isplib_sddmm_csr_hip(m, k, _ptr(col), ctypes.c_void_p(rp), ctypes.c_void_p(rp + 8), _ptr(y), k,
+                                        _ptr(g), k, int(bool(mean)), _ptr(dval), _stream(y.device))
+    _check(st, "isplib_sddmm_csr_hip")
+    return dval
+
+
+def csr_row_ids(rowptr, nnz: int):
+    rowptr = _dev(rowptr, "rowptr", torch.int64)
+    row = torch.empty(nnz, dtype=torch.int64, device=rowptr.device)
+    with torch.cuda.device(rowptr.device):
+        st = lib().isplib_csr_row_ids_hip(rowptr.numel() - 1, nnz, _ptr(rowptr), _ptr(row), _stream(rowptr.device))
+    _check(st, "isplib_csr_row_ids_hip")
+    return row
+
+
+def csr2csc(rowptr, col, val, ncols: int, *, mean_scale: bool = False, want_perm: bool = True,
+            want_row: bool = True, want_val: bool = True):
+    """Device CSR -> CSC operands: (colptr, csr2csc|None, row_t|None, val_t|None)."""
+    rowptr = _dev(rowptr, "rowptr", torch.int64)
+    col = _dev(col, "col", torch.int64)
+    if val is not None:
+        val = _dev(val, "val", torch.float32)
+    dev = col.device
+    m, nnz = rowptr.numel() - 1, col.numel()
+    colptr = torch.empty(ncols + 1, dtype=torch.int64, device=dev)
+    perm = torch.empty(nnz, dtype=torch.int64, device=dev) if want_perm else None
+    row_t = torch.empty(nnz, dtype=torch.int64, device=dev) if want_row else None
+    val_t = torch.empty(nnz, dtype=torch.float32, device=dev) if want_val else None
+    with torch.cuda.device(dev):
+        ws = lib().isplib_csr2csc_workspace_bytes(m, ncols, nnz)
+        if ws == 0:
+            raise RuntimeError("isplib_csr2csc_workspace_bytes failed: " + last_error())
+        work = torch.empty(ws, dtype=torch.uint8, device=dev)
+        st = lib().isplib_csr2csc_hip(m, ncols, nnz, _ptr(rowptr), _ptr(col), _ptr(val), int(bool(mean_scale)),
+                                      _ptr(colptr), _ptr(perm), _ptr(row_t), _ptr(val_t), _ptr(work), ws, _stream(dev))
+    _check(st, "isplib_csr2csc_hip")
+    return colptr, perm, row_t, val_t

@@ -1,0 +1,183 @@
+// backward.hip -- the two backward kernels that are not "SpMM on A^T":
+//   * fused scatter for SpMM-max/min (replaces the 6-8 ATen passes of
+//     reference csrc/fusedmm.cpp:410-451 / 477-517),
+//   * SDDMM-style dA for sum/mean (the call the reference leaves commented out,
+//     csrc/fusedmm.cpp:270,351).
+// dX of sum/mean needs no kernel of its own: it is fusedMM_csr_hip on the CSC
+// operands, exactly as the reference does at csrc/fusedmm.cpp:285,375.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/isplib_hip.h"
+#include "common.h"
+
+namespace isplib {
+
+// One thread per (row, feature) element of arg/grad_out; consecutive lanes hold
+// consecutive features of one row, so the reads are coalesced and each wave's
+// atomics to one destination row are contiguous where args agree.
+__global__ __launch_bounds__(256) void minmax_bw_kernel(int64_t total, int64_t k, int64_t nnz,
+                                                        const int64_t *__restrict__ indx,
+                                                        const float *__restrict__ val,
+                                                        const float *__restrict__ mat,
+                                                        const int64_t *__restrict__ arg,
+                                                        const float *__restrict__ grad_out,
+                                                        float *grad_mat, float *grad_val) {
+   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+      const int64_t a = arg[t];
+      if (a < 0 || a >= nnz) continue;            // nnz = "no winner" sentinel
+      const int64_t c = t % k;
+      const int64_t j = indx[a];
+      const float go = grad_out[t];
+      if (grad_mat) atomicAdd(grad_mat + j * k + c, (val ? val[a] : 1.0f) * go);
+      if (grad_val) atomicAdd(grad_val + a, mat[j * k + c] * go);
+   }
+}
+
+template <int VEC> __device__ __forceinline__ float dot_chunk(const float *p, const float *q);
+template <> __device__ __forceinline__ float dot_chunk<4>(const float *p, const float *q) {
+   const float4 a = *reinterpret_cast<const float4 *>(p);
+   const float4 b = *reinterpret_cast<const float4 *>(q);
+   return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
+}
+template <> __device__ __forceinline__ float dot_chunk<1>(const float *p, const float *q) { return p[0] * q[0]; }
+
+struct SddmmArgs {
+   int64_t m, k;
+   const int64_t *indx, *pntrb, *pntre;
+   const float *y;
+   int64_t ldy;
+   const float *g;
+   int64_t ldg;
+   int mean;
+   float *dval;
+   int long_row;
+};
+
+// one wave, edges [rb, re) of row `row`; G = 64/LPR edges per step
+template <int VEC, int LPR>
+__device__ __forceinline__ void sddmm_edges(const SddmmArgs &a, int64_t row, int64_t rb, int64_t re, float scale) {
+   constexpr int G = 64 / LPR;
+   constexpr int U = 4;
+   const int lane = threadIdx.x & 63;
+   const int g = lane / LPR, lc = lane % LPR;
+   const float *gr = a.g + (size_t)row * (size_t)a.ldg;
+   for (int64_t base = rb; base < re; base += 64) {
+      const int64_t p = base + lane;
+      const int c_l = p < re ? (int)a.indx[p] : 0;
+      const int64_t left = re - base;
+      const int cnt = left < 64 ? (int)left : 64;
+      for (int s = 0; s < cnt; s += G * U) {
+         float part[U];
+#pragma unroll
+         for (int u = 0; u < U; u++) {
+            const int ei = s + u * G + g;
+            const bool ok = ei < cnt;
+            const int cc = __shfl(c_l, ei & 63);
+            const float *yr = a.y + (size_t)cc * (size_t)a.ldy;
+            float acc = 0.0f;
+            if (ok)
+               for (int64_t c = (int64_t)lc * VEC; c < a.k; c += LPR * VEC) acc += dot_chunk<VEC>(yr + c, gr + c);
+            part[u] = acc;
+         }
+#pragma unroll
+         for (int u = 0; u < U; u++) {
+            float t = part[u];
+#pragma unroll
+            for (int off = LPR / 2; off >= 1; off >>= 1) t += __shfl_xor(t, off);
+            const int ei = s + u * G + g;
+            if (lc == 0 && ei < cnt) a.dval[base + ei] = t * scale;
+         }
+      }
+   }
+}
+
+template <int VEC, int LPR, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void sddmm_csr_kernel(const SddmmArgs a) {
+   const int wave = threadIdx.x >> 6;
+   const int64_t row0 = (int64_t)blockIdx.x * WAVES;
+   const int64_t row = row0 + wave;
+   if (row < a.m) {
+      const int64_t b = a.pntrb[row], e = a.pntre[row];
+      const int64_t deg = e - b;
+      if (deg > 0 && deg <= a.long_row) {
+         const float scale = a.mean ? 1.0f / (float)deg : 1.0f;
+         sddmm_edges<VEC, LPR>(a, row, b, e, scale);
+      }
+   }
+   for (int r = 0; r < WAVES; r++) {
+      const int64_t lr = row0 + r;
+      if (lr >= a.m) break;
+      const int64_t b = a.pntrb[lr], e = a.pntre[lr];
+      const int64_t deg = e - b;
+      if (deg <= a.long_row) continue;
+      int64_t chunk = (deg + WAVES - 1) / WAVES;
+      chunk = (chunk + 63) & ~(int64_t)63;
+      int64_t cb = b + (int64_t)wave * chunk, ce = cb + chunk;
+      if (cb > e) cb = e;
+      if (ce > e) ce = e;
+      const float scale = a.mean ? 1.0f / (float)deg : 1.0f;
+      sddmm_edges<VEC, LPR>(a, lr, cb, ce, scale);
+   }
+}
+
+template <int VEC, int LPR>
+static int launch_sddmm(const SddmmArgs &a, hipStream_t st) {
+   constexpr int WAVES = 4;
+   const int64_t nb = (a.m + WAVES - 1) / WAVES;
+   if (nb > 0x7fffffffLL) return ISPLIB_FAIL;
+   hipLaunchKernelGGL((sddmm_csr_kernel<VEC, LPR, WAVES>), dim3((unsigned)nb), dim3(WAVES * 64), 0, st, a);
+   return check_launch("sddmm_csr_kernel");
+}
+
+}  // namespace isplib
+
+using namespace isplib;
+
+extern "C" int isplib_spmm_minmax_bw_hip(int64_t m, int64_t n, int64_t k, int64_t nnz, const int64_t *indx,
+                                         const float *val, const float *mat, const int64_t *arg,
+                                         const float *grad_out, float *grad_mat, float *grad_val, void *stream) {
+   clear_error();
+   if (m < 0 || n < 0 || k < 0 || nnz < 0) return fail(ISPLIB_FAIL, "isplib_spmm_minmax_bw_hip: negative dimension");
+   hipStream_t st = (hipStream_t)stream;
+   if (grad_mat && n * k > 0) ISPLIB_HIP_TRY(hipMemsetAsync(grad_mat, 0, (size_t)n * (size_t)k * sizeof(float), st));
+   if (grad_val && nnz > 0) ISPLIB_HIP_TRY(hipMemsetAsync(grad_val, 0, (size_t)nnz * sizeof(float), st));
+   const int64_t total = m * k;
+   if (total == 0 || nnz == 0 || (!grad_mat && !grad_val)) return ISPLIB_SUCCESS;
+   if (!indx || !arg || !grad_out) return fail(ISPLIB_FAIL, "isplib_spmm_minmax_bw_hip: null operand");
+   if (grad_val && !mat) return fail(ISPLIB_FAIL, "isplib_spmm_minmax_bw_hip: grad_val needs mat");
+   int64_t blocks = (total + 255) / 256;
+   if (blocks > 256 * 32) blocks = 256 * 32;   // grid-stride beyond 32 blocks per CU
+   hipLaunchKernelGGL(minmax_bw_kernel, dim3((unsigned)blocks), dim3(256), 0, st, total, k, nnz, indx, val, mat, arg,
+                      grad_out, grad_mat, grad_val);
+   return check_launch("minmax_bw_kernel");
+}
+
+extern "C" int isplib_sddmm_csr_hip(int64_t m, int64_t k, const int64_t *indx, const int64_t *pntrb,
+                                    const int64_t *pntre, const float *y, int64_t ldy, const float *g, int64_t ldg,
+                                    int mean, float *dval, void *stream) {
+   clear_error();
+   if (m < 0 || k < 0) return fail(ISPLIB_FAIL, "isplib_sddmm_csr_hip: negative dimension");
+   if (m == 0) return ISPLIB_SUCCESS;
+   if (!indx || !pntrb || !pntre || !dval || (k > 0 && (!y || !g)))
+      return fail(ISPLIB_FAIL, "isplib_sddmm_csr_hip: null operand");
+   if (ldy < k || ldg < k) return fail(ISPLIB_FAIL, "isplib_sddmm_csr_hip: leading dimension smaller than k");
+   SddmmArgs a;
+   a.m = m; a.k = k; a.indx = indx; a.pntrb = pntrb; a.pntre = pntre;
+   a.y = y; a.ldy = ldy; a.g = g; a.ldg = ldg; a.mean = mean ? 1 : 0; a.dval = dval;
+   a.long_row = 4096;
+   hipStream_t st = (hipStream_t)stream;
+   const uintptr_t al = (uintptr_t)y | (uintptr_t)g;
+   const bool v4 = (k % 4 == 0) && (ldy % 4 == 0) && (ldg % 4 == 0) && ((al & 15) == 0);
+   if (v4) {
+      const int64_t w = k / 4;
+      if (w <= 8) return launch_sddmm<4, 8>(a, st);
+      if (w <= 16) return launch_sddmm<4, 16>(a, st);
+      if (w <= 32) return launch_sddmm<4, 32>(a, st);
+      return launch_sddmm<4, 64>(a, st);
+   }
+   if (k <= 16) return launch_sddmm<1, 16>(a, st);
+   if (k <= 32) return launch_sddmm<1, 32>(a, st);
+   return launch_sddmm<1, 64>(a, st);
+}

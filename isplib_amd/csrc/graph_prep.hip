@@ -1,0 +1,166 @@
+// graph_prep.hip -- CSR -> CSC operands on the device (the step immediately
+// before the path).  Replaces the host-side torch_sparse storage calls the
+// reference wrapper forces (isplib/__init__.py:67-73: row(), rowcount(),
+// csr2csc(), colptr()) and the two nnz-sized gathers it caches per graph
+// (:79-80 for sum, :86-99 for mean), which cost seconds per graph on the CPU.
+//
+// csr2csc is a STABLE sort of CSR positions by column id, so CSC order within a
+// column is ascending CSR position = ascending row -- the order torch_sparse
+// produces and the order that fixes which edge wins a max/min tie in A^T.
+// The sort is rocPRIM's LSD radix sort (stable by construction) on 32-bit keys
+// truncated to ceil(log2(n)) bits; everything else is hand-written.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "../../include/isplib_hip.h"
+#include "common.h"
+
+namespace isplib {
+
+__device__ __forceinline__ int64_t row_of(const int64_t *__restrict__ rowptr, int64_t m, int64_t p) {
+   // last r in [0, m) with rowptr[r] <= p  (empty rows are skipped naturally)
+   int64_t lo = 0, hi = m;   // invariant: rowptr[lo] <= p < rowptr[hi]
+   while (hi - lo > 1) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (rowptr[mid] <= p) lo = mid; else hi = mid;
+   }
+   return lo;
+}
+
+__global__ __launch_bounds__(256) void row_ids_kernel(int64_t m, int64_t nnz, const int64_t *__restrict__ rowptr,
+                                                      int64_t *__restrict__ row) {
+   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += stride)
+      row[p] = row_of(rowptr, m, p);
+}
+
+__global__ __launch_bounds__(256) void make_keys_kernel(int64_t nnz, const int64_t *__restrict__ col,
+                                                        uint32_t *__restrict__ keys, uint32_t *__restrict__ pos) {
+   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += stride) {
+      keys[p] = (uint32_t)col[p];
+      pos[p] = (uint32_t)p;
+   }
+}
+
+// colptr[c] = first CSC position whose column is >= c  (keys sorted ascending)
+__global__ __launch_bounds__(256) void colptr_kernel(int64_t n, int64_t nnz, const uint32_t *__restrict__ keys,
+                                                     int64_t *__restrict__ colptr) {
+   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+   for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c <= n; c += stride) {
+      int64_t lo = 0, hi = nnz;   // first index in [0, nnz] with keys[idx] >= c
+      while (lo < hi) {
+         const int64_t mid = (lo + hi) >> 1;
+         if ((int64_t)keys[mid] < c) lo = mid + 1; else hi = mid;
+      }
+      colptr[c] = lo;
+   }
+}
+
+__global__ __launch_bounds__(256) void finalize_kernel(int64_t m, int64_t nnz, const int64_t *__restrict__ rowptr,
+                                                       const float *__restrict__ val, int mean_scale,
+                                                       const uint32_t *__restrict__ pos_sorted,
+                                                       int64_t *__restrict__ csr2csc, int64_t *__restrict__ row_t,
+                                                       float *__restrict__ val_t) {
+   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nnz; q += stride) {
+      const int64_t p = (int64_t)pos_sorted[q];
+      const int64_t r = row_of(rowptr, m, p);
+      if (csr2csc) csr2csc[q] = p;
+      if (row_t) row_t[q] = r;
+      if (val_t) {
+         float v = val ? val[p] : 1.0f;
+         if (mean_scale) {
+            const int64_t deg = rowptr[r + 1] - rowptr[r];
+            v = v / (float)(deg > 1 ? deg : 1);
+         }
+         val_t[q] = v;
+      }
+   }
+}
+
+static inline unsigned grid_for(int64_t n) {
+   int64_t b = (n + 255) / 256;
+   if (b < 1) b = 1;
+   if (b > 256 * 16) b = 256 * 16;
+   return (unsigned)b;
+}
+
+static inline unsigned key_bits(int64_t n) {
+   unsigned bits = 1;
+   while (bits < 32 && ((int64_t)1 << bits) < n) bits++;
+   return bits;
+}
+
+static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static hipError_t sort_temp_bytes(int64_t n, int64_t nnz, size_t *bytes) {
+   *bytes = 0;
+   return rocprim::radix_sort_pairs<rocprim::default_config, const uint32_t *, uint32_t *, const uint32_t *, uint32_t *>(
+       nullptr, *bytes, nullptr, nullptr, nullptr, nullptr, (size_t)nnz, 0u, key_bits(n), (hipStream_t)0, false);
+}
+
+}  // namespace isplib
+
+using namespace isplib;
+
+extern "C" int isplib_csr_row_ids_hip(int64_t m, int64_t nnz, const int64_t *rowptr, int64_t *row, void *stream) {
+   clear_error();
+   if (m < 0 || nnz < 0) return fail(ISPLIB_FAIL, "isplib_csr_row_ids_hip: negative dimension");
+   if (nnz == 0) return ISPLIB_SUCCESS;
+   if (!rowptr || !row || m == 0) return fail(ISPLIB_FAIL, "isplib_csr_row_ids_hip: null operand");
+   hipLaunchKernelGGL(row_ids_kernel, dim3(grid_for(nnz)), dim3(256), 0, (hipStream_t)stream, m, nnz, rowptr, row);
+   return check_launch("row_ids_kernel");
+}
+
+extern "C" size_t isplib_csr2csc_workspace_bytes(int64_t m, int64_t n, int64_t nnz) {
+   (void)m;
+   if (nnz <= 0) return 256;
+   size_t temp = 0;
+   if (sort_temp_bytes(n, nnz, &temp) != hipSuccess) return 0;
+   return 4 * align_up((size_t)nnz * sizeof(uint32_t)) + align_up(temp) + 256;
+}
+
+extern "C" int isplib_csr2csc_hip(int64_t m, int64_t n, int64_t nnz, const int64_t *rowptr, const int64_t *col,
+                                  const float *val, int mean_scale, int64_t *colptr, int64_t *csr2csc,
+                                  int64_t *row_t, float *val_t, void *workspace, size_t workspace_bytes,
+                                  void *stream) {
+   clear_error();
+   if (m < 0 || n < 0 || nnz < 0) return fail(ISPLIB_FAIL, "isplib_csr2csc_hip: negative dimension");
+   if (n > 0x7fffffffLL || nnz > 0xffffffffLL) return fail(ISPLIB_FAIL, "isplib_csr2csc_hip: n < 2^31 and nnz < 2^32 required");
+   if (!colptr) return fail(ISPLIB_FAIL, "isplib_csr2csc_hip: colptr is required");
+   hipStream_t st = (hipStream_t)stream;
+   if (nnz == 0) {
+      ISPLIB_HIP_TRY(hipMemsetAsync(colptr, 0, (size_t)(n + 1) * sizeof(int64_t), st));
+      return ISPLIB_SUCCESS;
+   }
+   if (!rowptr || !col || !workspace) return fail(ISPLIB_FAIL, "isplib_csr2csc_hip: null operand");
+   size_t temp = 0;
+   ISPLIB_HIP_TRY(sort_temp_bytes(n, nnz, &temp));
+   const size_t arr = align_up((size_t)nnz * sizeof(uint32_t));
+   if (workspace_bytes < 4 * arr + align_up(temp)) return fail(ISPLIB_NOT_ENOUGH_MEM, "isplib_csr2csc_hip: workspace too small");
+   char *w = (char *)workspace;
+   uint32_t *keys_in = (uint32_t *)w;
+   uint32_t *keys_out = (uint32_t *)(w + arr);
+   uint32_t *pos_in = (uint32_t *)(w + 2 * arr);
+   uint32_t *pos_out = (uint32_t *)(w + 3 * arr);
+   void *tmp = (void *)(w + 4 * arr);
+
+   hipLaunchKernelGGL(make_keys_kernel, dim3(grid_for(nnz)), dim3(256), 0, st, nnz, col, keys_in, pos_in);
+   int rc = check_launch("make_keys_kernel");
+   if (rc) return rc;
+   ISPLIB_HIP_TRY((rocprim::radix_sort_pairs<rocprim::default_config, const uint32_t *, uint32_t *, const uint32_t *, uint32_t *>(
+       tmp, temp, keys_in, keys_out, pos_in, pos_out, (size_t)nnz, 0u, key_bits(n), st, false)));
+   hipLaunchKernelGGL(colptr_kernel, dim3(grid_for(n + 1)), dim3(256), 0, st, n, nnz, keys_out, colptr);
+   rc = check_launch("colptr_kernel");
+   if (rc) return rc;
+   if (csr2csc || row_t || val_t) {
+      hipLaunchKernelGGL(finalize_kernel, dim3(grid_for(nnz)), dim3(256), 0, st, m, nnz, rowptr, val, mean_scale,
+                         pos_out, csr2csc, row_t, val_t);
+      rc = check_launch("finalize_kernel");
+   }
+   return rc;
+}

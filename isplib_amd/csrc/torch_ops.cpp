@@ -1,0 +1,300 @@
+// torch_ops.cpp -- torch.ops.isplib.* for device tensors, on top of the C ABI.
+//
+// Mirrors the reference's operator + autograd layer (csrc/fusedmm.cpp:206-570):
+// same op names and argument lists, same saved-for-backward operands, same
+// backward formulas -- with the launcher (csrc/fusedmm.cpp:113-203) replaced by
+// fusedMM_csr_hip and the ATen scatter chain of max/min backward replaced by
+// one fused kernel.  Host-side only: no kernels here, torch is used for memory,
+// the current stream and autograd bookkeeping.
+//
+// Deliberate differences from the reference (each is a defect there):
+//   * tensors must live on the GPU; there is NO CPU path (a CPU tensor raises).
+//   * value == None means unit weights and the value stream is never read (the
+//     reference substitutes ones_like(col), an int64 tensor, :241,:329).
+//   * the cached transpose operands (value_index_select / row_index_select /
+//     new_row / new_rowcount) may be None: they are then built on the device
+//     when backward needs them (the reference dereferences them blindly,
+//     :246-247,:333).
+//   * grad_value of sum/mean is computed (SDDMM); the reference returns an
+//     undefined tensor (:268-272,:349-353).
+//   * outputs are torch::empty: the kernel writes every element, including the
+//     0 / nnz the reference gets from zeros()/full_like() fills (:147-152,171).
+#include <ATen/ATen.h>
+#include <c10/hip/HIPGuard.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/csrc/autograd/custom_function.h>
+#include <torch/library.h>
+
+#include <tuple>
+
+#include "../../include/isplib_hip.h"
+
+namespace {
+
+using at::Tensor;
+using c10::optional;
+using torch::autograd::AutogradContext;
+using torch::autograd::Variable;
+using torch::autograd::variable_list;
+
+enum Reduction { R_SUM = 0, R_MAX = 1, R_MIN = 2, R_MEAN = 3 };   // codes of csrc/fusedmm.cpp:168-186
+
+void check_status(int st, const char *what) {
+   TORCH_CHECK(st == ISPLIB_SUCCESS, what, " failed with status ", st, ": ", isplib_hip_last_error());
+}
+
+void check_index(const Tensor &t, const char *name) {
+   TORCH_CHECK(t.defined(), "isplib: `", name, "` is missing");
+   TORCH_CHECK(t.is_cuda(), "isplib: `", name, "` must be a GPU tensor -- isplib_amd has no CPU path");
+   TORCH_CHECK(t.scalar_type() == at::kLong, "isplib: `", name, "` must be int64 (csrc/fusedmm.cpp:43)");
+}
+
+void check_float(const Tensor &t, const char *name) {
+   TORCH_CHECK(t.defined(), "isplib: `", name, "` is missing");
+   TORCH_CHECK(t.is_cuda(), "isplib: `", name, "` must be a GPU tensor -- isplib_amd has no CPU path");
+   TORCH_CHECK(t.scalar_type() == at::kFloat, "isplib: `", name, "` must be float32 (csrc/fusedmm.cpp:44)");
+}
+
+void *current_stream(const Tensor &t) { return (void *)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+
+// fusedmm_spmm_fw, csrc/fusedmm.cpp:113-203
+std::tuple<Tensor, Tensor> spmm_fw(const Tensor &rowptr_, const Tensor &col_, const optional<Tensor> &value_,
+                                   const Tensor &mat_, int reduction) {
+   check_index(rowptr_, "rowptr");
+   check_index(col_, "col");
+   check_float(mat_, "mat");
+   TORCH_CHECK(mat_.dim() == 2, "isplib: `mat` must be 2-D [N, K] (csrc/fusedmm.cpp:121-122)");
+   TORCH_CHECK(rowptr_.dim() == 1 && rowptr_.numel() >= 1, "isplib: `rowptr` must be 1-D with M+1 entries");
+   c10::hip::HIPGuard guard(mat_.device());
+   const Tensor rowptr = rowptr_.contiguous(), col = col_.contiguous(), mat = mat_.contiguous();   // :140
+   Tensor value;
+   if (value_.has_value() && value_->defined()) {
+      check_float(*value_, "value");
+      value = value_->contiguous();
+      TORCH_CHECK(value.numel() == col.numel(), "isplib: `value` and `col` differ in length");
+   }
+   TORCH_CHECK(rowptr.device() == mat.device() && col.device() == mat.device(), "isplib: operands on different devices");
+   const int64_t M = rowptr.numel() - 1, N = mat.size(0), K = mat.size(1), nnz = col.numel();
+   Tensor out = at::empty({M, K}, mat.options());
+   Tensor arg;
+   int32_t msg = ISPLIB_MSG_SPMM_SUM;
+   if (reduction == R_MAX) msg = ISPLIB_MSG_SPMM_MAX;
+   if (reduction == R_MIN) msg = ISPLIB_MSG_SPMM_MIN;
+   if (reduction == R_MEAN) msg = ISPLIB_MSG_SPMM_MEAN;
+   if (reduction == R_MAX || reduction == R_MIN) arg = at::empty({M, K}, rowptr.options());
+   const int64_t *rp = rowptr.data_ptr<int64_t>();
+   const int st = fusedMM_csr_hip(msg, M, N, K, 1.0f, nnz, M, N, value.defined() ? value.data_ptr<float>() : nullptr,
+                                  col.data_ptr<int64_t>(), rp, rp + 1, nullptr, K, mat.data_ptr<float>(), K, 0.0f,
+                                  out.data_ptr<float>(), K, arg.defined() ? arg.data_ptr<int64_t>() : nullptr,
+                                  current_stream(mat));
+   check_status(st, "fusedMM_csr_hip");
+   return std::make_tuple(out, arg);
+}
+
+struct Transposed {
+   Tensor colptr, row_t, val_t;
+};
+
+// A^T operands built on the device (isplib/__init__.py:79-80 / :86-99 equivalents)
+Transposed build_transpose(const Tensor &rowptr, const Tensor &col, const Tensor &value, int64_t ncols, bool mean) {
+   c10::hip::HIPGuard guard(col.device());
+   const int64_t M = rowptr.numel() - 1, nnz = col.numel();
+   Transposed t;
+   t.colptr = at::empty({ncols + 1}, rowptr.options());
+   t.row_t = at::empty({nnz}, rowptr.options());
+   t.val_t = at::empty({nnz}, col.options().dtype(at::kFloat));
+   const size_t ws = isplib_csr2csc_workspace_bytes(M, ncols, nnz);
+   TORCH_CHECK(ws > 0, "isplib_csr2csc_workspace_bytes failed: ", isplib_hip_last_error());
+   Tensor work = at::empty({(int64_t)ws}, col.options().dtype(at::kByte));
+   const int st = isplib_csr2csc_hip(M, ncols, nnz, rowptr.data_ptr<int64_t>(), col.data_ptr<int64_t>(),
+                                     value.defined() ? value.data_ptr<float>() : nullptr, mean ? 1 : 0,
+                                     t.colptr.data_ptr<int64_t>(), nullptr, t.row_t.data_ptr<int64_t>(),
+                                     t.val_t.data_ptr<float>(), work.data_ptr(), ws, current_stream(col));
+   check_status(st, "isplib_csr2csc_hip");
+   return t;
+}
+
+Tensor sddmm(const Tensor &rowptr, const Tensor &col, const Tensor &mat, const Tensor &grad_out, bool mean) {
+   c10::hip::HIPGuard guard(mat.device());
+   const Tensor g = grad_out.contiguous(), y = mat.contiguous();
+   const int64_t M = rowptr.numel() - 1, K = y.size(1);
+   Tensor dval = at::empty({col.numel()}, y.options());
+   const int64_t *rp = rowptr.data_ptr<int64_t>();
+   const int st = isplib_sddmm_csr_hip(M, K, col.data_ptr<int64_t>(), rp, rp + 1, y.data_ptr<float>(), K,
+                                       g.data_ptr<float>(), K, mean ? 1 : 0, dval.data_ptr<float>(), current_stream(y));
+   check_status(st, "isplib_sddmm_csr_hip");
+   return dval;
+}
+
+Tensor or_undef(const optional<Tensor> &t) { return t.has_value() ? *t : Tensor(); }
+
+// ---- sum: csrc/fusedmm.cpp:210-294 ---------------------------------------------------------
+class SpmmSum : public torch::autograd::Function<SpmmSum> {
+ public:
+   static variable_list forward(AutogradContext *ctx, optional<Variable> opt_row, Variable rowptr, Variable col,
+                                optional<Variable> opt_value, optional<Variable> opt_colptr,
+                                optional<Variable> opt_csr2csc, Variable mat, optional<Variable> value_index_select,
+                                optional<Variable> row_index_select) {
+      const bool has_value = opt_value.has_value() && opt_value->defined();
+      auto out = std::get<0>(spmm_fw(rowptr, col, opt_value, mat, R_SUM));   // :244
+      ctx->saved_data["has_value"] = has_value;
+      ctx->save_for_backward({or_undef(opt_row), rowptr, col, or_undef(opt_value), or_undef(opt_colptr),
+                              or_undef(opt_csr2csc), mat, or_undef(value_index_select), or_undef(row_index_select)});
+      return {out};
+   }
+
+   static variable_list backward(AutogradContext *ctx, variable_list grad_outs) {
+      const bool has_value = ctx->saved_data["has_value"].toBool();
+      auto grad_out = grad_outs[0];
+      auto saved = ctx->get_saved_variables();
+      auto rowptr = saved[1], col = saved[2], value = saved[3], colptr = saved[4], mat = saved[6],
+           value_sel = saved[7], row_sel = saved[8];
+
+      auto grad_value = Variable();
+      if (has_value && ctx->needs_input_grad(3))                             // :269-272 (SDDMM, commented out there)
+         grad_value = sddmm(rowptr, col, mat, grad_out, false);
+
+      auto grad_mat = Variable();
+      if (ctx->needs_input_grad(6)) {
+         // :285  grad_mat = fusedmm_spmm_fw(colptr, row_index_select, value_index_select, grad_out)
+         if (colptr.defined() && row_sel.defined() && (value_sel.defined() || !has_value)) {
+            optional<Tensor> v = has_value ? optional<Tensor>(value_sel) : c10::nullopt;
+            grad_mat = std::get<0>(spmm_fw(colptr, row_sel, v, grad_out, R_SUM));
+         } else {
+            auto t = build_transpose(rowptr, col, has_value ? value : Tensor(), mat.size(0), false);
+            optional<Tensor> v = has_value ? optional<Tensor>(t.val_t) : c10::nullopt;
+            grad_mat = std::get<0>(spmm_fw(t.colptr, t.row_t, v, grad_out, R_SUM));
+         }
+      }
+      return {Variable(), Variable(), Variable(), grad_value, Variable(), Variable(), grad_mat, Variable(), Variable()};
+   }
+};
+
+// ---- mean: csrc/fusedmm.cpp:296-384 --------------------------------------------------------
+class SpmmMean : public torch::autograd::Function<SpmmMean> {
+ public:
+   static variable_list forward(AutogradContext *ctx, optional<Variable> opt_row, Variable rowptr, Variable col,
+                                optional<Variable> opt_value, optional<Variable> opt_rowcount,
+                                optional<Variable> opt_colptr, optional<Variable> opt_csr2csc, Variable mat,
+                                optional<Variable> new_row, optional<Variable> new_rowcount) {
+      const bool has_value = opt_value.has_value() && opt_value->defined();
+      auto out = std::get<0>(spmm_fw(rowptr, col, opt_value, mat, R_MEAN));   // :331
+      ctx->saved_data["has_value"] = has_value;
+      ctx->save_for_backward({or_undef(opt_row), rowptr, col, or_undef(opt_value), or_undef(opt_rowcount),
+                              or_undef(opt_colptr), or_undef(opt_csr2csc), mat, or_undef(new_row),
+                              or_undef(new_rowcount)});
+      return {out};
+   }
+
+   static variable_list backward(AutogradContext *ctx, variable_list grad_outs) {
+      const bool has_value = ctx->saved_data["has_value"].toBool();
+      auto grad_out = grad_outs[0];
+      auto saved = ctx->get_saved_variables();
+      auto rowptr = saved[1], col = saved[2], value = saved[3], colptr = saved[5], mat = saved[7], new_row = saved[8],
+           new_rowcount = saved[9];
+
+      auto grad_value = Variable();
+      if (has_value && ctx->needs_input_grad(3)) grad_value = sddmm(rowptr, col, mat, grad_out, true);   // :350-353
+
+      auto grad_mat = Variable();
+      if (ctx->needs_input_grad(7)) {
+         // :375  grad_mat = fusedmm_spmm_fw(colptr, new_row, new_rowcount, grad_out)   (a SUM on A^T)
+         const bool cached = colptr.defined() && new_row.defined() && new_rowcount.defined() &&
+                             new_row.numel() == col.numel() && new_rowcount.numel() == col.numel() &&
+                             new_rowcount.scalar_type() == at::kFloat && new_row.is_cuda();
+         if (cached) {
+            grad_mat = std::get<0>(spmm_fw(colptr, new_row, optional<Tensor>(new_rowcount), grad_out, R_SUM));
+         } else {
+            auto t = build_transpose(rowptr, col, has_value ? value : Tensor(), mat.size(0), true);
+            grad_mat = std::get<0>(spmm_fw(t.colptr, t.row_t, optional<Tensor>(t.val_t), grad_out, R_SUM));
+         }
+      }
+      return {Variable(), Variable(), Variable(), grad_value, Variable(), Variable(),
+              Variable(), grad_mat,   Variable(), Variable()};
+   }
+};
+
+// ---- max / min: csrc/fusedmm.cpp:386-452, 454-518 ------------------------------------------
+template <int RED>
+class SpmmMinMax : public torch::autograd::Function<SpmmMinMax<RED>> {
+ public:
+   static variable_list forward(AutogradContext *ctx, Variable rowptr, Variable col, optional<Variable> opt_value,
+                                Variable mat) {
+      const bool has_value = opt_value.has_value() && opt_value->defined();
+      auto result = spmm_fw(rowptr, col, opt_value, mat, RED);   // :397 / :465
+      auto out = std::get<0>(result);
+      auto arg_out = std::get<1>(result);
+      ctx->saved_data["has_value"] = has_value;
+      ctx->save_for_backward({col, or_undef(opt_value), mat, arg_out});
+      ctx->mark_non_differentiable({arg_out});                    // :403 / :470
+      return {out, arg_out};
+   }
+
+   static variable_list backward(AutogradContext *ctx, variable_list grad_outs) {
+      const bool has_value = ctx->saved_data["has_value"].toBool();
+      auto saved = ctx->get_saved_variables();
+      auto col = saved[0], value = saved[1], mat = saved[2], arg_out = saved[3];
+      const Tensor grad_out = grad_outs[0].contiguous();
+      const bool need_val = has_value && ctx->needs_input_grad(2);
+      const bool need_mat = ctx->needs_input_grad(3);
+      auto grad_value = Variable(), grad_mat = Variable();
+      if (need_val || need_mat) {
+         c10::hip::HIPGuard guard(mat.device());
+         const Tensor y = mat.contiguous();
+         const int64_t M = arg_out.size(0), N = y.size(0), K = y.size(1), nnz = col.numel();
+         if (need_val) grad_value = at::empty({nnz}, y.options());
+         if (need_mat) grad_mat = at::empty({N, K}, y.options());
+         // one fused pass for :417-446 (mask, gather, mul, masked_fill, scatter_add x2)
+         const int st = isplib_spmm_minmax_bw_hip(
+             M, N, K, nnz, col.data_ptr<int64_t>(), has_value ? value.data_ptr<float>() : nullptr, y.data_ptr<float>(),
+             arg_out.data_ptr<int64_t>(), grad_out.data_ptr<float>(), need_mat ? grad_mat.data_ptr<float>() : nullptr,
+             need_val ? grad_value.data_ptr<float>() : nullptr, current_stream(y));
+         check_status(st, "isplib_spmm_minmax_bw_hip");
+      }
+      return {Variable(), Variable(), grad_value, grad_mat};
+   }
+};
+
+// ---- op wrappers: csrc/fusedmm.cpp:520-563 -------------------------------------------------
+Tensor fusedmm_spmm_add(optional<Tensor> opt_row, Tensor rowptr, Tensor col, optional<Tensor> opt_value,
+                        optional<Tensor> opt_colptr, optional<Tensor> opt_csr2csc, Tensor mat,
+                        optional<Tensor> value_index_select, optional<Tensor> row_index_select) {
+   return SpmmSum::apply(opt_row, rowptr, col, opt_value, opt_colptr, opt_csr2csc, mat, value_index_select,
+                         row_index_select)[0];
+}
+
+Tensor fusedmm_spmm_mean(optional<Tensor> opt_row, Tensor rowptr, Tensor col, optional<Tensor> opt_value,
+                         optional<Tensor> opt_rowcount, optional<Tensor> opt_colptr, optional<Tensor> opt_csr2csc,
+                         Tensor mat, optional<Tensor> new_row, optional<Tensor> new_rowcount) {
+   return SpmmMean::apply(opt_row, rowptr, col, opt_value, opt_rowcount, opt_colptr, opt_csr2csc, mat, new_row,
+                          new_rowcount)[0];
+}
+
+std::tuple<Tensor, Tensor> fusedmm_spmm_max(Tensor rowptr, Tensor col, optional<Tensor> opt_value, Tensor mat) {
+   auto r = SpmmMinMax<R_MAX>::apply(rowptr, col, opt_value, mat);
+   return std::make_tuple(r[0], r[1]);
+}
+
+std::tuple<Tensor, Tensor> fusedmm_spmm_min(Tensor rowptr, Tensor col, optional<Tensor> opt_value, Tensor mat) {
+   auto r = SpmmMinMax<R_MIN>::apply(rowptr, col, opt_value, mat);
+   return std::make_tuple(r[0], r[1]);
+}
+
+void performDummySpMM(int64_t flag) { performDummySpMM_hip(flag, (void *)c10::hip::getCurrentHIPStream().stream()); }
+
+}  // namespace
+
+// schemas as registered at csrc/fusedmm.cpp:565-570
+TORCH_LIBRARY(isplib, m) {
+   m.def("fusedmm_spmm(Tensor? row, Tensor rowptr, Tensor col, Tensor? value, Tensor? colptr, Tensor? csr2csc, "
+         "Tensor mat, Tensor? value_index_select, Tensor? row_index_select) -> Tensor",
+         &fusedmm_spmm_add);
+   m.def("fusedmm_spmm_mean(Tensor? row, Tensor rowptr, Tensor col, Tensor? value, Tensor? rowcount, Tensor? colptr, "
+         "Tensor? csr2csc, Tensor mat, Tensor? new_row, Tensor? new_rowcount) -> Tensor",
+         &fusedmm_spmm_mean);
+   m.def("fusedmm_spmm_max(Tensor rowptr, Tensor col, Tensor? value, Tensor mat) -> (Tensor, Tensor)",
+         &fusedmm_spmm_max);
+   m.def("fusedmm_spmm_min(Tensor rowptr, Tensor col, Tensor? value, Tensor mat) -> (Tensor, Tensor)",
+         &fusedmm_spmm_min);
+   m.def("performDummySpMM(int flag) -> ()", &performDummySpMM);
+}

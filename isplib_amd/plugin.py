@@ -1,0 +1,180 @@
+"""iSpLibPlugin -- the reference's drop-in surface (isplib/__init__.py:34-210).
+
+``iSpLibPlugin.patch_pyg()`` swaps ``torch_sparse.matmul`` and
+``torch.sparse.mm`` for ``spmm_autotuned`` so that PyG's GCNConv / SAGEConv /
+GINConv, which aggregate through ``torch_sparse.matmul(adj_t, x, reduce)``, run
+on the HIP kernels unchanged; ``unpatch_pyg()`` restores LIFO;
+``@isplib_autotune`` wraps a function in the pair.
+
+Differences from the reference, each a defect there:
+  * per-graph operands live on the graph's storage object (or in a table that
+    checks the tensors are still the same live objects), not in class-level
+    dicts keyed by raw data pointers that go stale (:35-40,50);
+  * a ``mean`` call no longer poisons a later ``sum`` on the same graph (:85,141);
+  * the mean-backward weights use the intended pairing
+    value[csr2csc] / max(rowcount,1)[row[csr2csc]] (csrc/fusedmm.cpp:357-364), not
+    the mixed CSR/CSC order of :86-91;
+  * unit weights are never materialised (:51-57): ``value=None`` reaches the kernel;
+  * max/min return the tensor, like ``torch_sparse.matmul`` does, not the
+    ``(out, arg)`` tuple of :143,145 (the tuple stays available at the op level);
+  * an unknown ``reduce`` raises ValueError instead of returning None (:154-155);
+  * the patched ``torch.sparse.mm`` still serves ordinary torch sparse tensors.
+"""
+from __future__ import annotations
+
+import weakref
+from typing import Optional
+
+import torch
+
+from . import _lib
+from .sparse import SparseStorage, SparseTensor
+
+_lib.load_ops()
+
+try:  # optional third-party modules the patch targets (absent in this image)
+    import torch_sparse as _torch_sparse  # type: ignore
+except Exception:  # pragma: no cover
+    _torch_sparse = None
+try:
+    import torch_geometric.typing as _pyg_typing  # type: ignore
+except Exception:  # pragma: no cover
+    _pyg_typing = None
+
+
+class _ForeignGraphs:
+    """Prepared storage for SparseTensor objects that are not ours (torch_sparse).
+    Keyed by data pointers like the reference (:50) but every hit is validated
+    against weak references to the very tensors it was built from."""
+
+    def __init__(self):
+        self._table = {}
+
+    def get(self, rowptr, col, value, sizes) -> SparseStorage:
+        key = (rowptr.data_ptr(), col.data_ptr(), 0 if value is None else value.data_ptr(), col.numel())
+        hit = self._table.get(key)
+        if hit is not None:
+            refs, versions, storage = hit
+            same = refs[0]() is rowptr and refs[1]() is col and (value is None or refs[2]() is value)
+            if same and versions == (rowptr._version, col._version, None if value is None else value._version):
+                return storage
+        self._table = {k: v for k, v in self._table.items() if all(r() is not None for r in v[0])}
+        storage = SparseStorage(rowptr, col, value, sizes)
+        refs = (weakref.ref(rowptr), weakref.ref(col), weakref.ref(value if value is not None else col))
+        self._table[key] = (refs, (rowptr._version, col._version, None if value is None else value._version), storage)
+        return storage
+
+    def clear(self):
+        self._table.clear()
+
+
+_foreign = _ForeignGraphs()
+
+
+def _storage_of(src, other: torch.Tensor) -> SparseStorage:
+    st = getattr(src, "storage", None)
+    if isinstance(st, SparseStorage):
+        return st
+    rowptr, col, value = src.csr()                                   # :49
+    try:
+        sizes = tuple(src.sparse_sizes())
+    except Exception:
+        sizes = (rowptr.numel() - 1, other.size(-2))
+    return _foreign.get(rowptr, col, value, sizes)
+
+
+def spmm_autotuned(src, other: torch.Tensor, reduce: str = "sum") -> torch.Tensor:
+    """``torch_sparse.matmul(src, other, reduce)`` on the HIP path (isplib/__init__.py:48-157)."""
+    if reduce not in ("sum", "add", "mean", "max", "min"):
+        raise ValueError(f"isplib: unknown reduce '{reduce}' (expected sum|add|mean|max|min)")
+    if not isinstance(other, torch.Tensor) or not other.is_cuda:
+        raise RuntimeError("isplib_amd: `other` must be a GPU tensor -- there is no CPU path")
+    if other.dtype != torch.float32:
+        raise TypeError(f"isplib_amd: only float32 features are supported (csrc/fusedmm.cpp:44), got {other.dtype}")
+    s = _storage_of(src, other)
+    rowptr, col, value = s._rowptr, s._col, s._value
+    if value is not None and value.dtype != other.dtype:
+        value = value.to(other.dtype)                                # :63-64
+    squeeze = other.dim() == 1
+    mat = other.unsqueeze(-1) if squeeze else other
+    needs_grad = torch.is_grad_enabled() and mat.requires_grad       # :69-73
+    ops = torch.ops.isplib
+    if reduce in ("sum", "add"):
+        if needs_grad:                                               # :76-80 (built once per graph, on the device)
+            out = ops.fusedmm_spmm(None, rowptr, col, value, s.colptr(), None, mat, s.val_t(), s.row_t())
+        else:
+            out = ops.fusedmm_spmm(None, rowptr, col, value, None, None, mat, None, None)
+    elif reduce == "mean":
+        if needs_grad:                                               # :83-99, intended pairing
+            out = ops.fusedmm_spmm_mean(None, rowptr, col, value, None, s.colptr(), None, mat, s.row_t(), s.mean_val_t())
+        else:
+            out = ops.fusedmm_spmm_mean(None, rowptr, col, value, None, None, None, mat, None, None)
+    elif reduce == "max":
+        out = ops.fusedmm_spmm_max(rowptr, col, value, mat)[0]       # :143
+    else:
+        out = ops.fusedmm_spmm_min(rowptr, col, value, mat)[0]       # :145
+    return out.squeeze(-1) if squeeze else out
+
+
+matmul = spmm_autotuned
+
+
+class iSpLibPlugin:
+    backup = []          # LIFO of (torch_sparse.matmul | None, torch.sparse.mm, WITH_PT2, WITH_PT20)
+
+    @classmethod
+    def patch_pyg(cls) -> None:
+        saved_flags = (None, None)
+        if _pyg_typing is not None:                                  # :159-171
+            saved_flags = (getattr(_pyg_typing, "WITH_PT2", None), getattr(_pyg_typing, "WITH_PT20", None))
+            _pyg_typing.WITH_PT2 = False
+            _pyg_typing.WITH_PT20 = False
+        original_mm = torch.sparse.mm
+
+        def sparse_mm(src, other, reduce: str = "sum"):
+            if hasattr(src, "csr") and hasattr(src, "storage"):
+                return spmm_autotuned(src, other, reduce)
+            return original_mm(src, other) if reduce == "sum" else original_mm(src, other, reduce)
+
+        cls.backup.append((None if _torch_sparse is None else _torch_sparse.matmul, original_mm) + saved_flags)  # :173-174
+        if _torch_sparse is not None:
+            _torch_sparse.matmul = spmm_autotuned                    # :177
+        torch.sparse.mm = sparse_mm                                  # :178
+
+    @classmethod
+    def unpatch_pyg(cls) -> None:
+        if not cls.backup:                                           # :190
+            return
+        ts_matmul, sparse_mm, pt2, pt20 = cls.backup.pop()
+        torch.sparse.mm = sparse_mm                                  # :194
+        if _torch_sparse is not None and ts_matmul is not None:
+            _torch_sparse.matmul = ts_matmul                         # :195
+        if _pyg_typing is not None:                                  # :197-201
+            if pt2 is not None:
+                _pyg_typing.WITH_PT2 = pt2
+            if pt20 is not None:
+                _pyg_typing.WITH_PT20 = pt20
+
+    @classmethod
+    def is_patched(cls) -> bool:
+        return bool(cls.backup)
+
+    @classmethod
+    def clear_cache(cls) -> None:
+        _foreign.clear()
+
+
+def isplib_autotune(fn):
+    """Decorator: run ``fn`` with the patch applied (isplib/__init__.py:204-210);
+    unlike the reference, the patch is removed even when ``fn`` raises."""
+
+    def wrapper(*args, **kwargs):
+        iSpLibPlugin.patch_pyg()
+        try:
+            return fn(*args, **kwargs)
+        finally:
+            iSpLibPlugin.unpatch_pyg()
+
+    wrapper.__name__ = getattr(fn, "__name__", "wrapper")
+    wrapper.__doc__ = getattr(fn, "__doc__", None)
+    return wrapper

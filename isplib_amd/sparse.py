@@ -1,0 +1,182 @@
+"""A minimal CSR container with exactly the members the reference wrapper touches.
+
+The reference's ``spmm_autotuned`` (isplib/__init__.py:48-157) receives a
+``torch_sparse.SparseTensor`` and uses only
+
+    src.csr()                                   -> (rowptr, col, value|None)   :49
+    src.storage._row/_rowcount/_csr2csc/_colptr    cached-only fields          :58-61
+    src.storage.row()/rowcount()/csr2csc()/colptr()  lazy getters              :67,70-73
+
+``torch_sparse`` is not part of this image, so the package ships this
+duck-typed stand-in for users and tests; ``iSpLibPlugin`` accepts either.  The
+lazy getters run on the DEVICE through the C ABI (``isplib_csr2csc_hip`` /
+``isplib_csr_row_ids_hip``), replacing torch_sparse's host-side sort.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import cabi
+
+
+class SparseStorage:
+    """CSR storage with lazily built, cached transpose operands (torch_sparse names)."""
+
+    def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, value: Optional[torch.Tensor],
+                 sparse_sizes: Tuple[int, int]):
+        self._rowptr = rowptr
+        self._col = col
+        self._value = value
+        self._sparse_sizes = (int(sparse_sizes[0]), int(sparse_sizes[1]))
+        self._row: Optional[torch.Tensor] = None
+        self._rowcount: Optional[torch.Tensor] = None
+        self._colptr: Optional[torch.Tensor] = None
+        self._csr2csc: Optional[torch.Tensor] = None
+        # A^T operands kept beside the CSC fields (what isplib/__init__.py caches in
+        # class-level dicts keyed by data pointers, :35-40,76-106)
+        self._row_t: Optional[torch.Tensor] = None
+        self._val_t: Optional[torch.Tensor] = None
+        self._mean_val_t: Optional[torch.Tensor] = None
+
+    def sparse_sizes(self) -> Tuple[int, int]:
+        return self._sparse_sizes
+
+    def rowptr(self) -> torch.Tensor:
+        return self._rowptr
+
+    def col(self) -> torch.Tensor:
+        return self._col
+
+    def value(self) -> Optional[torch.Tensor]:
+        return self._value
+
+    def row(self) -> torch.Tensor:
+        if self._row is None:
+            self._row = cabi.csr_row_ids(self._rowptr, self._col.numel())
+        return self._row
+
+    def rowcount(self) -> torch.Tensor:
+        if self._rowcount is None:
+            self._rowcount = self._rowptr[1:] - self._rowptr[:-1]
+        return self._rowcount
+
+    def _build_transpose(self) -> None:
+        colptr, perm, row_t, val_t = cabi.csr2csc(self._rowptr, self._col, self._value, self._sparse_sizes[1],
+                                                  want_val=self._value is not None)
+        self._colptr, self._csr2csc, self._row_t, self._val_t = colptr, perm, row_t, val_t
+
+    def colptr(self) -> torch.Tensor:
+        if self._colptr is None:
+            self._build_transpose()
+        return self._colptr
+
+    def csr2csc(self) -> torch.Tensor:
+        if self._csr2csc is None:
+            self._build_transpose()
+        return self._csr2csc
+
+    # -- A^T operands (not torch_sparse API; used by the plug-in's per-graph cache) --
+    def row_t(self) -> torch.Tensor:
+        if self._row_t is None:
+            self._build_transpose()
+        return self._row_t
+
+    def val_t(self) -> Optional[torch.Tensor]:
+        if self._value is not None and self._val_t is None:
+            self._build_transpose()
+        return self._val_t
+
+    def mean_val_t(self) -> torch.Tensor:
+        """value[csr2csc] / max(rowcount,1)[row[csr2csc]] (csrc/fusedmm.cpp:357-364)."""
+        if self._mean_val_t is None:
+            _, _, _, self._mean_val_t = cabi.csr2csc(self._rowptr, self._col, self._value, self._sparse_sizes[1],
+                                                     mean_scale=True, want_perm=False, want_row=False)
+        return self._mean_val_t
+
+
+class SparseTensor:
+    """CSR sparse matrix; constructor arguments follow torch_sparse.SparseTensor
+    (README.md:105-110: row, col, value, sparse_sizes)."""
+
+    def __init__(self, row: Optional[torch.Tensor] = None, rowptr: Optional[torch.Tensor] = None,
+                 col: Optional[torch.Tensor] = None, value: Optional[torch.Tensor] = None,
+                 sparse_sizes: Optional[Tuple[int, int]] = None, is_sorted: bool = False, validate: bool = True):
+        if col is None:
+            raise ValueError("SparseTensor: `col` is required")
+        if rowptr is None:
+            if row is None:
+                raise ValueError("SparseTensor: one of `row` / `rowptr` is required")
+            if sparse_sizes is None:
+                m = int(row.max()) + 1 if row.numel() else 0
+                n = int(col.max()) + 1 if col.numel() else 0
+                sparse_sizes = (m, n)
+            m, n = int(sparse_sizes[0]), int(sparse_sizes[1])
+            if not is_sorted and row.numel():
+                # torch_sparse order: by row, then column; equal keys keep input order
+                perm = torch.sort(row * max(n, 1) + col, stable=True).indices
+                row, col = row[perm], col[perm]
+                value = value[perm] if value is not None else None
+            counts = torch.bincount(row, minlength=m) if row.numel() else torch.zeros(m, dtype=torch.int64, device=col.device)
+            rowptr = torch.zeros(m + 1, dtype=torch.int64, device=col.device)
+            torch.cumsum(counts, 0, out=rowptr[1:])
+        elif sparse_sizes is None:
+            sparse_sizes = (rowptr.numel() - 1, int(col.max()) + 1 if col.numel() else 0)
+        if validate:
+            m, n = int(sparse_sizes[0]), int(sparse_sizes[1])
+            if rowptr.numel() != m + 1:
+                raise ValueError("SparseTensor: rowptr must have M+1 entries")
+            if col.numel():
+                lo, hi = int(col.min()), int(col.max())
+                if lo < 0 or hi >= n:
+                    raise ValueError(f"SparseTensor: column index out of range [0, {n})")
+                if int(rowptr[0]) != 0 or int(rowptr[-1]) != col.numel() or bool((rowptr[1:] < rowptr[:-1]).any()):
+                    raise ValueError("SparseTensor: rowptr is not a monotone prefix of nnz")
+            if value is not None and value.numel() != col.numel():
+                raise ValueError("SparseTensor: value and col differ in length")
+        self.storage = SparseStorage(rowptr.to(torch.int64).contiguous(), col.to(torch.int64).contiguous(),
+                                     value.contiguous() if value is not None else None, sparse_sizes)
+
+    @classmethod
+    def from_csr(cls, rowptr, col, value=None, sparse_sizes=None, validate=True) -> "SparseTensor":
+        return cls(rowptr=rowptr, col=col, value=value, sparse_sizes=sparse_sizes, validate=validate)
+
+    def csr(self):
+        s = self.storage
+        return s._rowptr, s._col, s._value
+
+    def sparse_sizes(self) -> Tuple[int, int]:
+        return self.storage.sparse_sizes()
+
+    def size(self, dim: int) -> int:
+        return self.storage.sparse_sizes()[dim]
+
+    def nnz(self) -> int:
+        return self.storage._col.numel()
+
+    @property
+    def device(self):
+        return self.storage._col.device
+
+    def to(self, device) -> "SparseTensor":
+        s = self.storage
+        return SparseTensor(rowptr=s._rowptr.to(device), col=s._col.to(device),
+                            value=None if s._value is None else s._value.to(device),
+                            sparse_sizes=s._sparse_sizes, validate=False)
+
+    def cuda(self) -> "SparseTensor":
+        return self.to("cuda")
+
+    def t(self) -> "SparseTensor":
+        """Transpose (CSR of A^T), built on the device."""
+        s = self.storage
+        colptr, row_t, val_t = s.colptr(), s.row_t(), s.val_t()
+        return SparseTensor(rowptr=colptr, col=row_t, value=val_t,
+                            sparse_sizes=(s._sparse_sizes[1], s._sparse_sizes[0]), validate=False)
+
+    def matmul(self, other: torch.Tensor, reduce: str = "sum") -> torch.Tensor:
+        from .plugin import matmul
+        return matmul(self, other, reduce)
+
+    __matmul__ = matmul

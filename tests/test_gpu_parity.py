@@ -1,0 +1,145 @@
+"""GPU parity: the HIP path, called through the C ABI, against the CPU oracle on
+the same seeded inputs.  Bar: max/min values and arg indices BIT-EXACT; sum/mean
+within 1e-5 * sum|val*x| per element (BASELINE.json north_star: 1e-5 relative fp32).
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _assert_sum_close(got, ref, tol):
+    got = np.asarray(got)
+    fin = np.isfinite(ref) & np.isfinite(tol)
+    assert np.array_equal(np.isnan(got[~fin]), np.isnan(ref[~fin]))
+    inf = ~fin & ~np.isnan(ref)
+    assert np.array_equal(got[inf], ref[inf])
+    err = np.abs(got[fin].astype(np.float64) - ref[fin].astype(np.float64))
+    assert np.all(err <= tol[fin]), f"max err/tol = {np.max(err / tol[fin])}"
+
+
+def _run_all(gpu, oracle, rowptr, col, val, x, unit=False):
+    from isplib_amd import cabi
+    d_rowptr, d_col, d_x = _t(rowptr, gpu), _t(col, gpu), _t(x, gpu)
+    d_val = None if unit else _t(val, gpu)
+    tol = cases.sum_tolerance(oracle, rowptr, col, val, x)
+    for red in cases.REDUCES:
+        ref, ref_arg = oracle.spmm_fw(rowptr, col, val, x, red)
+        out, arg = cabi.spmm(d_rowptr, d_col, d_val, d_x, red)
+        torch.cuda.synchronize()
+        out = out.cpu().numpy()
+        if red in ("sum", "mean"):
+            _assert_sum_close(out, ref, tol)
+        else:
+            assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), f"{red}: values not bit-exact"
+            assert np.array_equal(arg.cpu().numpy(), ref_arg), f"{red}: arg indices differ"
+
+
+@pytest.mark.parametrize("k", cases.WIDTHS)
+def test_widths_weighted(gpu, oracle_mod, k):
+    rowptr, col = cases.random_csr(300, 257, 9.0, seed=10 + k, empty_rows=(0, 150, 299))
+    val = cases.weights(col.size, 4)
+    x = cases.dense(257, k, 3)
+    _run_all(gpu, oracle_mod, rowptr, col, val, x)
+
+
+@pytest.mark.parametrize("k", (16, 41, 128))
+def test_unit_weights_skip_value_stream(gpu, oracle_mod, k):
+    rowptr, col = cases.random_csr(200, 200, 12.0, seed=77)
+    val = cases.weights(col.size, 0, "unit")
+    x = cases.dense(200, k, 3)
+    _run_all(gpu, oracle_mod, rowptr, col, val, x, unit=True)
+
+
+@pytest.mark.parametrize("kind", ("integer", "constant", "signed_zero", "nonfinite"))
+@pytest.mark.parametrize("k", (64, 100))
+def test_ties_and_nonfinite(gpu, oracle_mod, kind, k):
+    rowptr, col = cases.random_csr(128, 96, 20.0, seed=5, empty_rows=(3,), duplicates=True)
+    val = cases.weights(col.size, 4, "signed_int" if kind != "constant" else "unit")
+    x = cases.dense(96, k, 3, kind)
+    _run_all(gpu, oracle_mod, rowptr, col, val, x)
+
+
+@pytest.mark.parametrize("k", (32, 128, 602))
+def test_hub_row_uses_workgroup_split(gpu, oracle_mod, k):
+    # one row far above the long-row threshold (2048) + degree-1 and empty rows around it
+    rowptr, col = cases.random_csr(64, 5000, 3.0, seed=9, empty_rows=(0, 63), hub=(17, 12345))
+    val = cases.weights(col.size, 4)
+    x = cases.dense(5000, k, 3, "integer" if k == 32 else "uniform")
+    _run_all(gpu, oracle_mod, rowptr, col, val, x)
+
+
+def test_rectangular_and_tiny(gpu, oracle_mod):
+    for m, n in ((1, 1), (3, 1000), (1000, 3), (65, 63)):
+        rowptr, col = cases.random_csr(m, n, 5.0, seed=m * 7 + n)
+        val = cases.weights(col.size, 4)
+        x = cases.dense(n, 20, 3)
+        _run_all(gpu, oracle_mod, rowptr, col, val, x)
+
+
+def test_all_rows_empty(gpu, oracle_mod):
+    rowptr = np.zeros(11, np.int64)
+    col = np.zeros(0, np.int64)
+    val = np.zeros(0, np.float32)
+    x = cases.dense(7, 16, 3)
+    _run_all(gpu, oracle_mod, rowptr, col, val, x)
+
+
+def test_reference_known_answers(gpu, oracle_mod):
+    from isplib_amd import cabi
+    rowptr, col, val, x, e_sum, e_max, e_arg = cases.readme_case()
+    d = [_t(a, gpu) for a in (rowptr, col, val, x)]
+    out, _ = cabi.spmm(*d, "sum")
+    assert np.array_equal(out.cpu().numpy(), e_sum)
+    out, arg = cabi.spmm(*d, "max")
+    assert np.array_equal(out.cpu().numpy(), e_max) and np.array_equal(arg.cpu().numpy(), e_arg)
+    rowptr, col, val, x, e = cases.gpu_toy_case()
+    out, _ = cabi.spmm(*[_t(a, gpu) for a in (rowptr, col, val, x)], "sum")
+    assert np.array_equal(out.cpu().numpy(), e)
+
+
+def test_strided_operands_through_leading_dimensions(gpu, oracle_mod):
+    from isplib_amd import cabi
+    rowptr, col = cases.random_csr(90, 80, 7.0, seed=21)
+    val = cases.weights(col.size, 4)
+    x = cases.dense(80, 48, 3)
+    big_y = torch.zeros((80, 64), device=gpu)
+    big_y[:, :48] = _t(x, gpu)
+    big_z = torch.full((90, 56), -7.0, device=gpu)
+    cabi.fusedMM_csr_hip(cabi.MSG_SPMM_SUM, _t(rowptr, gpu), _t(col, gpu), _t(val, gpu), big_y[:, :48], big_z[:, :48])
+    ref, _ = oracle_mod.spmm_fw(rowptr, col, val, x, "sum")
+    _assert_sum_close(big_z[:, :48].cpu().numpy(), ref, cases.sum_tolerance(oracle_mod, rowptr, col, val, x))
+    assert torch.all(big_z[:, 48:] == -7.0), "wrote outside ldz window"
+
+
+def test_status_codes(gpu):
+    from isplib_amd import cabi
+    rowptr = torch.tensor([0, 1], device=gpu)
+    col = torch.tensor([0], device=gpu)
+    y = torch.ones((1, 4), device=gpu)
+    z = torch.empty((1, 4), device=gpu)
+    assert cabi.fusedMM_csr_hip(0x11103, rowptr, col, None, y, z, check=False) == cabi.NO_OPT_IMPL   # VOP_ADD
+    assert cabi.fusedMM_csr_hip(0x23102, rowptr, col, None, y, z, check=False) == cabi.NO_OPT_IMPL   # MEAN with MAX
+    assert cabi.fusedMM_csr_hip(cabi.MSG_SPMM_SUM, rowptr, col, None, y, z, beta=1.0, check=False) == cabi.FAIL
+    assert "beta" in cabi.last_error()
+    assert cabi.fusedMM_csr_hip(cabi.MSG_SPMM_SUM, rowptr, col, None, y, z, check=False) == cabi.SUCCESS
+    cabi.perform_dummy_spmm(1)
+    torch.cuda.synchronize()
+
+
+def test_run_twice_bitwise_identical(gpu):
+    from isplib_amd import cabi
+    rowptr, col = cases.random_csr(500, 400, 30.0, seed=2, hub=(5, 9000))
+    val = cases.weights(col.size, 4)
+    x = cases.dense(400, 128, 3)
+    d = [_t(a, gpu) for a in (rowptr, col, val, x)]
+    a, _ = cabi.spmm(*d, "sum")
+    b, _ = cabi.spmm(*d, "sum")
+    assert torch.equal(a, b)
