@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- edges-aggregated/sec of SpMM-sum on a Reddit-shaped graph, K=128, fp32.
+
+A "step" is one forward pass of the hot path (out = A @ X through the C ABI
+``fusedMM_csr_hip``) over the whole graph, operands resident in HBM.
+N = 1: the whole graph on one MI355X.
+N > 1: the adjacency is 1-D row-partitioned (balanced by nnz) over the ranks;
+       a step is ONE RCCL all-gather of X plus the local SpMM, so total work is
+       fixed ("strong" scaling) and value = nnz(whole graph) / max-over-ranks time.
+
+Prints ONE JSON line (rank 0).  ``roofline.achieved`` = algorithmic bytes per
+launch (reference dtypes) / average kernel time from HIP
+events recorded on the stream the kernel runs on.  ``cpu_baseline`` = the
+oracle (restated FusedMM-semantics CPU kernel, OpenMP) on this box's host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--workload", default="reddit", choices=["cora", "reddit", "products"])
+    p.add_argument("--k", type=int, default=None, help="feature width (default: 128 reddit, 16 cora, 256 products)")
+    p.add_argument("--reduce", default="sum", choices=["sum", "mean", "max", "min"])
+    p.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only; result is then not the metric)")
+    p.add_argument("--weighted", action="store_true", help="U(0,1) edge weights instead of unit weights")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-backward", action="store_true")
+    return p.parse_args()
+
+
+def partition_rows(rowptr: torch.Tensor, world: int):
+    """Contiguous row ranges with ~equal nnz."""
+    nnz = int(rowptr[-1])
+    targets = torch.arange(1, world, device=rowptr.device, dtype=torch.int64) * (nnz // world)
+    cuts = torch.searchsorted(rowptr, targets).tolist()
+    return [0] + cuts + [rowptr.numel() - 1]
+
+
+def cpu_baseline(rowptr, col, x, nnz):
+    """Oracle on the host cores: 1 pass to gauge, then up to 2 more; median."""
+    import oracle
+    oracle.build()
+    rp, cl, xx = rowptr.cpu().numpy(), col.cpu().numpy(), x.cpu().numpy()
+    import numpy as np
+    val = np.ones(cl.size, np.float32)   # the reference materialises unit weights (isplib/__init__.py:51-57)
+    times = []
+    t0 = time.perf_counter()
+    oracle.spmm_fw(rp, cl, val, xx, "sum")
+    times.append(time.perf_counter() - t0)
+    budget = 25.0 - times[0]
+    while len(times) < 3 and budget > times[0]:
+        t0 = time.perf_counter()
+        oracle.spmm_fw(rp, cl, val, xx, "sum")
+        times.append(time.perf_counter() - t0)
+        budget -= times[-1]
+    t = statistics.median(times) if len(times) > 1 else times[0]
+    return {"value": nnz / t, "unit": "edges/s", "cores": oracle.num_threads(), "kind": "port",
+            "sample": f"whole workload, {len(times)} pass(es), median {t * 1e3:.1f} ms/pass; "
+                      "oracle/fusedmm_oracle.c (restated FusedMM-semantics kernel, -O3 -march=native -fopenmp)",
+            "ms_per_step": t * 1e3, "host_cpus": os.cpu_count()}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from isplib_amd import cabi, synth
+    k = a.k or {"reddit": 128, "cora": 16, "products": 256}[a.workload]
+    rowptr, col, n = synth.dataset_like(a.workload, device=dev, scale=a.scale)
+    nnz = col.numel()
+    x = synth.features(n, k, device=dev)
+    val = synth.edge_weights(nnz, device=dev) if a.weighted else None
+    msg = cabi.MESSAGE[a.reduce]
+
+    if world == 1:
+        l_rowptr, l_col, l_val, m_local, x_in = rowptr, col, val, n, x
+        out = torch.empty((n, k), dtype=torch.float32, device=dev)
+        arg = torch.empty((n, k), dtype=torch.int64, device=dev) if a.reduce in ("max", "min") else None
+        gather = None
+    else:
+        from isplib_amd.dist import RowPartition
+        part = RowPartition(rowptr, col, val, n, rank, world)
+        l_rowptr, l_col, l_val, m_local = part.rowptr, part.col_padded, part.val, part.rows
+        x_shard = part.shard(x)
+        x_in = part.gather_buffer(k)
+        out = torch.empty((m_local, k), dtype=torch.float32, device=dev)
+        arg = torch.empty((m_local, k), dtype=torch.int64, device=dev) if a.reduce in ("max", "min") else None
+        gather = lambda: part.all_gather(x_shard, x_in)  # noqa: E731
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+
+    def step(i=None):
+        if gather is not None:
+            gather()
+        if i is not None:
+            ev[i][0].record()
+        cabi.fusedMM_csr_hip(msg, l_rowptr, l_col, l_val, x_in, out, arg)
+        if i is not None:
+            ev[i][1].record()
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms = [s.elapsed_time(e) for s, e in ev]
+    kern_avg_ms = sum(kern_ms) / len(kern_ms)
+
+    # backward of SpMM-sum = the same kernel on A^T (csrc/fusedmm.cpp:285); reported beside the metric
+    bwd = None
+    if world == 1 and not a.no_backward and a.reduce == "sum":
+        colptr, _, row_t, val_t = cabi.csr2csc(rowptr, col, val, n, want_perm=False, want_val=val is not None)
+        dy = synth.features(n, k, seed=5, device=dev)
+        dx = torch.empty((n, k), dtype=torch.float32, device=dev)
+        for _ in range(2):
+            cabi.fusedMM_csr_hip(msg, colptr, row_t, val_t, dy, dx)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(5):
+            cabi.fusedMM_csr_hip(msg, colptr, row_t, val_t, dy, dx)
+        e.record()
+        torch.cuda.synchronize()
+        bms = s.elapsed_time(e) / 5
+        bwd = {"ms": bms, "edges_per_s": nnz / (bms * 1e-3)}
+        del colptr, row_t, val_t, dy, dx
+
+    if rank == 0:
+        ms_per_step = elapsed / a.steps * 1e3
+        with_arg = a.reduce in ("max", "min")
+        # dominant kernel = the SpMM launch of this rank (rank 0's slice when partitioned)
+        b_alg = synth.algorithmic_bytes(m_local, n, l_col.numel(), k, with_arg)
+        achieved = b_alg / (kern_avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath) and world == 1 and a.scale == 1.0:
+            try:
+                rec = json.load(open(tpath)).get(f"{a.workload}-{a.reduce}-k{k}")
+                traffic = rec["hbm_bytes_per_launch"] if rec else None
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "edges_aggregated_per_sec", "value": nnz / (elapsed / a.steps), "unit": "edges/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"{a.workload}-like graph (Chung-Lu, N={n}, nnz={nnz}), SpMM-{a.reduce} forward, K={k}, fp32"
+                            + (", U(0,1) weights" if a.weighted else ", unit weights")
+                            + ("" if a.scale == 1.0 else f", SCALED x{a.scale} (debug)"),
+                "partition": "none" if world == 1 else f"1-D rows by nnz, {world} ranks, one all-gather(X) per step",
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                "kernel": "spmm_csr_kernel", "kernel_avg_ms": kern_avg_ms, "algorithmic_bytes_per_launch": b_alg,
+                "gather_model_GBps": synth.gather_bytes(m_local, l_col.numel(), k) / (kern_avg_ms * 1e-3) / 1e9,
+            },
+        }
+        if bwd:
+            res["backward"] = bwd
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(rowptr, col, x, nnz)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -20,11 +20,12 @@
 //   * outputs are torch::empty: the kernel writes every element, including the
 //     0 / nnz the reference gets from zeros()/full_like() fills (:147-152,171).
 #include <ATen/ATen.h>
-#include <c10/hip/HIPGuard.h>
+#include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/csrc/autograd/custom_function.h>
 #include <torch/library.h>
 
+#include <initializer_list>
 #include <tuple>
 
 #include "../../include/isplib_hip.h"
@@ -65,7 +66,7 @@ std::tuple<Tensor, Tensor> spmm_fw(const Tensor &rowptr_, const Tensor &col_, co
    check_float(mat_, "mat");
    TORCH_CHECK(mat_.dim() == 2, "isplib: `mat` must be 2-D [N, K] (csrc/fusedmm.cpp:121-122)");
    TORCH_CHECK(rowptr_.dim() == 1 && rowptr_.numel() >= 1, "isplib: `rowptr` must be 1-D with M+1 entries");
-   c10::hip::HIPGuard guard(mat_.device());
+   c10::DeviceGuard guard(mat_.device());
    const Tensor rowptr = rowptr_.contiguous(), col = col_.contiguous(), mat = mat_.contiguous();   // :140
    Tensor value;
    if (value_.has_value() && value_->defined()) {
@@ -97,7 +98,7 @@ struct Transposed {
 
 // A^T operands built on the device (isplib/__init__.py:79-80 / :86-99 equivalents)
 Transposed build_transpose(const Tensor &rowptr, const Tensor &col, const Tensor &value, int64_t ncols, bool mean) {
-   c10::hip::HIPGuard guard(col.device());
+   c10::DeviceGuard guard(col.device());
    const int64_t M = rowptr.numel() - 1, nnz = col.numel();
    Transposed t;
    t.colptr = at::empty({ncols + 1}, rowptr.options());
@@ -115,7 +116,7 @@ Transposed build_transpose(const Tensor &rowptr, const Tensor &col, const Tensor
 }
 
 Tensor sddmm(const Tensor &rowptr, const Tensor &col, const Tensor &mat, const Tensor &grad_out, bool mean) {
-   c10::hip::HIPGuard guard(mat.device());
+   c10::DeviceGuard guard(mat.device());
    const Tensor g = grad_out.contiguous(), y = mat.contiguous();
    const int64_t M = rowptr.numel() - 1, K = y.size(1);
    Tensor dval = at::empty({col.numel()}, y.options());
@@ -128,6 +129,15 @@ Tensor sddmm(const Tensor &rowptr, const Tensor &col, const Tensor &mat, const T
 
 Tensor or_undef(const optional<Tensor> &t) { return t.has_value() ? *t : Tensor(); }
 
+// AutogradContext::needs_input_grad() is indexed by autograd EDGE, i.e. by position among
+// the tensor arguments that are actually present -- absent optionals take no edge.
+int64_t edge_of(std::initializer_list<bool> present_before) {
+   int64_t e = 0;
+   for (bool p : present_before) e += p ? 1 : 0;
+   return e;
+}
+bool present(const optional<Tensor> &t) { return t.has_value() && t->defined(); }
+
 // ---- sum: csrc/fusedmm.cpp:210-294 ---------------------------------------------------------
 class SpmmSum : public torch::autograd::Function<SpmmSum> {
  public:
@@ -138,6 +148,9 @@ class SpmmSum : public torch::autograd::Function<SpmmSum> {
       const bool has_value = opt_value.has_value() && opt_value->defined();
       auto out = std::get<0>(spmm_fw(rowptr, col, opt_value, mat, R_SUM));   // :244
       ctx->saved_data["has_value"] = has_value;
+      ctx->saved_data["value_edge"] = edge_of({present(opt_row), true, true});
+      ctx->saved_data["mat_edge"] =
+          edge_of({present(opt_row), true, true, has_value, present(opt_colptr), present(opt_csr2csc)});
       ctx->save_for_backward({or_undef(opt_row), rowptr, col, or_undef(opt_value), or_undef(opt_colptr),
                               or_undef(opt_csr2csc), mat, or_undef(value_index_select), or_undef(row_index_select)});
       return {out};
@@ -151,11 +164,11 @@ class SpmmSum : public torch::autograd::Function<SpmmSum> {
            value_sel = saved[7], row_sel = saved[8];
 
       auto grad_value = Variable();
-      if (has_value && ctx->needs_input_grad(3))                             // :269-272 (SDDMM, commented out there)
+      if (has_value && ctx->needs_input_grad(ctx->saved_data["value_edge"].toInt()))   // :269-272 (SDDMM, commented out there)
          grad_value = sddmm(rowptr, col, mat, grad_out, false);
 
       auto grad_mat = Variable();
-      if (ctx->needs_input_grad(6)) {
+      if (ctx->needs_input_grad(ctx->saved_data["mat_edge"].toInt())) {
          // :285  grad_mat = fusedmm_spmm_fw(colptr, row_index_select, value_index_select, grad_out)
          if (colptr.defined() && row_sel.defined() && (value_sel.defined() || !has_value)) {
             optional<Tensor> v = has_value ? optional<Tensor>(value_sel) : c10::nullopt;
@@ -180,6 +193,9 @@ class SpmmMean : public torch::autograd::Function<SpmmMean> {
       const bool has_value = opt_value.has_value() && opt_value->defined();
       auto out = std::get<0>(spmm_fw(rowptr, col, opt_value, mat, R_MEAN));   // :331
       ctx->saved_data["has_value"] = has_value;
+      ctx->saved_data["value_edge"] = edge_of({present(opt_row), true, true});
+      ctx->saved_data["mat_edge"] = edge_of({present(opt_row), true, true, has_value, present(opt_rowcount),
+                                             present(opt_colptr), present(opt_csr2csc)});
       ctx->save_for_backward({or_undef(opt_row), rowptr, col, or_undef(opt_value), or_undef(opt_rowcount),
                               or_undef(opt_colptr), or_undef(opt_csr2csc), mat, or_undef(new_row),
                               or_undef(new_rowcount)});
@@ -194,10 +210,11 @@ class SpmmMean : public torch::autograd::Function<SpmmMean> {
            new_rowcount = saved[9];
 
       auto grad_value = Variable();
-      if (has_value && ctx->needs_input_grad(3)) grad_value = sddmm(rowptr, col, mat, grad_out, true);   // :350-353
+      if (has_value && ctx->needs_input_grad(ctx->saved_data["value_edge"].toInt()))
+         grad_value = sddmm(rowptr, col, mat, grad_out, true);   // :350-353
 
       auto grad_mat = Variable();
-      if (ctx->needs_input_grad(7)) {
+      if (ctx->needs_input_grad(ctx->saved_data["mat_edge"].toInt())) {
          // :375  grad_mat = fusedmm_spmm_fw(colptr, new_row, new_rowcount, grad_out)   (a SUM on A^T)
          const bool cached = colptr.defined() && new_row.defined() && new_rowcount.defined() &&
                              new_row.numel() == col.numel() && new_rowcount.numel() == col.numel() &&
@@ -235,11 +252,12 @@ class SpmmMinMax : public torch::autograd::Function<SpmmMinMax<RED>> {
       auto saved = ctx->get_saved_variables();
       auto col = saved[0], value = saved[1], mat = saved[2], arg_out = saved[3];
       const Tensor grad_out = grad_outs[0].contiguous();
+      // edges: rowptr 0, col 1, value 2 (if present), mat last
       const bool need_val = has_value && ctx->needs_input_grad(2);
-      const bool need_mat = ctx->needs_input_grad(3);
+      const bool need_mat = ctx->needs_input_grad(has_value ? 3 : 2);
       auto grad_value = Variable(), grad_mat = Variable();
       if (need_val || need_mat) {
-         c10::hip::HIPGuard guard(mat.device());
+         c10::DeviceGuard guard(mat.device());
          const Tensor y = mat.contiguous();
          const int64_t M = arg_out.size(0), N = y.size(0), K = y.size(1), nnz = col.numel();
          if (need_val) grad_value = at::empty({nnz}, y.options());

@@ -1,0 +1,104 @@
+"""1-D row partition of the adjacency over the GPUs of one node (one process per
+GPU, ``torch.distributed``; backend "nccl" is RCCL over xGMI on ROCm).
+
+The reference has no distributed path at all; this is new
+design, following BASELINE.json's north_star: rank p owns a contiguous range
+of rows of A chosen so that nnz is balanced, plus the matching rows of X.  One
+SpMM = ONE all-gather of X (every rank contributes its shard) followed by the
+local ``out[R_p] = A[R_p, :] @ X``.  Each output row is still produced by one
+wave in the same edge order, so the result is bit-identical to the single-GPU
+one and no reduce-scatter / atomics are needed.  The backward is the same
+thing on A^T (csrc/fusedmm.cpp:285): all-gather dY, local ``A^T[R_p, :] @ dY``.
+
+Shards have unequal row counts (nnz-balanced); the gather buffer is laid out
+[world, max_rows, K] and the local column ids are remapped ONCE, at partition
+time, into that padded layout, so the SpMM reads the gathered buffer in place
+(no compaction copy after the collective).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def nnz_balanced_cuts(rowptr: torch.Tensor, world: int) -> List[int]:
+    """world+1 row boundaries with ~nnz/world entries per part."""
+    nnz = int(rowptr[-1])
+    m = rowptr.numel() - 1
+    if world == 1:
+        return [0, m]
+    targets = torch.arange(1, world, device=rowptr.device, dtype=torch.int64) * (nnz // world)
+    cuts = torch.searchsorted(rowptr, targets).clamp_(max=m).tolist()
+    out = [0] + cuts + [m]
+    for i in range(1, len(out)):          # keep boundaries monotone on degenerate inputs
+        out[i] = max(out[i], out[i - 1])
+    return out
+
+
+class RowPartition:
+    """This rank's slice of a CSR matrix whose columns index the row-sharded X."""
+
+    def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, val: Optional[torch.Tensor], ncols: int,
+                 rank: int, world: int, cuts: Optional[List[int]] = None, group=None):
+        m = rowptr.numel() - 1
+        self.rank, self.world, self.group = rank, world, group
+        self.row_cuts = cuts if cuts is not None else nnz_balanced_cuts(rowptr, world)
+        # X (ncols rows) is sharded with the same boundaries when A is square, evenly otherwise
+        if ncols == m:
+            self.x_cuts = list(self.row_cuts)
+        else:
+            self.x_cuts = [min(ncols, (ncols * p + world - 1) // world) for p in range(world)] + [ncols]
+        r0, r1 = self.row_cuts[rank], self.row_cuts[rank + 1]
+        self.row0, self.rows = r0, r1 - r0
+        lo, hi = int(rowptr[r0]), int(rowptr[r1])
+        self.edge0, self.nnz, self.total_nnz = lo, hi - lo, int(rowptr[-1])
+        self.rowptr = (rowptr[r0:r1 + 1] - lo).contiguous()
+        self.col = col[lo:hi].contiguous()
+        self.val = None if val is None else val[lo:hi].contiguous()
+        sizes = [self.x_cuts[p + 1] - self.x_cuts[p] for p in range(world)]
+        self.max_rows = max(max(sizes), 1)
+        self.x_rows = sizes[rank]
+        xc = torch.tensor(self.x_cuts, dtype=torch.int64, device=col.device)
+        owner = torch.searchsorted(xc[1:].contiguous(), self.col, right=True).clamp_(max=world - 1)
+        self.col_padded = (owner * self.max_rows + (self.col - xc[owner])).contiguous()
+        self.ncols_padded = world * self.max_rows
+
+    def shard(self, x_full: torch.Tensor) -> torch.Tensor:
+        """This rank's rows of a replicated X, zero-padded to max_rows."""
+        k = x_full.size(1)
+        out = torch.zeros((self.max_rows, k), dtype=x_full.dtype, device=x_full.device)
+        out[: self.x_rows] = x_full[self.x_cuts[self.rank]: self.x_cuts[self.rank + 1]]
+        return out
+
+    def gather_buffer(self, k: int, device=None, dtype=torch.float32) -> torch.Tensor:
+        return torch.empty((self.ncols_padded, k), dtype=dtype, device=device or self.col.device)
+
+    def all_gather(self, x_shard: torch.Tensor, buf: torch.Tensor):
+        """ONE collective per SpMM.  x_shard: [max_rows, K] contiguous."""
+        if self.world == 1:
+            buf.copy_(x_shard)
+            return None
+        return dist.all_gather_into_tensor(buf, x_shard, group=self.group)
+
+    def unpad(self, buf: torch.Tensor) -> torch.Tensor:
+        """Gathered padded buffer -> replicated [ncols, K] (tests / debugging only)."""
+        parts = [buf[p * self.max_rows: p * self.max_rows + (self.x_cuts[p + 1] - self.x_cuts[p])]
+                 for p in range(self.world)]
+        return torch.cat(parts, 0)
+
+    def spmm(self, x_shard: torch.Tensor, reduce: str = "sum", buf: Optional[torch.Tensor] = None):
+        """all-gather(X) + local SpMM on the HIP path; returns (out[rows, K], arg|None).
+        arg holds GLOBAL CSR positions (local position + this rank's edge offset;
+        the 'no winner' sentinel becomes the global nnz)."""
+        from . import cabi
+        k = x_shard.size(1)
+        buf = self.gather_buffer(k, x_shard.device) if buf is None else buf
+        self.all_gather(x_shard, buf)
+        out = torch.empty((self.rows, k), dtype=torch.float32, device=x_shard.device)
+        arg = torch.empty((self.rows, k), dtype=torch.int64, device=x_shard.device) if reduce in ("max", "min") else None
+        cabi.fusedMM_csr_hip(cabi.MESSAGE[reduce], self.rowptr, self.col_padded, self.val, buf, out, arg)
+        if arg is not None:
+            arg = torch.where(arg == self.nnz, arg.new_full((), self.total_nnz), arg + self.edge0)
+        return out, arg
