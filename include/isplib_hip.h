@@ -93,6 +93,43 @@ int fusedMM_csr_hip(int32_t imessage, int64_t m, int64_t n, int64_t k,
                     float *z /*[dev] m x ldz*/, int64_t ldz,
                     int64_t *z_arg /*[dev] m x ldz | NULL*/, void *stream);
 
+/*
+ * Column-sliced SpMM: same result as fusedMM_csr_hip, faster when y does not fit an
+ * XCD's 4 MiB L2 and rows are long (Reddit-like graphs).  The columns of A (= rows of
+ * y) are cut into `slices` (a multiple of 8) equal ranges; every XCD of the MI355X
+ * walks all rows of its own slice(s), so its L2 holds 1/slices of y instead of all of
+ * it; the per-slice partials (workspace) are folded in slice order by a second kernel.
+ * No atomics: bitwise reproducible; max/min still resolve ties to the lowest CSR
+ * position.  Requires column indices sorted within each row (torch_sparse order; the
+ * CSC operands of csrc/fusedmm.cpp:285 are sorted too).
+ *
+ *   isplib_spmm_slices_build_hip: sliceptr[i*(slices+1)+s] = first CSR position of row
+ *     i with column >= s*ceil(n/slices); once per graph, independent of k.  If
+ *     unsorted_flag != NULL it receives 1 when some row is not sorted (the table must
+ *     then not be used) -- the one-per-graph replacement for the per-graph caches of
+ *     isplib/__init__.py:76-106.
+ *   workspace: isplib_spmm_sliced_workspace_bytes(imessage, m, k, slices) bytes,
+ *     256-byte aligned.
+ */
+size_t isplib_spmm_slices_bytes(int64_t m, int slices);
+int    isplib_spmm_slices_build_hip(int64_t m, int64_t n, int64_t nnz,
+                                    const int64_t *pntrb, const int64_t *pntre,
+                                    const int64_t *indx, int slices,
+                                    int64_t *sliceptr /*[dev] m*(slices+1)*/,
+                                    int32_t *unsorted_flag /*[dev] 1 | NULL*/,
+                                    void *stream);
+size_t isplib_spmm_sliced_workspace_bytes(int32_t imessage, int64_t m, int64_t k, int slices);
+int    fusedMM_csr_sliced_hip(int32_t imessage, int64_t m, int64_t n, int64_t k,
+                              int64_t nnz, const float *val, const int64_t *indx,
+                              const int64_t *pntrb, const int64_t *pntre,
+                              const int64_t *sliceptr, int slices,
+                              const float *y, int64_t ldy, float *z, int64_t ldz,
+                              int64_t *z_arg, void *workspace,
+                              size_t workspace_bytes, void *stream);
+
+/* Tuning knob for experiments (key 0: lanes per row slot, 0 = choose by k). */
+int isplib_hip_tune(int key, int value);
+
 /* Warm-up hook with the reference's name; launches one empty kernel. */
 void performDummySpMM_hip(int64_t flag, void *stream);
 

@@ -28,6 +28,8 @@ EXPORTS = (
     "isplib_hip_abi_version", "isplib_hip_last_error", "fusedMM_csr_hip", "performDummySpMM_hip",
     "isplib_spmm_minmax_bw_hip", "isplib_sddmm_csr_hip", "isplib_csr_row_ids_hip",
     "isplib_csr2csc_workspace_bytes", "isplib_csr2csc_hip",
+    "isplib_spmm_slices_bytes", "isplib_spmm_slices_build_hip", "isplib_spmm_sliced_workspace_bytes",
+    "fusedMM_csr_sliced_hip", "isplib_hip_tune",
 )
 
 _i64, _f32, _vp, _i32 = ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_int32
@@ -56,6 +58,17 @@ def lib() -> ctypes.CDLL:
         L.isplib_csr2csc_hip.restype = ctypes.c_int
         L.isplib_csr2csc_hip.argtypes = [_i64, _i64, _i64, _vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp, _vp,
                                          _vp, ctypes.c_size_t, _vp]
+        L.isplib_spmm_slices_bytes.restype = ctypes.c_size_t
+        L.isplib_spmm_slices_bytes.argtypes = [_i64, ctypes.c_int]
+        L.isplib_spmm_slices_build_hip.restype = ctypes.c_int
+        L.isplib_spmm_slices_build_hip.argtypes = [_i64, _i64, _i64, _vp, _vp, _vp, ctypes.c_int, _vp, _vp, _vp]
+        L.isplib_spmm_sliced_workspace_bytes.restype = ctypes.c_size_t
+        L.isplib_spmm_sliced_workspace_bytes.argtypes = [_i32, _i64, _i64, ctypes.c_int]
+        L.fusedMM_csr_sliced_hip.restype = ctypes.c_int
+        L.fusedMM_csr_sliced_hip.argtypes = [_i32, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, ctypes.c_int,
+                                             _vp, _i64, _vp, _i64, _vp, _vp, ctypes.c_size_t, _vp]
+        L.isplib_hip_tune.restype = ctypes.c_int
+        L.isplib_hip_tune.argtypes = [ctypes.c_int, ctypes.c_int]
         _sigs_set = True
     return L
 
@@ -187,3 +200,59 @@ def csr2csc(rowptr, col, val, ncols: int, *, mean_scale: bool = False, want_perm
                                       _ptr(colptr), _ptr(perm), _ptr(row_t), _ptr(val_t), _ptr(work), ws, _stream(dev))
     _check(st, "isplib_csr2csc_hip")
     return colptr, perm, row_t, val_t
+
+
+def spmm_slices(rowptr, col, ncols: int, slices: int = 8, check_sorted: bool = True):
+    """Per-graph slice table for fusedMM_csr_sliced_hip: (sliceptr[m*(slices+1)], rows_sorted).
+    ``rows_sorted`` is False when some row's columns are not ascending (table unusable);
+    reading it synchronises once -- this runs once per graph, never per SpMM."""
+    rowptr = _dev(rowptr, "rowptr", torch.int64)
+    col = _dev(col, "col", torch.int64)
+    dev = col.device
+    m = rowptr.numel() - 1
+    sliceptr = torch.empty(m * (slices + 1), dtype=torch.int64, device=dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev) if check_sorted else None
+    rp = rowptr.data_ptr()
+    with torch.cuda.device(dev):
+        st = lib().isplib_spmm_slices_build_hip(m, ncols, col.numel(), ctypes.c_void_p(rp), ctypes.c_void_p(rp + 8),
+                                                _ptr(col), slices, _ptr(sliceptr), _ptr(flag), _stream(dev))
+    _check(st, "isplib_spmm_slices_build_hip")
+    return sliceptr, (True if flag is None else int(flag.item()) == 0)
+
+
+def sliced_workspace(reduce: str, m: int, k: int, slices: int, device) -> torch.Tensor:
+    nbytes = lib().isplib_spmm_sliced_workspace_bytes(MESSAGE[reduce], m, k, slices)
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def fusedMM_csr_sliced_hip(imessage: int, rowptr, col, val, sliceptr, slices: int, y, z, z_arg, workspace,
+                           check: bool = True) -> int:
+    """Raw boundary call of the column-sliced SpMM (operands as fusedMM_csr_hip + slice table + workspace)."""
+    assert y.is_cuda and y.dtype == torch.float32 and y.dim() == 2 and y.stride(1) == 1
+    m, n, k = rowptr.numel() - 1, y.size(0), y.size(1)
+    rp = rowptr.data_ptr()
+    with torch.cuda.device(y.device):
+        st = lib().fusedMM_csr_sliced_hip(int(imessage), m, n, k, col.numel(), _ptr(val), _ptr(col),
+                                          ctypes.c_void_p(rp), ctypes.c_void_p(rp + 8), _ptr(sliceptr), slices,
+                                          _ptr(y), y.stride(0) if n > 1 else max(k, y.stride(0)), _ptr(z),
+                                          z.stride(0) if m > 1 else max(k, z.stride(0)), _ptr(z_arg),
+                                          _ptr(workspace), workspace.numel(), _stream(y.device))
+    if check:
+        _check(st, "fusedMM_csr_sliced_hip")
+    return st
+
+
+def spmm_sliced(rowptr, col, val, sliceptr, slices: int, y, reduce: str = "sum", workspace=None):
+    """Allocate outputs (+ workspace) and call the sliced boundary; returns (out, arg|None)."""
+    rowptr = _dev(rowptr, "rowptr", torch.int64)
+    col = _dev(col, "col", torch.int64)
+    if val is not None:
+        val = _dev(val, "val", torch.float32)
+    y = y.contiguous()
+    m, k = rowptr.numel() - 1, y.size(1)
+    out = torch.empty((m, k), dtype=torch.float32, device=y.device)
+    arg = torch.empty((m, k), dtype=torch.int64, device=y.device) if reduce in ("max", "min") else None
+    if workspace is None:
+        workspace = sliced_workspace(reduce, m, k, slices, y.device)
+    fusedMM_csr_sliced_hip(MESSAGE[reduce], rowptr, col, val, sliceptr, slices, y, out, arg, workspace)
+    return out, arg

@@ -82,6 +82,46 @@ __global__ __launch_bounds__(256) void finalize_kernel(int64_t m, int64_t nnz, c
    }
 }
 
+// sliceptr[i*(S+1)+s] = first CSR position of row i whose column is >= s*width (columns sorted in-row)
+__global__ __launch_bounds__(256) void slices_kernel(int64_t m, int64_t width, int slices,
+                                                     const int64_t *__restrict__ pntrb,
+                                                     const int64_t *__restrict__ pntre,
+                                                     const int64_t *__restrict__ indx,
+                                                     int64_t *__restrict__ sliceptr) {
+   const int64_t per = slices + 1;
+   const int64_t total = m * per;
+   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+      const int64_t row = t / per;
+      const int s = (int)(t - row * per);
+      const int64_t b = pntrb[row], e = pntre[row];
+      int64_t lo = b, hi = e;
+      if (s == 0) hi = b;
+      else if (s == slices) lo = e;
+      const int64_t target = (int64_t)s * width;
+      while (lo < hi) {
+         const int64_t mid = (lo + hi) >> 1;
+         if (indx[mid] < target) lo = mid + 1; else hi = mid;
+      }
+      sliceptr[t] = lo;
+   }
+}
+
+// flag = 1 if any row has a descending column pair (the slice table is then meaningless)
+__global__ __launch_bounds__(256) void sorted_check_kernel(int64_t m, const int64_t *__restrict__ pntrb,
+                                                           const int64_t *__restrict__ pntre,
+                                                           const int64_t *__restrict__ indx, int *flag) {
+   const int lane = threadIdx.x & 63;
+   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+   bool bad = false;
+   for (int64_t row = wave; row < m; row += nwaves) {
+      const int64_t b = pntrb[row], e = pntre[row];
+      for (int64_t p = b + 1 + lane; p < e; p += 64) bad |= indx[p] < indx[p - 1];
+   }
+   if (bad) atomicOr(flag, 1);
+}
+
 static inline unsigned grid_for(int64_t n) {
    int64_t b = (n + 255) / 256;
    if (b < 1) b = 1;
@@ -161,6 +201,34 @@ extern "C" int isplib_csr2csc_hip(int64_t m, int64_t n, int64_t nnz, const int64
       hipLaunchKernelGGL(finalize_kernel, dim3(grid_for(nnz)), dim3(256), 0, st, m, nnz, rowptr, val, mean_scale,
                          pos_out, csr2csc, row_t, val_t);
       rc = check_launch("finalize_kernel");
+   }
+   return rc;
+}
+
+extern "C" size_t isplib_spmm_slices_bytes(int64_t m, int slices) {
+   if (m < 0 || slices < 1) return 0;
+   return (size_t)m * (size_t)(slices + 1) * sizeof(int64_t);
+}
+
+extern "C" int isplib_spmm_slices_build_hip(int64_t m, int64_t n, int64_t nnz, const int64_t *pntrb,
+                                            const int64_t *pntre, const int64_t *indx, int slices, int64_t *sliceptr,
+                                            int32_t *unsorted_flag, void *stream) {
+   clear_error();
+   if (m < 0 || n < 0 || nnz < 0) return fail(ISPLIB_FAIL, "isplib_spmm_slices_build_hip: negative dimension");
+   if (slices < 8 || slices % 8 != 0) return fail(ISPLIB_FAIL, "isplib_spmm_slices_build_hip: slices must be a positive multiple of 8");
+   hipStream_t st = (hipStream_t)stream;
+   if (unsorted_flag) ISPLIB_HIP_TRY(hipMemsetAsync(unsorted_flag, 0, sizeof(int32_t), st));
+   if (m == 0) return ISPLIB_SUCCESS;
+   if (!pntrb || !pntre || !sliceptr || (nnz > 0 && !indx)) return fail(ISPLIB_FAIL, "isplib_spmm_slices_build_hip: null operand");
+   const int64_t width = (n + slices - 1) / slices > 0 ? (n + slices - 1) / slices : 1;
+   hipLaunchKernelGGL(slices_kernel, dim3(grid_for(m * (slices + 1))), dim3(256), 0, st, m, width, slices, pntrb, pntre,
+                      indx, sliceptr);
+   int rc = check_launch("slices_kernel");
+   if (rc) return rc;
+   if (unsorted_flag && nnz > 0) {
+      hipLaunchKernelGGL(sorted_check_kernel, dim3(grid_for(m * 64)), dim3(256), 0, st, m, pntrb, pntre, indx,
+                         (int *)unsorted_flag);
+      rc = check_launch("sorted_check_kernel");
    }
    return rc;
 }

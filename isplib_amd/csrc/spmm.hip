@@ -52,7 +52,13 @@ struct SpmmArgs {
    int64_t *z_arg;         // may be null
    int mean;               // OP_ADD only: divide by max(deg,1)
    int long_row;           // rows with more edges are split across the workgroup
-   unsigned nblk;          // number of row blocks (grid.x)
+   unsigned nblk;          // number of row blocks
+   // column-sliced mode (fusedMM_csr_sliced_hip): row i's edges with column in slice s are
+   // [sliceptr[i*(slices+1)+s], sliceptr[i*(slices+1)+s+1]); slice s is walked by XCD s / sl_per_xcd
+   const int64_t *sliceptr;
+   int slices, sl_per_xcd;
+   float *part_val;        // [slices][m][k] partial results
+   int *part_idx;          // [slices][m][k] row-relative edge ids (max/min), INT_MAX = none
 };
 
 template <int VEC> __device__ __forceinline__ void load_vec(const float *p, float (&r)[VEC]);
@@ -203,7 +209,24 @@ __device__ __forceinline__ void write_row(const SpmmArgs &a, int64_t row, int64_
    }
 }
 
-template <int OP, int VEC, int LPR, int NCH, int WAVES>
+// sliced mode: raw partial of (slice, row); finished by combine_slices_kernel
+template <int OP, int VEC, int NCH>
+__device__ __forceinline__ void write_partial(const SpmmArgs &a, int slice, int64_t row, const int (&ccol)[NCH],
+                                              const bool (&cok)[NCH], const float (&acc)[NCH][VEC],
+                                              const int (&bi)[NCH][VEC]) {
+   const size_t off = ((size_t)slice * (size_t)a.m + (size_t)row) * (size_t)a.k;
+#pragma unroll
+   for (int j = 0; j < NCH; j++) {
+      if (!cok[j]) continue;
+      store_vec<VEC>(a.part_val + off + ccol[j], acc[j]);
+      if (OP != OP_ADD) {
+#pragma unroll
+         for (int v = 0; v < VEC; v++) a.part_idx[off + ccol[j] + v] = bi[j][v];
+      }
+   }
+}
+
+template <int OP, int VEC, int LPR, int NCH, int WAVES, bool SLICED>
 __global__ __launch_bounds__(WAVES * 64) void spmm_csr_kernel(const SpmmArgs a) {
    constexpr int U = (8 / NCH) > 2 ? (8 / NCH) : 2;
    constexpr int PANEL = LPR * VEC * NCH;   // columns covered by one grid.y slice
@@ -214,11 +237,21 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_csr_kernel(const SpmmArgs a) 
    const int wave = threadIdx.x >> 6;
    const int g = lane / LPR, lc = lane % LPR;
 
-   // XCD-aware remap: physical blocks pb, pb+8, ... (one XCD) get consecutive logical ids
+   // XCD-aware remap: physical blocks pb, pb+8, ... share one XCD (speed only, never correctness).
+   //  plain : each XCD walks a contiguous range of row blocks.
+   //  sliced: each XCD walks ALL row blocks of its own column slice(s), so its L2 only
+   //          ever sees 1/8 of the rows of y; grid.x = 8 * sl_per_xcd * nblk.
    const unsigned pb = blockIdx.x, nb = a.nblk;
    const unsigned xcd = pb & 7u, within = pb >> 3;
-   const unsigned per = nb >> 3, rem = nb & 7u;
-   const unsigned lb = xcd * per + (xcd < rem ? xcd : rem) + within;
+   unsigned lb;
+   int slice = 0;
+   if (SLICED) {
+      slice = (int)xcd * a.sl_per_xcd + (int)(within / nb);
+      lb = within % nb;
+   } else {
+      const unsigned per = nb >> 3, rem = nb & 7u;
+      lb = xcd * per + (xcd < rem ? xcd : rem) + within;
+   }
 
    int ccol[NCH];
    bool cok[NCH];
@@ -233,7 +266,14 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_csr_kernel(const SpmmArgs a) 
 
    // phase 1: one row per wave (rows up to long_row edges)
    if (row < a.m) {
-      const int64_t b = a.pntrb[row], e = a.pntre[row];
+      int64_t b, e, row_b;
+      if (SLICED) {
+         const int64_t *sp = a.sliceptr + (size_t)row * (size_t)(a.slices + 1) + slice;
+         b = sp[0]; e = sp[1];
+         row_b = OP == OP_ADD ? b : a.pntrb[row];
+      } else {
+         b = a.pntrb[row]; e = a.pntre[row]; row_b = b;
+      }
       const int64_t deg = e - b;
       if (deg <= a.long_row) {
          float acc[NCH][VEC];
@@ -242,9 +282,12 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_csr_kernel(const SpmmArgs a) 
          for (int j = 0; j < NCH; j++)
 #pragma unroll
             for (int v = 0; v < VEC; v++) { acc[j][v] = identity<OP>(); bi[j][v] = INT_MAX; }
-         wave_edges<OP, VEC, LPR, NCH, U>(a, b, b, e, ccol, cok, acc, bi);
+         wave_edges<OP, VEC, LPR, NCH, U>(a, row_b, b, e, ccol, cok, acc, bi);
          slot_reduce<OP, VEC, LPR, NCH>(acc, bi);
-         if (g == 0) write_row<OP, VEC, NCH>(a, row, b, deg, ccol, cok, acc, bi);
+         if (g == 0) {
+            if (SLICED) write_partial<OP, VEC, NCH>(a, slice, row, ccol, cok, acc, bi);
+            else write_row<OP, VEC, NCH>(a, row, b, deg, ccol, cok, acc, bi);
+         }
       }
    }
 
@@ -252,7 +295,14 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_csr_kernel(const SpmmArgs a) 
    for (int r = 0; r < WAVES; r++) {
       const int64_t lr = row0 + r;
       if (lr >= a.m) break;                        // uniform over the block
-      const int64_t b = a.pntrb[lr], e = a.pntre[lr];
+      int64_t b, e, row_b;
+      if (SLICED) {
+         const int64_t *sp = a.sliceptr + (size_t)lr * (size_t)(a.slices + 1) + slice;
+         b = sp[0]; e = sp[1];
+         row_b = OP == OP_ADD ? b : a.pntrb[lr];
+      } else {
+         b = a.pntrb[lr]; e = a.pntre[lr]; row_b = b;
+      }
       const int64_t deg = e - b;
       if (deg <= a.long_row) continue;             // uniform over the block
       int64_t chunk = (deg + WAVES - 1) / WAVES;
@@ -266,7 +316,7 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_csr_kernel(const SpmmArgs a) 
       for (int j = 0; j < NCH; j++)
 #pragma unroll
          for (int v = 0; v < VEC; v++) { acc[j][v] = identity<OP>(); bi[j][v] = INT_MAX; }
-      wave_edges<OP, VEC, LPR, NCH, U>(a, b, cb, ce, ccol, cok, acc, bi);
+      wave_edges<OP, VEC, LPR, NCH, U>(a, row_b, cb, ce, ccol, cok, acc, bi);
       slot_reduce<OP, VEC, LPR, NCH>(acc, bi);
       if (g == 0) {
 #pragma unroll
@@ -298,9 +348,67 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_csr_kernel(const SpmmArgs a) 
                acc[j][v] = t;
                bi[j][v] = ti;
             }
-         write_row<OP, VEC, NCH>(a, lr, b, deg, ccol, cok, acc, bi);
+         if (SLICED) write_partial<OP, VEC, NCH>(a, slice, lr, ccol, cok, acc, bi);
+         else write_row<OP, VEC, NCH>(a, lr, b, deg, ccol, cok, acc, bi);
       }
       __syncthreads();
+   }
+}
+
+// Finishes the sliced mode: folds the per-slice partials of one output row in slice order
+// (ascending column = ascending CSR position, so the fold order is fixed and ties resolve
+// to the lowest edge id), then applies what write_row applies: mean scale, empty-row value,
+// absolute arg positions.  One thread per VEC output columns; coalesced along K.
+template <int OP, int VEC>
+__global__ __launch_bounds__(256) void combine_slices_kernel(const SpmmArgs a) {
+   const int64_t kv = a.k / VEC;
+   const int64_t total = a.m * kv;
+   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+   const size_t plane = (size_t)a.m * (size_t)a.k;
+   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+      const int64_t row = t / kv;
+      const int c = (int)(t - row * kv) * VEC;
+      const size_t off = (size_t)row * (size_t)a.k + c;
+      float acc[VEC];
+      int bi[VEC];
+      load_vec<VEC>(a.part_val + off, acc);
+      if (OP != OP_ADD) {
+#pragma unroll
+         for (int v = 0; v < VEC; v++) bi[v] = a.part_idx[off + v];
+      }
+      for (int s = 1; s < a.slices; s++) {
+         float p[VEC];
+         load_vec<VEC>(a.part_val + s * plane + off, p);
+#pragma unroll
+         for (int v = 0; v < VEC; v++) {
+            if (OP == OP_ADD) {
+               acc[v] += p[v];
+            } else {
+               const int oi = a.part_idx[s * plane + off + v];
+               const bool take = better<OP>(p[v], oi, acc[v], bi[v]);
+               acc[v] = take ? p[v] : acc[v];
+               bi[v] = take ? oi : bi[v];
+            }
+         }
+      }
+      const int64_t rb = a.pntrb[row];
+      const int64_t deg = a.pntre[row] - rb;
+      if (OP == OP_ADD) {
+         if (a.mean) {
+            const float d = (float)(deg > 1 ? deg : 1);
+#pragma unroll
+            for (int v = 0; v < VEC; v++) acc[v] = acc[v] / d;
+         }
+      } else if (deg <= 0) {
+#pragma unroll
+         for (int v = 0; v < VEC; v++) acc[v] = 0.0f;
+      }
+      store_vec<VEC>(a.z + (size_t)row * (size_t)a.ldz + c, acc);
+      if (OP != OP_ADD && a.z_arg) {
+         int64_t *ar = a.z_arg + (size_t)row * (size_t)a.ldz + c;
+#pragma unroll
+         for (int v = 0; v < VEC; v++) ar[v] = bi[v] == INT_MAX ? a.nnz : rb + (int64_t)bi[v];
+      }
    }
 }
 
@@ -315,14 +423,29 @@ static int launch_cfg(const SpmmArgs &a0, hipStream_t st) {
    a.nblk = (unsigned)nb;
    constexpr int PANEL = LPR * VEC * NCH;
    const unsigned ny = (unsigned)((a.k + PANEL - 1) / PANEL);
-   hipLaunchKernelGGL((spmm_csr_kernel<OP, VEC, LPR, NCH, WAVES>), dim3((unsigned)nb, ny, 1), dim3(WAVES * 64, 1, 1), 0,
-                      st, a);
+   if (a.sliceptr) {
+      const int64_t gx = nb * a.slices;   // slices is a multiple of 8
+      if (gx > 0x7fffffffLL) return ISPLIB_FAIL;
+      hipLaunchKernelGGL((spmm_csr_kernel<OP, VEC, LPR, NCH, WAVES, true>), dim3((unsigned)gx, ny, 1),
+                         dim3(WAVES * 64, 1, 1), 0, st, a);
+      int rc = check_launch("spmm_csr_kernel<sliced>");
+      if (rc) return rc;
+      int64_t blocks = (a.m * (a.k / VEC) + 255) / 256;
+      if (blocks > 256 * 32) blocks = 256 * 32;
+      hipLaunchKernelGGL((combine_slices_kernel<OP, VEC>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+      return check_launch("combine_slices_kernel");
+   }
+   hipLaunchKernelGGL((spmm_csr_kernel<OP, VEC, LPR, NCH, WAVES, false>), dim3((unsigned)nb, ny, 1),
+                      dim3(WAVES * 64, 1, 1), 0, st, a);
    return check_launch("spmm_csr_kernel");
 }
 
+int g_force_lpr = 0;   // tuning knob (isplib_hip_tune): lanes per row slot, 0 = by K
+
 template <int OP, int VEC>
 static int launch_vec(const SpmmArgs &a, hipStream_t st) {
-   const int64_t width = a.k / VEC;   // vector columns
+   int64_t width = a.k / VEC;   // vector columns
+   if (g_force_lpr > 0 && g_force_lpr < width) width = g_force_lpr;   // narrower slots: K swept in grid.y panels
    if (width <= 8) return launch_cfg<OP, VEC, 8, 1>(a, st);
    if (width <= 16) return launch_cfg<OP, VEC, 16, 1>(a, st);
    if (width <= 32) return launch_cfg<OP, VEC, 32, 1>(a, st);
@@ -343,12 +466,10 @@ static int launch_op(const SpmmArgs &a, hipStream_t st) {
 
 using namespace isplib;
 
-extern "C" int fusedMM_csr_hip(int32_t imessage, int64_t m, int64_t n, int64_t k, float alpha, int64_t nnz,
-                               int64_t rows, int64_t cols, const float *val, const int64_t *indx,
-                               const int64_t *pntrb, const int64_t *pntre, const float *x, int64_t ldx,
-                               const float *y, int64_t ldy, float beta, float *z, int64_t ldz, int64_t *z_arg,
-                               void *stream) {
-   (void)alpha; (void)rows; (void)cols; (void)x; (void)ldx;
+static int spmm_entry(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t nnz, const float *val,
+                      const int64_t *indx, const int64_t *pntrb, const int64_t *pntre, const float *y, int64_t ldy,
+                      float beta, float *z, int64_t ldz, int64_t *z_arg, const int64_t *sliceptr, int slices,
+                      void *workspace, size_t workspace_bytes, void *stream) {
    clear_error();
    const int32_t vop = imessage & 0xF, rop = imessage & 0xF0, sop = imessage & 0xF00, vsc = imessage & 0xF000,
                  aop = imessage & 0xF0000;
@@ -375,10 +496,56 @@ extern "C" int fusedMM_csr_hip(int32_t imessage, int64_t m, int64_t n, int64_t k
    a.mean = (vsc == ISPLIB_VSC_MEAN) ? 1 : 0;
    a.long_row = 2048;
    a.nblk = 0;
+   a.sliceptr = nullptr; a.slices = 1; a.sl_per_xcd = 1; a.part_val = nullptr; a.part_idx = nullptr;
+   if (sliceptr) {
+      if (slices < 8 || slices % 8 != 0) return fail(ISPLIB_FAIL, "fusedMM_csr_sliced_hip: slices must be a positive multiple of 8");
+      const size_t need = isplib_spmm_sliced_workspace_bytes(imessage, m, k, slices);
+      if (!workspace || workspace_bytes < need) return fail(ISPLIB_NOT_ENOUGH_MEM, "fusedMM_csr_sliced_hip: workspace too small");
+      if (((uintptr_t)workspace & 255) != 0) return fail(ISPLIB_FAIL, "fusedMM_csr_sliced_hip: workspace must be 256-byte aligned");
+      a.sliceptr = sliceptr; a.slices = slices; a.sl_per_xcd = slices / 8;
+      a.part_val = (float *)workspace;
+      const size_t plane = ((size_t)slices * (size_t)m * (size_t)k * sizeof(float) + 255) & ~(size_t)255;
+      a.part_idx = aop == ISPLIB_AOP_ADD ? nullptr : (int *)((char *)workspace + plane);
+   }
    hipStream_t st = (hipStream_t)stream;
    if (aop == ISPLIB_AOP_ADD) return launch_op<OP_ADD>(a, st);
    if (aop == ISPLIB_AOP_MAX) return launch_op<OP_MAX>(a, st);
    return launch_op<OP_MIN>(a, st);
+}
+
+extern "C" int fusedMM_csr_hip(int32_t imessage, int64_t m, int64_t n, int64_t k, float alpha, int64_t nnz,
+                               int64_t rows, int64_t cols, const float *val, const int64_t *indx,
+                               const int64_t *pntrb, const int64_t *pntre, const float *x, int64_t ldx,
+                               const float *y, int64_t ldy, float beta, float *z, int64_t ldz, int64_t *z_arg,
+                               void *stream) {
+   (void)alpha; (void)rows; (void)cols; (void)x; (void)ldx;
+   return spmm_entry(imessage, m, n, k, nnz, val, indx, pntrb, pntre, y, ldy, beta, z, ldz, z_arg, nullptr, 1, nullptr,
+                     0, stream);
+}
+
+extern "C" size_t isplib_spmm_sliced_workspace_bytes(int32_t imessage, int64_t m, int64_t k, int slices) {
+   if (m <= 0 || k <= 0 || slices <= 0) return 256;
+   const size_t plane = ((size_t)slices * (size_t)m * (size_t)k * sizeof(float) + 255) & ~(size_t)255;
+   const bool minmax = (imessage & 0xF0000) != ISPLIB_AOP_ADD;
+   return plane * (minmax ? 2 : 1);
+}
+
+extern "C" int fusedMM_csr_sliced_hip(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t nnz,
+                                      const float *val, const int64_t *indx, const int64_t *pntrb,
+                                      const int64_t *pntre, const int64_t *sliceptr, int slices, const float *y,
+                                      int64_t ldy, float *z, int64_t ldz, int64_t *z_arg, void *workspace,
+                                      size_t workspace_bytes, void *stream) {
+   if (!sliceptr) {
+      clear_error();
+      return fail(ISPLIB_FAIL, "fusedMM_csr_sliced_hip: sliceptr is required");
+   }
+   return spmm_entry(imessage, m, n, k, nnz, val, indx, pntrb, pntre, y, ldy, 0.0f, z, ldz, z_arg, sliceptr, slices,
+                     workspace, workspace_bytes, stream);
+}
+
+extern "C" int isplib_hip_tune(int key, int value) {
+   if (key == 0) { g_force_lpr = value; return ISPLIB_SUCCESS; }
+   return ISPLIB_FAIL;
 }
 
 extern "C" void performDummySpMM_hip(int64_t flag, void *stream) {

@@ -25,21 +25,30 @@ def _assert_sum_close(got, ref, tol):
     assert np.all(err <= tol[fin]), f"max err/tol = {np.max(err / tol[fin])}"
 
 
-def _run_all(gpu, oracle, rowptr, col, val, x, unit=False):
+def _run_all(gpu, oracle, rowptr, col, val, x, unit=False, slices=(8, 16)):
+    """Every reduction through both boundary entry points: fusedMM_csr_hip and, when the rows
+    are column-sorted, fusedMM_csr_sliced_hip for each slice count."""
     from isplib_amd import cabi
     d_rowptr, d_col, d_x = _t(rowptr, gpu), _t(col, gpu), _t(x, gpu)
     d_val = None if unit else _t(val, gpu)
     tol = cases.sum_tolerance(oracle, rowptr, col, val, x)
+    tables = []
+    for s in slices:
+        table, ok = cabi.spmm_slices(d_rowptr, d_col, x.shape[0], s)
+        assert ok, "test graphs are column-sorted"
+        tables.append((s, table))
     for red in cases.REDUCES:
         ref, ref_arg = oracle.spmm_fw(rowptr, col, val, x, red)
-        out, arg = cabi.spmm(d_rowptr, d_col, d_val, d_x, red)
+        results = [("plain", cabi.spmm(d_rowptr, d_col, d_val, d_x, red))]
+        results += [(f"sliced{s}", cabi.spmm_sliced(d_rowptr, d_col, d_val, t, s, d_x, red)) for s, t in tables]
         torch.cuda.synchronize()
-        out = out.cpu().numpy()
-        if red in ("sum", "mean"):
-            _assert_sum_close(out, ref, tol)
-        else:
-            assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), f"{red}: values not bit-exact"
-            assert np.array_equal(arg.cpu().numpy(), ref_arg), f"{red}: arg indices differ"
+        for name, (out, arg) in results:
+            out = out.cpu().numpy()
+            if red in ("sum", "mean"):
+                _assert_sum_close(out, ref, tol)
+            else:
+                assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), f"{red}/{name}: values not bit-exact"
+                assert np.array_equal(arg.cpu().numpy(), ref_arg), f"{red}/{name}: arg indices differ"
 
 
 @pytest.mark.parametrize("k", cases.WIDTHS)
@@ -143,3 +152,35 @@ def test_run_twice_bitwise_identical(gpu):
     a, _ = cabi.spmm(*d, "sum")
     b, _ = cabi.spmm(*d, "sum")
     assert torch.equal(a, b)
+
+
+def test_slice_table_detects_unsorted_rows(gpu):
+    from isplib_amd import cabi
+    rowptr = torch.tensor([0, 3, 5], device=gpu)
+    col = torch.tensor([0, 2, 1, 0, 1], device=gpu)
+    _, ok = cabi.spmm_slices(rowptr, col, 3, 8)
+    assert not ok
+    col = torch.tensor([0, 1, 2, 0, 1], device=gpu)
+    table, ok = cabi.spmm_slices(rowptr, col, 3, 8)
+    assert ok
+    t = table.view(2, 9).cpu()
+    assert t[0, 0] == 0 and t[0, 8] == 3 and t[1, 0] == 3 and t[1, 8] == 5
+    assert bool((t[:, 1:] >= t[:, :-1]).all())
+
+
+def test_sliced_status_codes(gpu):
+    from isplib_amd import cabi
+    rowptr = torch.tensor([0, 1], device=gpu)
+    col = torch.tensor([0], device=gpu)
+    y = torch.ones((1, 4), device=gpu)
+    z = torch.empty((1, 4), device=gpu)
+    table, _ = cabi.spmm_slices(rowptr, col, 1, 8)
+    small = torch.empty(16, dtype=torch.uint8, device=gpu)
+    assert cabi.fusedMM_csr_sliced_hip(cabi.MSG_SPMM_SUM, rowptr, col, None, table, 8, y, z, None, small,
+                                       check=False) == cabi.NOT_ENOUGH_MEM
+    ws = cabi.sliced_workspace("sum", 1, 4, 8, gpu)
+    assert cabi.fusedMM_csr_sliced_hip(cabi.MSG_SPMM_SUM, rowptr, col, None, table, 12, y, z, None, ws,
+                                       check=False) == cabi.FAIL
+    assert cabi.fusedMM_csr_sliced_hip(cabi.MSG_SPMM_SUM, rowptr, col, None, table, 8, y, z, None, ws) == cabi.SUCCESS
+    torch.cuda.synchronize()
+    assert torch.all(z == 1.0)
