@@ -59,8 +59,9 @@ void check_float(const Tensor &t, const char *name) {
 void *current_stream(const Tensor &t) { return (void *)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
 
 // fusedmm_spmm_fw, csrc/fusedmm.cpp:113-203
+// `slices_`: optional per-graph slice table (isplib_spmm_slices_build_hip) -> column-sliced kernel
 std::tuple<Tensor, Tensor> spmm_fw(const Tensor &rowptr_, const Tensor &col_, const optional<Tensor> &value_,
-                                   const Tensor &mat_, int reduction) {
+                                   const Tensor &mat_, int reduction, const Tensor &slices_ = Tensor()) {
    check_index(rowptr_, "rowptr");
    check_index(col_, "col");
    check_float(mat_, "mat");
@@ -84,6 +85,21 @@ std::tuple<Tensor, Tensor> spmm_fw(const Tensor &rowptr_, const Tensor &col_, co
    if (reduction == R_MEAN) msg = ISPLIB_MSG_SPMM_MEAN;
    if (reduction == R_MAX || reduction == R_MIN) arg = at::empty({M, K}, rowptr.options());
    const int64_t *rp = rowptr.data_ptr<int64_t>();
+   if (slices_.defined() && M > 0 && K > 0) {
+      check_index(slices_, "slices");
+      const Tensor table = slices_.contiguous();
+      TORCH_CHECK(table.numel() % M == 0 && table.numel() / M >= 9, "isplib: slice table does not match rowptr");
+      const int nsl = (int)(table.numel() / M - 1);
+      const size_t ws = isplib_spmm_sliced_workspace_bytes(msg, M, K, nsl);
+      Tensor work = at::empty({(int64_t)ws}, mat.options().dtype(at::kByte));
+      const int st = fusedMM_csr_sliced_hip(msg, M, N, K, nnz, value.defined() ? value.data_ptr<float>() : nullptr,
+                                            col.data_ptr<int64_t>(), rp, rp + 1, table.data_ptr<int64_t>(), nsl,
+                                            mat.data_ptr<float>(), K, out.data_ptr<float>(), K,
+                                            arg.defined() ? arg.data_ptr<int64_t>() : nullptr, work.data_ptr(), ws,
+                                            current_stream(mat));
+      check_status(st, "fusedMM_csr_sliced_hip");
+      return std::make_tuple(out, arg);
+   }
    const int st = fusedMM_csr_hip(msg, M, N, K, 1.0f, nnz, M, N, value.defined() ? value.data_ptr<float>() : nullptr,
                                   col.data_ptr<int64_t>(), rp, rp + 1, nullptr, K, mat.data_ptr<float>(), K, 0.0f,
                                   out.data_ptr<float>(), K, arg.defined() ? arg.data_ptr<int64_t>() : nullptr,
@@ -144,9 +160,11 @@ class SpmmSum : public torch::autograd::Function<SpmmSum> {
    static variable_list forward(AutogradContext *ctx, optional<Variable> opt_row, Variable rowptr, Variable col,
                                 optional<Variable> opt_value, optional<Variable> opt_colptr,
                                 optional<Variable> opt_csr2csc, Variable mat, optional<Variable> value_index_select,
-                                optional<Variable> row_index_select) {
+                                optional<Variable> row_index_select, optional<Variable> slices,
+                                optional<Variable> slices_t) {
       const bool has_value = opt_value.has_value() && opt_value->defined();
-      auto out = std::get<0>(spmm_fw(rowptr, col, opt_value, mat, R_SUM));   // :244
+      auto out = std::get<0>(spmm_fw(rowptr, col, opt_value, mat, R_SUM, or_undef(slices)));   // :244
+      ctx->saved_data["slices_t"] = or_undef(slices_t);
       ctx->saved_data["has_value"] = has_value;
       ctx->saved_data["value_edge"] = edge_of({present(opt_row), true, true});
       ctx->saved_data["mat_edge"] =
@@ -172,14 +190,15 @@ class SpmmSum : public torch::autograd::Function<SpmmSum> {
          // :285  grad_mat = fusedmm_spmm_fw(colptr, row_index_select, value_index_select, grad_out)
          if (colptr.defined() && row_sel.defined() && (value_sel.defined() || !has_value)) {
             optional<Tensor> v = has_value ? optional<Tensor>(value_sel) : c10::nullopt;
-            grad_mat = std::get<0>(spmm_fw(colptr, row_sel, v, grad_out, R_SUM));
+            grad_mat = std::get<0>(spmm_fw(colptr, row_sel, v, grad_out, R_SUM, ctx->saved_data["slices_t"].toTensor()));
          } else {
             auto t = build_transpose(rowptr, col, has_value ? value : Tensor(), mat.size(0), false);
             optional<Tensor> v = has_value ? optional<Tensor>(t.val_t) : c10::nullopt;
             grad_mat = std::get<0>(spmm_fw(t.colptr, t.row_t, v, grad_out, R_SUM));
          }
       }
-      return {Variable(), Variable(), Variable(), grad_value, Variable(), Variable(), grad_mat, Variable(), Variable()};
+      return {Variable(), Variable(), Variable(), grad_value, Variable(), Variable(),
+              grad_mat,   Variable(), Variable(), Variable(),  Variable()};
    }
 };
 
@@ -189,9 +208,11 @@ class SpmmMean : public torch::autograd::Function<SpmmMean> {
    static variable_list forward(AutogradContext *ctx, optional<Variable> opt_row, Variable rowptr, Variable col,
                                 optional<Variable> opt_value, optional<Variable> opt_rowcount,
                                 optional<Variable> opt_colptr, optional<Variable> opt_csr2csc, Variable mat,
-                                optional<Variable> new_row, optional<Variable> new_rowcount) {
+                                optional<Variable> new_row, optional<Variable> new_rowcount,
+                                optional<Variable> slices, optional<Variable> slices_t) {
       const bool has_value = opt_value.has_value() && opt_value->defined();
-      auto out = std::get<0>(spmm_fw(rowptr, col, opt_value, mat, R_MEAN));   // :331
+      auto out = std::get<0>(spmm_fw(rowptr, col, opt_value, mat, R_MEAN, or_undef(slices)));   // :331
+      ctx->saved_data["slices_t"] = or_undef(slices_t);
       ctx->saved_data["has_value"] = has_value;
       ctx->saved_data["value_edge"] = edge_of({present(opt_row), true, true});
       ctx->saved_data["mat_edge"] = edge_of({present(opt_row), true, true, has_value, present(opt_rowcount),
@@ -220,14 +241,15 @@ class SpmmMean : public torch::autograd::Function<SpmmMean> {
                              new_row.numel() == col.numel() && new_rowcount.numel() == col.numel() &&
                              new_rowcount.scalar_type() == at::kFloat && new_row.is_cuda();
          if (cached) {
-            grad_mat = std::get<0>(spmm_fw(colptr, new_row, optional<Tensor>(new_rowcount), grad_out, R_SUM));
+            grad_mat = std::get<0>(spmm_fw(colptr, new_row, optional<Tensor>(new_rowcount), grad_out, R_SUM,
+                                           ctx->saved_data["slices_t"].toTensor()));
          } else {
             auto t = build_transpose(rowptr, col, has_value ? value : Tensor(), mat.size(0), true);
             grad_mat = std::get<0>(spmm_fw(t.colptr, t.row_t, optional<Tensor>(t.val_t), grad_out, R_SUM));
          }
       }
       return {Variable(), Variable(), Variable(), grad_value, Variable(), Variable(),
-              Variable(), grad_mat,   Variable(), Variable()};
+              Variable(), grad_mat,   Variable(), Variable(), Variable(),  Variable()};
    }
 };
 
@@ -236,9 +258,9 @@ template <int RED>
 class SpmmMinMax : public torch::autograd::Function<SpmmMinMax<RED>> {
  public:
    static variable_list forward(AutogradContext *ctx, Variable rowptr, Variable col, optional<Variable> opt_value,
-                                Variable mat) {
+                                Variable mat, optional<Variable> slices) {
       const bool has_value = opt_value.has_value() && opt_value->defined();
-      auto result = spmm_fw(rowptr, col, opt_value, mat, RED);   // :397 / :465
+      auto result = spmm_fw(rowptr, col, opt_value, mat, RED, or_undef(slices));   // :397 / :465
       auto out = std::get<0>(result);
       auto arg_out = std::get<1>(result);
       ctx->saved_data["has_value"] = has_value;
@@ -269,7 +291,7 @@ class SpmmMinMax : public torch::autograd::Function<SpmmMinMax<RED>> {
              need_val ? grad_value.data_ptr<float>() : nullptr, current_stream(y));
          check_status(st, "isplib_spmm_minmax_bw_hip");
       }
-      return {Variable(), Variable(), grad_value, grad_mat};
+      return {Variable(), Variable(), grad_value, grad_mat, Variable()};
    }
 };
 
@@ -278,23 +300,55 @@ Tensor fusedmm_spmm_add(optional<Tensor> opt_row, Tensor rowptr, Tensor col, opt
                         optional<Tensor> opt_colptr, optional<Tensor> opt_csr2csc, Tensor mat,
                         optional<Tensor> value_index_select, optional<Tensor> row_index_select) {
    return SpmmSum::apply(opt_row, rowptr, col, opt_value, opt_colptr, opt_csr2csc, mat, value_index_select,
-                         row_index_select)[0];
+                         row_index_select, optional<Tensor>(), optional<Tensor>())[0];
 }
+
+// same op with the per-graph slice tables of A (forward) and A^T (backward): column-sliced kernels
+Tensor fusedmm_spmm_sliced(Tensor rowptr, Tensor col, optional<Tensor> opt_value, optional<Tensor> opt_colptr,
+                           Tensor mat, optional<Tensor> value_t, optional<Tensor> row_t, optional<Tensor> slices,
+                           optional<Tensor> slices_t) {
+   return SpmmSum::apply(optional<Tensor>(), rowptr, col, opt_value, opt_colptr, optional<Tensor>(), mat, value_t,
+                         row_t, slices, slices_t)[0];
+}
+
+Tensor fusedmm_spmm_mean_sliced(Tensor rowptr, Tensor col, optional<Tensor> opt_value, optional<Tensor> opt_colptr,
+                                Tensor mat, optional<Tensor> row_t, optional<Tensor> mean_value_t,
+                                optional<Tensor> slices, optional<Tensor> slices_t) {
+   return SpmmMean::apply(optional<Tensor>(), rowptr, col, opt_value, optional<Tensor>(), opt_colptr,
+                          optional<Tensor>(), mat, row_t, mean_value_t, slices, slices_t)[0];
+}
+
+std::tuple<Tensor, Tensor> fusedmm_spmm_max_sliced(Tensor rowptr, Tensor col, optional<Tensor> opt_value, Tensor mat,
+                                                   optional<Tensor> slices);
+std::tuple<Tensor, Tensor> fusedmm_spmm_min_sliced(Tensor rowptr, Tensor col, optional<Tensor> opt_value, Tensor mat,
+                                                   optional<Tensor> slices);
 
 Tensor fusedmm_spmm_mean(optional<Tensor> opt_row, Tensor rowptr, Tensor col, optional<Tensor> opt_value,
                          optional<Tensor> opt_rowcount, optional<Tensor> opt_colptr, optional<Tensor> opt_csr2csc,
                          Tensor mat, optional<Tensor> new_row, optional<Tensor> new_rowcount) {
    return SpmmMean::apply(opt_row, rowptr, col, opt_value, opt_rowcount, opt_colptr, opt_csr2csc, mat, new_row,
-                          new_rowcount)[0];
+                          new_rowcount, optional<Tensor>(), optional<Tensor>())[0];
 }
 
 std::tuple<Tensor, Tensor> fusedmm_spmm_max(Tensor rowptr, Tensor col, optional<Tensor> opt_value, Tensor mat) {
-   auto r = SpmmMinMax<R_MAX>::apply(rowptr, col, opt_value, mat);
+   auto r = SpmmMinMax<R_MAX>::apply(rowptr, col, opt_value, mat, optional<Tensor>());
+   return std::make_tuple(r[0], r[1]);
+}
+
+std::tuple<Tensor, Tensor> fusedmm_spmm_max_sliced(Tensor rowptr, Tensor col, optional<Tensor> opt_value, Tensor mat,
+                                                   optional<Tensor> slices) {
+   auto r = SpmmMinMax<R_MAX>::apply(rowptr, col, opt_value, mat, slices);
+   return std::make_tuple(r[0], r[1]);
+}
+
+std::tuple<Tensor, Tensor> fusedmm_spmm_min_sliced(Tensor rowptr, Tensor col, optional<Tensor> opt_value, Tensor mat,
+                                                   optional<Tensor> slices) {
+   auto r = SpmmMinMax<R_MIN>::apply(rowptr, col, opt_value, mat, slices);
    return std::make_tuple(r[0], r[1]);
 }
 
 std::tuple<Tensor, Tensor> fusedmm_spmm_min(Tensor rowptr, Tensor col, optional<Tensor> opt_value, Tensor mat) {
-   auto r = SpmmMinMax<R_MIN>::apply(rowptr, col, opt_value, mat);
+   auto r = SpmmMinMax<R_MIN>::apply(rowptr, col, opt_value, mat, optional<Tensor>());
    return std::make_tuple(r[0], r[1]);
 }
 
@@ -315,4 +369,15 @@ TORCH_LIBRARY(isplib, m) {
    m.def("fusedmm_spmm_min(Tensor rowptr, Tensor col, Tensor? value, Tensor mat) -> (Tensor, Tensor)",
          &fusedmm_spmm_min);
    m.def("performDummySpMM(int flag) -> ()", &performDummySpMM);
+   // additions (not in the reference): the same operators fed with per-graph slice tables
+   m.def("fusedmm_spmm_sliced(Tensor rowptr, Tensor col, Tensor? value, Tensor? colptr, Tensor mat, Tensor? value_t, "
+         "Tensor? row_t, Tensor? slices, Tensor? slices_t) -> Tensor",
+         &fusedmm_spmm_sliced);
+   m.def("fusedmm_spmm_mean_sliced(Tensor rowptr, Tensor col, Tensor? value, Tensor? colptr, Tensor mat, Tensor? row_t, "
+         "Tensor? mean_value_t, Tensor? slices, Tensor? slices_t) -> Tensor",
+         &fusedmm_spmm_mean_sliced);
+   m.def("fusedmm_spmm_max_sliced(Tensor rowptr, Tensor col, Tensor? value, Tensor mat, Tensor? slices) -> (Tensor, Tensor)",
+         &fusedmm_spmm_max_sliced);
+   m.def("fusedmm_spmm_min_sliced(Tensor rowptr, Tensor col, Tensor? value, Tensor mat, Tensor? slices) -> (Tensor, Tensor)",
+         &fusedmm_spmm_min_sliced);
 }

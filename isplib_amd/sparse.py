@@ -39,6 +39,9 @@ class SparseStorage:
         self._row_t: Optional[torch.Tensor] = None
         self._val_t: Optional[torch.Tensor] = None
         self._mean_val_t: Optional[torch.Tensor] = None
+        # slice tables of the column-sliced kernels, {n_slices: table | None (rows not sorted)}
+        self._slices = {}
+        self._slices_t = {}
 
     def sparse_sizes(self) -> Tuple[int, int]:
         return self._sparse_sizes
@@ -87,6 +90,20 @@ class SparseStorage:
         if self._value is not None and self._val_t is None:
             self._build_transpose()
         return self._val_t
+
+    def slices(self, n_slices: int) -> Optional[torch.Tensor]:
+        """Slice table of A for fusedMM_csr_sliced_hip, or None when rows are not column-sorted."""
+        if n_slices not in self._slices:
+            table, ok = cabi.spmm_slices(self._rowptr, self._col, self._sparse_sizes[1], n_slices)
+            self._slices[n_slices] = table if ok else None
+        return self._slices[n_slices]
+
+    def slices_t(self, n_slices: int) -> Optional[torch.Tensor]:
+        """Slice table of A^T (CSC operands are sorted by construction)."""
+        if n_slices not in self._slices_t:
+            table, ok = cabi.spmm_slices(self.colptr(), self.row_t(), self._sparse_sizes[0], n_slices)
+            self._slices_t[n_slices] = table if ok else None
+        return self._slices_t[n_slices]
 
     def mean_val_t(self) -> torch.Tensor:
         """value[csr2csc] / max(rowcount,1)[row[csr2csc]] (csrc/fusedmm.cpp:357-364)."""

@@ -1,0 +1,229 @@
+"""CPU tests of the host side (no GPU, no compute calls into the HIP library):
+the C ABI library loads and exports every symbol include/isplib_hip.h declares,
+the torch operator surface has the reference's names, CPU tensors are refused
+loudly (no silent fallback), the plug-in patches/unpatches LIFO, and the 1-D row
+partition is equivalent to the whole graph on a 2-rank gloo job.
+"""
+import os
+import re
+import subprocess
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from tests import cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "isplib_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"^\s*(?:const\s+)?(?:int|void|size_t|char)\s*\*?\s*(\w+)\s*\(", text, flags=re.M)
+    return sorted(set(names))
+
+
+def test_header_declares_expected_entry_points():
+    names = _declared_functions()
+    for must in ("fusedMM_csr_hip", "fusedMM_csr_sliced_hip", "performDummySpMM_hip", "isplib_spmm_minmax_bw_hip",
+                 "isplib_sddmm_csr_hip", "isplib_csr2csc_hip", "isplib_spmm_slices_build_hip"):
+        assert must in names
+
+
+def test_cabi_library_exports_every_declared_symbol():
+    from isplib_amd import _lib, cabi
+    assert os.path.exists(_lib.CABI_PATH), "libisplib_hip.so not built (python -c 'import __graft_entry__ as g; g.build()')"
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.CABI_PATH], text=True)
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    declared = _declared_functions()
+    missing = [n for n in declared if n not in exported]
+    assert not missing, f"declared in include/isplib_hip.h but not exported: {missing}"
+    assert sorted(cabi.EXPORTS) == declared, "isplib_amd.cabi.EXPORTS out of sync with the header"
+    L = cabi.lib()
+    for n in declared:
+        getattr(L, n)
+    assert L.isplib_hip_abi_version() == 1
+    assert cabi.last_error() == ""
+
+
+def test_cabi_argument_validation_without_gpu():
+    """Status codes that are decided before any HIP call."""
+    from isplib_amd import cabi
+    L = cabi.lib()
+    st = L.fusedMM_csr_hip(0x11103, 1, 1, 1, 1.0, 0, 1, 1, None, None, None, None, None, 1, None, 1, 0.0, None, 1, None, None)
+    assert st == cabi.NO_OPT_IMPL and "SpMM" in cabi.last_error()
+    st = L.fusedMM_csr_hip(cabi.MSG_SPMM_SUM, 1, 1, 1, 1.0, 0, 1, 1, None, None, None, None, None, 1, None, 1, 0.5, None, 1, None, None)
+    assert st == cabi.FAIL and "beta" in cabi.last_error()
+    st = L.fusedMM_csr_hip(cabi.MSG_SPMM_SUM, 0, 0, 4, 1.0, 0, 0, 0, None, None, None, None, None, 4, None, 4, 0.0, None, 4, None, None)
+    assert st == cabi.SUCCESS            # m == 0: nothing to do
+    st = L.fusedMM_csr_hip(cabi.MSG_SPMM_SUM, 2, 1 << 31, 4, 1.0, 0, 2, 2, None, None, None, None, None, 4, None, 4, 0.0, None, 4, None, None)
+    assert st == cabi.FAIL and "2^31" in cabi.last_error()
+    assert L.isplib_spmm_slices_bytes(10, 8) == 10 * 9 * 8
+    assert L.isplib_spmm_sliced_workspace_bytes(cabi.MSG_SPMM_SUM, 10, 4, 8) >= 8 * 10 * 4 * 4
+    assert L.isplib_spmm_sliced_workspace_bytes(cabi.MSG_SPMM_MAX, 10, 4, 8) >= 2 * 8 * 10 * 4 * 4
+
+
+def test_torch_ops_have_reference_names_and_schemas():
+    import isplib_amd  # noqa: F401
+    ops = torch.ops.isplib
+    s = str(ops.fusedmm_spmm.default._schema)
+    assert "Tensor? row, Tensor rowptr, Tensor col, Tensor? value, Tensor? colptr, Tensor? csr2csc, Tensor mat" in s
+    assert "value_index_select" in s and "row_index_select" in s
+    s = str(ops.fusedmm_spmm_mean.default._schema)
+    assert "Tensor? rowcount" in s and "new_row" in s and "new_rowcount" in s
+    for name in ("fusedmm_spmm_max", "fusedmm_spmm_min"):
+        s = str(getattr(ops, name).default._schema)
+        assert "Tensor rowptr, Tensor col, Tensor? value, Tensor mat" in s and "-> (Tensor, Tensor)" in s
+    assert "int flag" in str(ops.performDummySpMM.default._schema)
+
+
+def test_cpu_tensors_are_refused_not_silently_served():
+    import isplib_amd
+    rowptr, col = torch.tensor([0, 1, 2]), torch.tensor([0, 1])
+    x = torch.ones(2, 4)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        torch.ops.isplib.fusedmm_spmm(None, rowptr, col, None, None, None, x, None, None)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        torch.ops.isplib.fusedmm_spmm_max(rowptr, col, None, x)
+    adj = isplib_amd.SparseTensor.from_csr(rowptr, col, None, (2, 2))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        isplib_amd.matmul(adj, x)
+    with pytest.raises(ValueError, match="unknown reduce"):
+        isplib_amd.matmul(adj, x, "prod")
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        isplib_amd.cabi.spmm(rowptr, col, None, x)
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "isplib_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text and "fusedmm_oracle" not in text, f
+
+
+def test_sparse_tensor_coo_to_csr_keeps_torch_sparse_order():
+    import isplib_amd
+    # README.md:105-110: duplicates (0,0) keep their input order (3 then -2)
+    adj = isplib_amd.SparseTensor(row=torch.tensor([2, 0, 1, 0, 0]), col=torch.tensor([1, 0, 0, 2, 0]),
+                                  value=torch.tensor([3., 3., 4., 2., -2.]), sparse_sizes=(3, 3))
+    rowptr, col, val = adj.csr()
+    e_rowptr, e_col, e_val, *_ = cases.readme_case()
+    assert rowptr.tolist() == e_rowptr.tolist() and col.tolist() == e_col.tolist() and val.tolist() == e_val.tolist()
+    assert adj.storage.rowcount().tolist() == [3, 1, 1]
+    with pytest.raises(ValueError, match="out of range"):
+        isplib_amd.SparseTensor(row=torch.tensor([0]), col=torch.tensor([5]), sparse_sizes=(2, 2))
+    with pytest.raises(ValueError, match="monotone"):
+        isplib_amd.SparseTensor(rowptr=torch.tensor([0, 2, 1]), col=torch.tensor([0]), sparse_sizes=(2, 2))
+
+
+def test_patch_unpatch_is_lifo_and_restores(monkeypatch):
+    import isplib_amd
+    from isplib_amd import plugin
+    fake_ts = types.SimpleNamespace(matmul=lambda *a, **k: "torch_sparse.matmul")
+    fake_typing = types.SimpleNamespace(WITH_PT2=True, WITH_PT20=True)
+    monkeypatch.setattr(plugin, "_torch_sparse", fake_ts)
+    monkeypatch.setattr(plugin, "_pyg_typing", fake_typing)
+    orig_ts, orig_mm = fake_ts.matmul, torch.sparse.mm
+    assert not isplib_amd.iSpLibPlugin.is_patched()
+    isplib_amd.iSpLibPlugin.patch_pyg()
+    assert fake_ts.matmul is plugin.spmm_autotuned and torch.sparse.mm is not orig_mm
+    assert fake_typing.WITH_PT2 is False and fake_typing.WITH_PT20 is False       # isplib/__init__.py:168-169
+    isplib_amd.iSpLibPlugin.patch_pyg()                                            # nested
+    isplib_amd.iSpLibPlugin.unpatch_pyg()
+    assert fake_ts.matmul is plugin.spmm_autotuned                                 # still patched (LIFO)
+    isplib_amd.iSpLibPlugin.unpatch_pyg()
+    assert fake_ts.matmul is orig_ts and torch.sparse.mm is orig_mm
+    assert fake_typing.WITH_PT2 is True and fake_typing.WITH_PT20 is True
+    isplib_amd.iSpLibPlugin.unpatch_pyg()                                          # extra unpatch is a no-op (:190)
+
+    @isplib_amd.isplib_autotune
+    def inside():
+        return fake_ts.matmul is plugin.spmm_autotuned
+
+    assert inside() and fake_ts.matmul is orig_ts
+
+
+def test_patched_sparse_mm_still_serves_torch_sparse_tensors():
+    import isplib_amd
+    a = torch.eye(3).to_sparse()
+    isplib_amd.iSpLibPlugin.patch_pyg()
+    try:
+        out = torch.sparse.mm(a, torch.ones(3, 2))
+    finally:
+        isplib_amd.iSpLibPlugin.unpatch_pyg()
+    assert torch.equal(out, torch.ones(3, 2))
+
+
+def test_synthetic_graphs_have_dataset_shapes():
+    from isplib_amd import synth
+    rowptr, col, n = synth.dataset_like("cora")
+    assert n == 2708 and col.numel() == 10556 and rowptr.numel() == n + 1
+    deg = rowptr[1:] - rowptr[:-1]
+    row = torch.repeat_interleave(torch.arange(n), deg)
+    key = row * n + col
+    assert bool((key[1:] > key[:-1]).all()), "rows / in-row columns must be sorted, no duplicates"
+    assert torch.equal(torch.sort(col * n + row).values, key), "must be symmetric"
+    assert bool((row != col).all())
+    # B_alg of config 2
+    assert synth.algorithmic_bytes(232965, 232965, 114615892, 128) == 1615810592
+
+
+# ---- 1-D row partition, world_size 2 over gloo -----------------------------------------------
+
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+import oracle
+from isplib_amd.dist import RowPartition
+from tests import cases
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+rowptr, col = cases.random_csr(97, 97, 11.0, seed=5, empty_rows=(0, 50), hub=(3, 400))
+val = cases.weights(col.size, 4)
+x = cases.dense(97, 24, 3, "integer")
+t = torch.from_numpy
+part = RowPartition(t(rowptr), t(col), t(val), 97, rank, world)
+buf = part.gather_buffer(24)
+part.all_gather(part.shard(t(x)), buf)                      # the ONE collective
+assert torch.equal(part.unpad(buf), t(x))
+for red in ("sum", "mean", "max", "min"):
+    ref, ref_arg = oracle.spmm_fw(rowptr, col, val, x, red)
+    # local SpMM of this rank's rows straight from the padded gather buffer (oracle stands in for the GPU kernel)
+    out, arg = oracle.spmm_fw(part.rowptr.numpy(), part.col_padded.numpy(), part.val.numpy(), buf.numpy(), red)
+    r0, r1 = part.row_cuts[rank], part.row_cuts[rank + 1]
+    assert np.array_equal(out, ref[r0:r1]), red             # bit-identical to the single-device rows
+    if arg is not None:
+        garg = np.where(arg == part.nnz, part.total_nnz, arg + part.edge0)
+        assert np.array_equal(garg, ref_arg[r0:r1]), red
+sizes = [part.row_cuts[i + 1] - part.row_cuts[i] for i in range(world)]
+assert sum(sizes) == 97
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_row_partition_equivalence_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{o}"
+        assert f"rank {r} ok" in o
+
+
+def test_nnz_balanced_cuts():
+    from isplib_amd.dist import nnz_balanced_cuts
+    rowptr, _ = cases.random_csr(1000, 1000, 20.0, seed=1, hub=(10, 5000))
+    cuts = nnz_balanced_cuts(torch.from_numpy(rowptr), 4)
+    assert cuts[0] == 0 and cuts[-1] == 1000 and cuts == sorted(cuts)
+    per = [int(rowptr[cuts[i + 1]] - rowptr[cuts[i]]) for i in range(4)]
+    assert max(per) - min(per) <= 5000 + 60
