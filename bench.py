@@ -46,14 +46,6 @@ def parse():
     return p.parse_args()
 
 
-def partition_rows(rowptr: torch.Tensor, world: int):
-    """Contiguous row ranges with ~equal nnz."""
-    nnz = int(rowptr[-1])
-    targets = torch.arange(1, world, device=rowptr.device, dtype=torch.int64) * (nnz // world)
-    cuts = torch.searchsorted(rowptr, targets).tolist()
-    return [0] + cuts + [rowptr.numel() - 1]
-
-
 def cpu_baseline(rowptr, col, x, nnz):
     """Oracle on the host cores: 1 pass to gauge, then up to 2 more; median."""
     import oracle
@@ -191,9 +183,10 @@ def main():
         achieved = b_alg / (kern_avg_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and world == 1 and a.scale == 1.0:
+        # measured offline (separate --pmc passes cannot run inside this process): profiles/traffic.json
+        if os.path.exists(tpath) and world == 1 and a.scale == 1.0 and not a.weighted:
             try:
-                rec = json.load(open(tpath)).get(f"{a.workload}-{a.reduce}-k{k}")
+                rec = json.load(open(tpath)).get(f"{a.workload}-{a.reduce}-k{k}-s{a.slices}")
                 traffic = rec["hbm_bytes_per_launch"] if rec else None
             except Exception:
                 traffic = None
@@ -211,6 +204,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                "traffic_source": None if traffic is None else "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, gfx950-corrected)",
                 "kernel": "spmm_csr_kernel" + (f"<sliced x{a.slices}> + combine_slices_kernel" if a.slices > 0 else ""),
                 "kernel_avg_ms": kern_avg_ms, "algorithmic_bytes_per_launch": b_alg,
                 "gather_model_GBps": synth.gather_bytes(m_local, l_col.numel(), k) / (kern_avg_ms * 1e-3) / 1e9,
