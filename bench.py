@@ -40,7 +40,8 @@ def parse():
     p.add_argument("--reduce", default="sum", choices=["sum", "mean", "max", "min"])
     p.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only; result is then not the metric)")
     p.add_argument("--weighted", action="store_true", help="U(0,1) edge weights instead of unit weights")
-    p.add_argument("--slices", type=int, default=8, help="column slices (multiple of 8; 0 = plain row kernel)")
+    p.add_argument("--slices", type=int, default=-1,
+                   help="column slices (multiple of 8; 0 = plain row kernel; -1 = isplib_amd.plugin.suggest_slices)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-backward", action="store_true")
     return p.parse_args()
@@ -114,6 +115,9 @@ def main():
     # per-graph preparation, outside the timed region (the reference also builds its per-graph
     # operands once, isplib/__init__.py:76-106): slice table + workspace of the column-sliced path
     table = work = None
+    if a.slices < 0:
+        from isplib_amd.plugin import suggest_slices
+        a.slices = suggest_slices(m_local, x_in.size(0), l_col.numel(), k)
     if a.slices > 0:
         table, ok = cabi.spmm_slices(l_rowptr, l_col, x_in.size(0), a.slices)
         if not ok:

@@ -53,6 +53,7 @@ struct SpmmArgs {
    int mean;               // OP_ADD only: divide by max(deg,1)
    int long_row;           // rows with more edges are split across the workgroup
    unsigned nblk;          // number of row blocks
+   unsigned ybytes;        // n*ldy*4 when it fits the buffer-descriptor path, else 0
    // column-sliced mode (fusedMM_csr_sliced_hip): row i's edges with column in slice s are
    // [sliceptr[i*(slices+1)+s], sliceptr[i*(slices+1)+s+1]); slice s is walked by XCD s / sl_per_xcd
    const int64_t *sliceptr;
@@ -155,6 +156,93 @@ __device__ __forceinline__ void wave_edges(const SpmmArgs &a, int64_t row_b, int
    }
 }
 
+// Fast form of wave_edges for 16-B lanes when the whole dense operand is addressable with a
+// 32-bit byte offset (n*ldy*4 <= BUF_LIMIT): y is read through a buffer descriptor, so
+//   * the row offset is ONE 32-bit multiply per edge, done before the cross-lane hand-off
+//     (64 edges per coalesced metadata load), and one add per gather;
+//   * out-of-range lanes carry an offset past the descriptor's size: the hardware range
+//     check returns 0 for them, so the loop has no branches and no exec-mask flips;
+//   * HAS_VAL = false (unit weights) never touches the value stream and adds instead of fma.
+constexpr unsigned BUF_LIMIT = 0xE0000000u;   // bytes addressable; offsets >= BUF_OOB read as 0
+constexpr unsigned BUF_OOB = 0xF0000000u;     // + any column offset (< 2^24) stays < 2^32: never wraps
+
+typedef __attribute__((__vector_size__(4 * sizeof(int)))) int v4i_t;
+
+// UU gathers per slot issued back to back for the edges [s, s + G*UU) of the current 64-edge batch
+template <int OP, bool HAS_VAL, int LPR, int NCH, int UU>
+__device__ __forceinline__ void buf_step(const __amdgpu_buffer_rsrc_t rsrc, unsigned off_l, float v_l, int s, int cnt,
+                                         int rel0, int g, const unsigned (&cbyte)[NCH], const unsigned (&poison)[NCH],
+                                         const bool (&cok)[NCH], float (&acc)[NCH][4], int (&bi)[NCH][4]) {
+   constexpr int G = 64 / LPR;
+   v4i_t t[UU][NCH];
+   float vv[UU];
+#pragma unroll
+   for (int u = 0; u < UU; u++) {
+      const int ei = (s + u * G + g) & 63;
+      const unsigned off = (unsigned)__shfl((int)off_l, ei);
+      if (HAS_VAL) vv[u] = __shfl(v_l, ei);
+#pragma unroll
+      for (int j = 0; j < NCH; j++) {
+         // masked edge: off = BUF_OOB, + cbyte (< 2^24) cannot wrap; masked column: OR-ed past the limit
+         const unsigned o = (off + cbyte[j]) | poison[j];
+         t[u][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)o, 0, 0);
+      }
+   }
+#pragma unroll
+   for (int u = 0; u < UU; u++) {
+      const int ei = s + u * G + g;
+#pragma unroll
+      for (int j = 0; j < NCH; j++) {
+#pragma unroll
+         for (int v = 0; v < 4; v++) {
+            const float x = __int_as_float(t[u][j][v]);
+            if (OP == OP_ADD) {
+               acc[j][v] = HAS_VAL ? fmaf(vv[u], x, acc[j][v]) : acc[j][v] + x;
+            } else {
+               const float tt = HAS_VAL ? vv[u] * x : x;
+               const bool win = (ei < cnt) && cok[j] && (OP == OP_MAX ? tt > acc[j][v] : tt < acc[j][v]);
+               acc[j][v] = win ? tt : acc[j][v];
+               bi[j][v] = win ? rel0 + ei : bi[j][v];
+            }
+         }
+      }
+   }
+}
+
+template <int OP, bool HAS_VAL, int LPR, int NCH, int U>
+__device__ __forceinline__ void wave_edges_buf(const SpmmArgs &a, const __amdgpu_buffer_rsrc_t rsrc, int64_t row_b,
+                                               int64_t rb, int64_t re, const int (&ccol)[NCH], const bool (&cok)[NCH],
+                                               float (&acc)[NCH][4], int (&bi)[NCH][4]) {
+   constexpr int G = 64 / LPR;
+   constexpr int UT = U >= 4 ? 2 : 1;   // tail granularity: fewer all-masked gathers on short segments
+   const int lane = threadIdx.x & 63;
+   const int g = lane / LPR;
+   const unsigned ldyb = (unsigned)a.ldy * 4u;
+   unsigned cbyte[NCH], poison[NCH];   // lanes whose columns lie beyond k read past the descriptor too
+#pragma unroll
+   for (int j = 0; j < NCH; j++) {
+      cbyte[j] = (unsigned)ccol[j] * 4u;
+      poison[j] = cok[j] ? 0u : BUF_OOB;
+   }
+   for (int64_t base = rb; base < re; base += 64) {
+      const int64_t p = base + lane;
+      unsigned off_l = BUF_OOB;
+      float v_l = 0.0f;
+      if (p < re) {
+         off_l = (unsigned)a.indx[p] * ldyb;
+         if (HAS_VAL) v_l = a.val[p];
+      }
+      const int64_t left = re - base;
+      const int cnt = left < 64 ? (int)left : 64;
+      const int rel0 = (int)(base - row_b);
+      int s = 0;
+      for (; s + G * U <= cnt; s += G * U)
+         buf_step<OP, HAS_VAL, LPR, NCH, U>(rsrc, off_l, v_l, s, cnt, rel0, g, cbyte, poison, cok, acc, bi);
+      for (; s < cnt; s += G * UT)
+         buf_step<OP, HAS_VAL, LPR, NCH, UT>(rsrc, off_l, v_l, s, cnt, rel0, g, cbyte, poison, cok, acc, bi);
+   }
+}
+
 // butterfly over the G edge slots of a wave; every lane ends with the result
 template <int OP, int VEC, int LPR, int NCH>
 __device__ __forceinline__ void slot_reduce(float (&acc)[NCH][VEC], int (&bi)[NCH][VEC]) {
@@ -226,7 +314,8 @@ __device__ __forceinline__ void write_partial(const SpmmArgs &a, int slice, int6
    }
 }
 
-template <int OP, int VEC, int LPR, int NCH, int WAVES, bool SLICED>
+// ADDR: 0 = 64-bit addresses (any size, any VEC); 1 / 2 = buffer descriptor, unit weights / weighted (VEC = 4)
+template <int OP, int VEC, int LPR, int NCH, int WAVES, bool SLICED, int ADDR>
 __global__ __launch_bounds__(WAVES * 64) void spmm_csr_kernel(const SpmmArgs a) {
    constexpr int U = (8 / NCH) > 2 ? (8 / NCH) : 2;
    constexpr int PANEL = LPR * VEC * NCH;   // columns covered by one grid.y slice
@@ -236,6 +325,8 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_csr_kernel(const SpmmArgs a) 
    const int lane = threadIdx.x & 63;
    const int wave = threadIdx.x >> 6;
    const int g = lane / LPR, lc = lane % LPR;
+   __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+       const_cast<float *>(a.y), 0, ADDR ? (int)a.ybytes : 0, 0x00020000);   // kernarg-only: provably wave-uniform
 
    // XCD-aware remap: physical blocks pb, pb+8, ... share one XCD (speed only, never correctness).
    //  plain : each XCD walks a contiguous range of row blocks.
@@ -282,7 +373,8 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_csr_kernel(const SpmmArgs a) 
          for (int j = 0; j < NCH; j++)
 #pragma unroll
             for (int v = 0; v < VEC; v++) { acc[j][v] = identity<OP>(); bi[j][v] = INT_MAX; }
-         wave_edges<OP, VEC, LPR, NCH, U>(a, row_b, b, e, ccol, cok, acc, bi);
+         if constexpr (ADDR != 0) wave_edges_buf<OP, ADDR == 2, LPR, NCH, U>(a, rsrc, row_b, b, e, ccol, cok, acc, bi);
+         else wave_edges<OP, VEC, LPR, NCH, U>(a, row_b, b, e, ccol, cok, acc, bi);
          slot_reduce<OP, VEC, LPR, NCH>(acc, bi);
          if (g == 0) {
             if (SLICED) write_partial<OP, VEC, NCH>(a, slice, row, ccol, cok, acc, bi);
@@ -316,7 +408,8 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_csr_kernel(const SpmmArgs a) 
       for (int j = 0; j < NCH; j++)
 #pragma unroll
          for (int v = 0; v < VEC; v++) { acc[j][v] = identity<OP>(); bi[j][v] = INT_MAX; }
-      wave_edges<OP, VEC, LPR, NCH, U>(a, row_b, cb, ce, ccol, cok, acc, bi);
+      if constexpr (ADDR != 0) wave_edges_buf<OP, ADDR == 2, LPR, NCH, U>(a, rsrc, row_b, cb, ce, ccol, cok, acc, bi);
+      else wave_edges<OP, VEC, LPR, NCH, U>(a, row_b, cb, ce, ccol, cok, acc, bi);
       slot_reduce<OP, VEC, LPR, NCH>(acc, bi);
       if (g == 0) {
 #pragma unroll
@@ -414,8 +507,19 @@ __global__ __launch_bounds__(256) void combine_slices_kernel(const SpmmArgs a) {
 
 __global__ void dummy_kernel(int64_t flag) { (void)flag; }
 
+template <int OP, int VEC, int LPR, int NCH, int ADDR>
+static int launch_addr(const SpmmArgs &a0, hipStream_t st);
+
 template <int OP, int VEC, int LPR, int NCH>
-static int launch_cfg(const SpmmArgs &a0, hipStream_t st) {
+static int launch_cfg(const SpmmArgs &a, hipStream_t st) {
+   if constexpr (VEC == 4) {
+      if (a.ybytes != 0) return a.val ? launch_addr<OP, VEC, LPR, NCH, 2>(a, st) : launch_addr<OP, VEC, LPR, NCH, 1>(a, st);
+   }
+   return launch_addr<OP, VEC, LPR, NCH, 0>(a, st);
+}
+
+template <int OP, int VEC, int LPR, int NCH, int ADDR>
+static int launch_addr(const SpmmArgs &a0, hipStream_t st) {
    constexpr int WAVES = 4;
    SpmmArgs a = a0;
    const int64_t nb = (a.m + WAVES - 1) / WAVES;
@@ -426,7 +530,7 @@ static int launch_cfg(const SpmmArgs &a0, hipStream_t st) {
    if (a.sliceptr) {
       const int64_t gx = nb * a.slices;   // slices is a multiple of 8
       if (gx > 0x7fffffffLL) return ISPLIB_FAIL;
-      hipLaunchKernelGGL((spmm_csr_kernel<OP, VEC, LPR, NCH, WAVES, true>), dim3((unsigned)gx, ny, 1),
+      hipLaunchKernelGGL((spmm_csr_kernel<OP, VEC, LPR, NCH, WAVES, true, ADDR>), dim3((unsigned)gx, ny, 1),
                          dim3(WAVES * 64, 1, 1), 0, st, a);
       int rc = check_launch("spmm_csr_kernel<sliced>");
       if (rc) return rc;
@@ -435,12 +539,13 @@ static int launch_cfg(const SpmmArgs &a0, hipStream_t st) {
       hipLaunchKernelGGL((combine_slices_kernel<OP, VEC>), dim3((unsigned)blocks), dim3(256), 0, st, a);
       return check_launch("combine_slices_kernel");
    }
-   hipLaunchKernelGGL((spmm_csr_kernel<OP, VEC, LPR, NCH, WAVES, false>), dim3((unsigned)nb, ny, 1),
+   hipLaunchKernelGGL((spmm_csr_kernel<OP, VEC, LPR, NCH, WAVES, false, ADDR>), dim3((unsigned)nb, ny, 1),
                       dim3(WAVES * 64, 1, 1), 0, st, a);
    return check_launch("spmm_csr_kernel");
 }
 
 int g_force_lpr = 0;   // tuning knob (isplib_hip_tune): lanes per row slot, 0 = by K
+int g_addr_mode = 1;   // tuning knob: 0 = always 64-bit addressing, 1 = buffer descriptors when they fit
 
 template <int OP, int VEC>
 static int launch_vec(const SpmmArgs &a, hipStream_t st) {
@@ -496,6 +601,10 @@ static int spmm_entry(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t
    a.mean = (vsc == ISPLIB_VSC_MEAN) ? 1 : 0;
    a.long_row = 2048;
    a.nblk = 0;
+   {
+      const unsigned long long yb = (unsigned long long)n * (unsigned long long)ldy * 4ull;
+      a.ybytes = (yb <= BUF_LIMIT && g_addr_mode != 0) ? (unsigned)yb : 0u;
+   }
    a.sliceptr = nullptr; a.slices = 1; a.sl_per_xcd = 1; a.part_val = nullptr; a.part_idx = nullptr;
    if (sliceptr) {
       if (slices < 8 || slices % 8 != 0) return fail(ISPLIB_FAIL, "fusedMM_csr_sliced_hip: slices must be a positive multiple of 8");
@@ -545,6 +654,7 @@ extern "C" int fusedMM_csr_sliced_hip(int32_t imessage, int64_t m, int64_t n, in
 
 extern "C" int isplib_hip_tune(int key, int value) {
    if (key == 0) { g_force_lpr = value; return ISPLIB_SUCCESS; }
+   if (key == 1) { g_addr_mode = value; return ISPLIB_SUCCESS; }
    return ISPLIB_FAIL;
 }
 

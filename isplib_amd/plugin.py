@@ -84,18 +84,30 @@ def _storage_of(src, other: torch.Tensor) -> SparseStorage:
     return _foreign.get(rowptr, col, value, sizes)
 
 
+def suggest_slices(m: int, n: int, nnz: int, k: int, minmax: bool = False) -> int:
+    """Column-slice count for an M x N, nnz-entry SpMM over K fp32 features (0 = plain kernel).
+
+    Two measured constraints on MI355X: a slice of the dense operand should
+    be about 8 MB (2x an XCD's 4 MiB L2: hot rows stay resident, 72 % L2 hits on the Reddit-shaped
+    graph) and a (row, slice) segment must keep >= ~30 edges or per-wave overhead and the partial
+    planes (S * M * K * 4 B written and re-read) eat the gain.  Reddit-shaped: K=32 -> 0, K=64 -> 8,
+    K=128 -> 16, K=256 -> 16; ogbn-products-shaped (mean degree 50) -> 0."""
+    del minmax
+    if m <= 0 or n <= 0:
+        return 0
+    by_cache = (n * k * 4) / float(8 << 20)
+    by_degree = (nnz / m) / 30.0
+    s = int(min(by_cache, by_degree) / 8.0 + 0.5) * 8
+    return min(s, 64) if s >= 8 else 0
+
+
 def choose_slices(storage: SparseStorage, rows: int, k: int) -> int:
-    """How many column slices the SpMM over `rows` x K features should use (0 = plain kernel).
-    Slicing pays when the dense operand overflows an XCD's 4 MiB L2 and rows are long enough
-    that a (row, slice) segment still fills a wave: measured on MI355X, Reddit-shaped K=128:
-    7.5 ms plain, 4.5 ms with 8 slices.  ISPLIB_SLICES=<n> overrides (0 disables)."""
+    """suggest_slices for a graph held in `storage`; ISPLIB_SLICES=<n> overrides (0 disables)."""
     env = os.environ.get("ISPLIB_SLICES")
     if env is not None:
         n = int(env)
         return n if n >= 8 and n % 8 == 0 else 0
-    m = max(storage._rowptr.numel() - 1, 1)
-    avg_deg = storage._col.numel() / m
-    return 8 if (avg_deg >= 64 and rows * k * 4 >= (16 << 20)) else 0
+    return suggest_slices(storage._rowptr.numel() - 1, rows, storage._col.numel(), k)
 
 
 def spmm_autotuned(src, other: torch.Tensor, reduce: str = "sum") -> torch.Tensor:
