@@ -82,6 +82,25 @@ template <> __device__ __forceinline__ void store_vec<2>(float *p, const float (
 }
 template <> __device__ __forceinline__ void store_vec<1>(float *p, const float (&r)[1]) { *p = r[0]; }
 
+// 16-byte store that may sit on any 4-byte boundary (ragged K); vfirst leading components belong to
+// the neighbouring lane (the last vector of a row is shifted back to end at column k) and are skipped
+struct __attribute__((packed, aligned(4))) f4u_t { float x, y, z, w; };
+template <int VEC> __device__ __forceinline__ void store_tail(float *p, const float (&r)[VEC], int vfirst) {
+   if (VEC == 4) {
+      if (vfirst == 0 && ((uintptr_t)p & 15) == 0) {
+         store_vec<VEC>(p, r);
+      } else if (vfirst == 0) {
+         f4u_t t; t.x = r[0]; t.y = r[1]; t.z = r[2]; t.w = r[VEC - 1];
+         *reinterpret_cast<f4u_t *>(p) = t;
+      } else {
+#pragma unroll
+         for (int v = 1; v < VEC; v++) if (v >= vfirst) p[v] = r[v];
+      }
+   } else {
+      store_vec<VEC>(p, r);
+   }
+}
+
 // (value, edge id) comparator: does candidate (t, i) replace (bt, bi)?
 template <int OP> __device__ __forceinline__ bool better(float t, int i, float bt, int bi) {
    if (OP == OP_MAX) return (t > bt) || (t == bt && i < bi);
@@ -268,7 +287,7 @@ __device__ __forceinline__ void slot_reduce(float (&acc)[NCH][VEC], int (&bi)[NC
 
 template <int OP, int VEC, int NCH>
 __device__ __forceinline__ void write_row(const SpmmArgs &a, int64_t row, int64_t row_b, int64_t deg,
-                                          const int (&ccol)[NCH], const bool (&cok)[NCH],
+                                          const int (&ccol)[NCH], const bool (&cok)[NCH], const int (&vfirst)[NCH],
                                           float (&acc)[NCH][VEC], const int (&bi)[NCH][VEC]) {
    float *zr = a.z + (size_t)row * (size_t)a.ldz;
    if (OP == OP_ADD) {
@@ -288,11 +307,12 @@ __device__ __forceinline__ void write_row(const SpmmArgs &a, int64_t row, int64_
 #pragma unroll
    for (int j = 0; j < NCH; j++) {
       if (!cok[j]) continue;
-      store_vec<VEC>(zr + ccol[j], acc[j]);
+      store_tail<VEC>(zr + ccol[j], acc[j], vfirst[j]);
       if (OP != OP_ADD && a.z_arg) {
          int64_t *ar = a.z_arg + (size_t)row * (size_t)a.ldz + ccol[j];
 #pragma unroll
-         for (int v = 0; v < VEC; v++) ar[v] = bi[j][v] == INT_MAX ? a.nnz : row_b + (int64_t)bi[j][v];
+         for (int v = 0; v < VEC; v++)
+            if (v >= vfirst[j]) ar[v] = bi[j][v] == INT_MAX ? a.nnz : row_b + (int64_t)bi[j][v];
       }
    }
 }
@@ -300,24 +320,25 @@ __device__ __forceinline__ void write_row(const SpmmArgs &a, int64_t row, int64_
 // sliced mode: raw partial of (slice, row); finished by combine_slices_kernel
 template <int OP, int VEC, int NCH>
 __device__ __forceinline__ void write_partial(const SpmmArgs &a, int slice, int64_t row, const int (&ccol)[NCH],
-                                              const bool (&cok)[NCH], const float (&acc)[NCH][VEC],
-                                              const int (&bi)[NCH][VEC]) {
+                                              const bool (&cok)[NCH], const int (&vfirst)[NCH],
+                                              const float (&acc)[NCH][VEC], const int (&bi)[NCH][VEC]) {
    const size_t off = ((size_t)slice * (size_t)a.m + (size_t)row) * (size_t)a.k;
 #pragma unroll
    for (int j = 0; j < NCH; j++) {
       if (!cok[j]) continue;
-      store_vec<VEC>(a.part_val + off + ccol[j], acc[j]);
+      store_tail<VEC>(a.part_val + off + ccol[j], acc[j], vfirst[j]);
       if (OP != OP_ADD) {
 #pragma unroll
-         for (int v = 0; v < VEC; v++) a.part_idx[off + ccol[j] + v] = bi[j][v];
+         for (int v = 0; v < VEC; v++)
+            if (v >= vfirst[j]) a.part_idx[off + ccol[j] + v] = bi[j][v];
       }
    }
 }
 
 // ADDR: 0 = 64-bit addresses (any size, any VEC); 1 / 2 = buffer descriptor, unit weights / weighted (VEC = 4)
 template <int OP, int VEC, int LPR, int NCH, int WAVES, bool SLICED, int ADDR>
-__global__ __launch_bounds__(WAVES * 64) void spmm_csr_kernel(const SpmmArgs a) {
-   constexpr int U = (8 / NCH) > 2 ? (8 / NCH) : 2;
+__global__ __launch_bounds__(WAVES * 64, ((NCH == 1 && ADDR == 1 && LPR >= 16 && OP == OP_ADD) ? 8 : ((NCH == 1 && ADDR == 2 && OP == OP_ADD) ? 7 : 1))) void spmm_csr_kernel(const SpmmArgs a) {
+   constexpr int U = (ADDR == 2 && NCH == 1) ? 6 : ((8 / NCH) > 2 ? (8 / NCH) : 2);   // weighted: 6 keeps 8 waves/SIMD in reach
    constexpr int PANEL = LPR * VEC * NCH;   // columns covered by one grid.y slice
    __shared__ float sh_val[WAVES][PANEL];
    __shared__ int sh_idx[OP == OP_ADD ? 1 : WAVES][OP == OP_ADD ? 1 : PANEL];
@@ -351,6 +372,18 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_csr_kernel(const SpmmArgs a) 
       ccol[j] = (int)blockIdx.y * PANEL + (j * LPR + lc) * VEC;
       cok[j] = ccol[j] < a.k;
    }
+   // ragged K (k % 4 != 0, buffer path only): the last 16-byte vector of a row is shifted back so
+   // that it ends at column k; its first vfirst components duplicate the neighbouring lane's work
+   // and are simply not stored.  Rows then need only 4-byte alignment.
+   int vfirst[NCH];
+#pragma unroll
+   for (int j = 0; j < NCH; j++) {
+      vfirst[j] = 0;
+      if (VEC == 4 && ADDR != 0 && cok[j] && ccol[j] + 4 > (int)a.k) {
+         vfirst[j] = ccol[j] + 4 - (int)a.k;
+         ccol[j] = (int)a.k - 4;
+      }
+   }
 
    const int64_t row0 = (int64_t)lb * WAVES;
    const int64_t row = row0 + wave;
@@ -377,8 +410,8 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_csr_kernel(const SpmmArgs a) 
          else wave_edges<OP, VEC, LPR, NCH, U>(a, row_b, b, e, ccol, cok, acc, bi);
          slot_reduce<OP, VEC, LPR, NCH>(acc, bi);
          if (g == 0) {
-            if (SLICED) write_partial<OP, VEC, NCH>(a, slice, row, ccol, cok, acc, bi);
-            else write_row<OP, VEC, NCH>(a, row, b, deg, ccol, cok, acc, bi);
+            if (SLICED) write_partial<OP, VEC, NCH>(a, slice, row, ccol, cok, vfirst, acc, bi);
+            else write_row<OP, VEC, NCH>(a, row, b, deg, ccol, cok, vfirst, acc, bi);
          }
       }
    }
@@ -441,8 +474,8 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_csr_kernel(const SpmmArgs a) 
                acc[j][v] = t;
                bi[j][v] = ti;
             }
-         if (SLICED) write_partial<OP, VEC, NCH>(a, slice, lr, ccol, cok, acc, bi);
-         else write_row<OP, VEC, NCH>(a, lr, b, deg, ccol, cok, acc, bi);
+         if (SLICED) write_partial<OP, VEC, NCH>(a, slice, lr, ccol, cok, vfirst, acc, bi);
+         else write_row<OP, VEC, NCH>(a, lr, b, deg, ccol, cok, vfirst, acc, bi);
       }
       __syncthreads();
    }
@@ -510,6 +543,22 @@ __global__ void dummy_kernel(int64_t flag) { (void)flag; }
 template <int OP, int VEC, int LPR, int NCH, int ADDR>
 static int launch_addr(const SpmmArgs &a0, hipStream_t st);
 
+template <int OP, int CV>
+static int launch_combine_vec(const SpmmArgs &a, hipStream_t st) {
+   int64_t blocks = (a.m * (a.k / CV) + 255) / 256;
+   if (blocks > 256 * 32) blocks = 256 * 32;
+   hipLaunchKernelGGL((combine_slices_kernel<OP, CV>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+   return check_launch("combine_slices_kernel");
+}
+
+template <int OP>
+static int launch_combine(const SpmmArgs &a, hipStream_t st) {   // vector width by the alignment of z and the planes
+   const uintptr_t al = (uintptr_t)a.z;
+   if (a.k % 4 == 0 && a.ldz % 4 == 0 && (al & 15) == 0) return launch_combine_vec<OP, 4>(a, st);
+   if (a.k % 2 == 0 && a.ldz % 2 == 0 && (al & 7) == 0) return launch_combine_vec<OP, 2>(a, st);
+   return launch_combine_vec<OP, 1>(a, st);
+}
+
 template <int OP, int VEC, int LPR, int NCH>
 static int launch_cfg(const SpmmArgs &a, hipStream_t st) {
    if constexpr (VEC == 4) {
@@ -534,10 +583,7 @@ static int launch_addr(const SpmmArgs &a0, hipStream_t st) {
                          dim3(WAVES * 64, 1, 1), 0, st, a);
       int rc = check_launch("spmm_csr_kernel<sliced>");
       if (rc) return rc;
-      int64_t blocks = (a.m * (a.k / VEC) + 255) / 256;
-      if (blocks > 256 * 32) blocks = 256 * 32;
-      hipLaunchKernelGGL((combine_slices_kernel<OP, VEC>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-      return check_launch("combine_slices_kernel");
+      return launch_combine<OP>(a, st);
    }
    hipLaunchKernelGGL((spmm_csr_kernel<OP, VEC, LPR, NCH, WAVES, false, ADDR>), dim3((unsigned)nb, ny, 1),
                       dim3(WAVES * 64, 1, 1), 0, st, a);
@@ -549,7 +595,7 @@ int g_addr_mode = 1;   // tuning knob: 0 = always 64-bit addressing, 1 = buffer 
 
 template <int OP, int VEC>
 static int launch_vec(const SpmmArgs &a, hipStream_t st) {
-   int64_t width = a.k / VEC;   // vector columns
+   int64_t width = (a.k + VEC - 1) / VEC;   // vector columns (ragged K: the last one is shifted back)
    if (g_force_lpr > 0 && g_force_lpr < width) width = g_force_lpr;   // narrower slots: K swept in grid.y panels
    if (width <= 8) return launch_cfg<OP, VEC, 8, 1>(a, st);
    if (width <= 16) return launch_cfg<OP, VEC, 16, 1>(a, st);
@@ -563,6 +609,7 @@ template <int OP>
 static int launch_op(const SpmmArgs &a, hipStream_t st) {
    const uintptr_t al = (uintptr_t)a.y | (uintptr_t)a.z;
    if (a.k % 4 == 0 && a.ldy % 4 == 0 && a.ldz % 4 == 0 && (al & 15) == 0) return launch_vec<OP, 4>(a, st);
+   if (a.ybytes != 0 && a.k >= 4 && g_addr_mode == 1) return launch_vec<OP, 4>(a, st);   // ragged / dword-aligned rows
    if (a.k % 2 == 0 && a.ldy % 2 == 0 && a.ldz % 2 == 0 && (al & 7) == 0) return launch_vec<OP, 2>(a, st);
    return launch_vec<OP, 1>(a, st);
 }

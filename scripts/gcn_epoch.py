@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Config 5 of BASELINE.json: 2-layer GCN full-batch training on a Reddit-shaped graph through the
+plug-in surface, epoch time mean/std -- the caller of the hot path, restated from the reference's
+benchmark script tests/cpu/gcn-sparse.py:55-129 (model :58-68, Adam :79, epoch structure :84-92,
+report :114-125).  PyG is not in this image, so GCNConv(cached=True, normalize=False) is restated as
+    out = matmul(adj_t, x @ W) + b                       (aggregate AFTER the linear layer: K = 32, then C)
+with `matmul` = isplib_amd.matmul, i.e. what torch_sparse.matmul becomes after iSpLibPlugin.patch_pyg().
+
+    python scripts/gcn_epoch.py [--epochs 10] [--scale 1.0] [--hidden 32]
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+
+class GCNConv(torch.nn.Module):
+    def __init__(self, fin, fout):
+        super().__init__()
+        self.lin = torch.nn.Linear(fin, fout, bias=False)
+        self.bias = torch.nn.Parameter(torch.zeros(fout))
+
+    def forward(self, x, adj_t, matmul):
+        return matmul(adj_t, self.lin(x), "sum") + self.bias
+
+
+class Net(torch.nn.Module):
+    def __init__(self, fin, hidden, classes):
+        super().__init__()
+        self.conv1, self.conv2 = GCNConv(fin, hidden), GCNConv(hidden, classes)
+
+    def forward(self, x, adj_t, matmul):
+        x = F.relu(self.conv1(x, adj_t, matmul))
+        x = F.dropout(x, training=self.training)
+        return F.log_softmax(self.conv2(x, adj_t, matmul), dim=1)
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument("--epochs", type=int, default=10)
+    p.add_argument("--scale", type=float, default=1.0)
+    p.add_argument("--hidden", type=int, default=32)        # EMBEDDING_SIZE, tests/cpu/gcn-sparse.py:4
+    p.add_argument("--features", type=int, default=602)     # Reddit, tests/cpu/dataset_tester.ipynb:496
+    p.add_argument("--classes", type=int, default=41)
+    a = p.parse_args()
+    torch.manual_seed(0)                                    # tests/cpu/gcn-sparse.py:10-12
+    dev = torch.device("cuda:0")
+    import isplib_amd
+    from isplib_amd import synth
+    rowptr, col, n = synth.dataset_like("reddit", device=dev, scale=a.scale)
+    adj_t = isplib_amd.SparseTensor.from_csr(rowptr, col, None, (n, n), validate=False)
+    x = synth.features(n, a.features, device=dev)
+    y = torch.randint(0, a.classes, (n,), device=dev)
+    train_mask = torch.rand(n, device=dev) < 0.66
+    model = Net(a.features, a.hidden, a.classes).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01, weight_decay=5e-4)
+    isplib_amd.iSpLibPlugin.patch_pyg()
+    matmul = isplib_amd.matmul
+    times, losses = [], []
+    for epoch in range(a.epochs + 1):                       # epoch 0 builds the per-graph operands; not timed
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model.train()
+        opt.zero_grad()
+        out = model(x, adj_t, matmul)
+        loss = F.nll_loss(out[train_mask], y[train_mask])
+        loss.backward()
+        opt.step()
+        pred = model(x, adj_t, matmul).argmax(1)            # second forward, as at :89
+        acc = float((pred[train_mask] == y[train_mask]).float().mean())
+        torch.cuda.synchronize()
+        if epoch:
+            times.append(time.perf_counter() - t0)
+            losses.append(float(loss.detach()))
+    isplib_amd.iSpLibPlugin.unpatch_pyg()
+    print(json.dumps({"workload": f"2-layer GCN {a.features}->{a.hidden}->{a.classes}, reddit-like N={n} nnz={col.numel()}",
+                      "epochs": a.epochs, "epoch_ms_mean": statistics.mean(times) * 1e3,
+                      "epoch_ms_std": statistics.pstdev(times) * 1e3, "first_loss": losses[0], "last_loss": losses[-1],
+                      "train_acc": acc, "spmm_calls_per_epoch": 6}))
+
+
+if __name__ == "__main__":
+    main()

@@ -184,3 +184,45 @@ def test_sliced_status_codes(gpu):
     assert cabi.fusedMM_csr_sliced_hip(cabi.MSG_SPMM_SUM, rowptr, col, None, table, 8, y, z, None, ws) == cabi.SUCCESS
     torch.cuda.synchronize()
     assert torch.all(z == 1.0)
+
+
+@pytest.mark.parametrize("k", (5, 7, 41, 100, 128, 602))
+def test_generic_64bit_addressing_path(gpu, oracle_mod, k):
+    """isplib_hip_tune(1, 0) forces the 64-bit-address kernels (the path taken when the dense operand
+    is too large for a buffer descriptor); results must not change."""
+    from isplib_amd import cabi
+    rowptr, col = cases.random_csr(150, 140, 10.0, seed=k, empty_rows=(0, 149), hub=(70, 3000))
+    val = cases.weights(col.size, 4)
+    x = cases.dense(140, k, 3, "integer" if k % 2 else "uniform")
+    assert cabi.lib().isplib_hip_tune(1, 0) == 0
+    try:
+        _run_all(gpu, oracle_mod, rowptr, col, val, x, slices=(8,))
+    finally:
+        cabi.lib().isplib_hip_tune(1, 1)
+    _run_all(gpu, oracle_mod, rowptr, col, val, x, slices=(8,))
+
+
+def test_dword_aligned_rows_take_the_vector_path(gpu, oracle_mod):
+    """Rows that are only 4-byte aligned (odd K, odd leading dimensions, offset base) through fusedMM_csr_hip."""
+    from isplib_amd import cabi
+    rowptr, col = cases.random_csr(77, 66, 6.0, seed=3, empty_rows=(5,))
+    val = cases.weights(col.size, 4)
+    for k, ldy, ldz, shift in ((41, 41, 41, 0), (41, 45, 47, 1), (12, 13, 12, 3), (4, 5, 7, 1), (9, 9, 9, 2)):
+        x = cases.dense(66, k, 3)
+        ybuf = torch.zeros(66 * ldy + 8, device=gpu)
+        y = ybuf[shift: shift + 66 * ldy].view(66, ldy)[:, :k]
+        y.copy_(_t(x, gpu))
+        zbuf = torch.full((77 * ldz + 8,), -7.0, device=gpu)
+        z = zbuf[shift: shift + 77 * ldz].view(77, ldz)[:, :k]
+        abuf = torch.full((77 * ldz + 8,), -7, dtype=torch.int64, device=gpu)
+        for red in cases.REDUCES:
+            ref, ref_arg = oracle_mod.spmm_fw(rowptr, col, val, x, red)
+            arg = abuf[shift: shift + 77 * ldz].view(77, ldz)[:, :k] if red in ("max", "min") else None
+            cabi.fusedMM_csr_hip(cabi.MESSAGE[red], _t(rowptr, gpu), _t(col, gpu), _t(val, gpu), y, z, arg)
+            if red in ("sum", "mean"):
+                _assert_sum_close(z.cpu().numpy(), ref, cases.sum_tolerance(oracle_mod, rowptr, col, val, x))
+            else:
+                assert np.array_equal(z.cpu().numpy(), ref) and np.array_equal(arg.cpu().numpy(), ref_arg)
+        if ldz > k:
+            pad = zbuf[shift: shift + 77 * ldz].view(77, ldz)[:, k:]
+            assert torch.all(pad == -7.0), "wrote outside the k columns"
