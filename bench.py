@@ -80,12 +80,19 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    # one process per GPU; backend "nccl" is RCCL over xGMI.  ISPLIB_BENCH_BACKEND=gloo lets several ranks
+    # share one GPU to rehearse the N > 1 code path on a single-GPU box (never used for a reported number).
+    backend = os.environ.get("ISPLIB_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from isplib_amd import cabi, synth
     k = a.k or {"reddit": 128, "cora": 16, "products": 256}[a.workload]
@@ -114,11 +121,15 @@ def main():
 
     # per-graph preparation, outside the timed region (the reference also builds its per-graph
     # operands once, isplib/__init__.py:76-106): slice table + workspace of the column-sliced path
-    table = work = None
+    from isplib_amd.plugin import suggest_slices
+    table = work = plan = None
     if a.slices < 0:
-        from isplib_amd.plugin import suggest_slices
         a.slices = suggest_slices(m_local, x_in.size(0), l_col.numel(), k)
-    if a.slices > 0:
+    if world > 1 and a.slices > 0:
+        plan = part.plan(k, a.reduce, slices=a.slices)     # slice count rounded to a multiple of world
+        if plan is not None:
+            a.slices, table, work = plan
+    elif a.slices > 0:
         table, ok = cabi.spmm_slices(l_rowptr, l_col, x_in.size(0), a.slices)
         if not ok:
             raise SystemExit("synthetic graph rows are not column-sorted?")
@@ -130,7 +141,35 @@ def main():
         else:
             cabi.fusedMM_csr_hip(msg, rp, cl, vl, xin, o, ar)
 
+    # N > 1: local column slices are aggregated while the all-gather is in flight (isplib_amd/dist.py).
+    # Checked once against the plain "gather, then SpMM" order before it is trusted; ISPLIB_OVERLAP=0 disables.
+    overlap = world > 1 and plan is not None and os.environ.get("ISPLIB_OVERLAP", "1") != "0"
+    if overlap:
+        try:
+            gather()
+            spmm(l_rowptr, l_col, l_val, table, x_in, out, arg)
+            want = out.clone()
+            out.zero_()
+            part.spmm_overlapped(x_shard, x_in, out, plan, a.reduce, arg)
+            torch.cuda.synchronize()
+            good = torch.equal(out, want)
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] overlapped schedule raised {type(e).__name__}: {e}", file=sys.stderr)
+            good = False
+        flag = torch.tensor([1 if good else 0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        overlap = bool(flag.item())
+        if not overlap and rank == 0:
+            print("[bench] overlapped schedule disabled (mismatch or error); using gather-then-SpMM", file=sys.stderr)
+
     def step(i=None):
+        if overlap:
+            if i is not None:
+                ev[i][0].record()
+            part.spmm_overlapped(x_shard, x_in, out, plan, a.reduce, arg)
+            if i is not None:
+                ev[i][1].record()
+            return
         if gather is not None:
             gather()
         if i is not None:
@@ -197,13 +236,15 @@ def main():
         res = {
             "metric": "edges_aggregated_per_sec", "value": nnz / (elapsed / a.steps), "unit": "edges/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" + ("" if backend == "nccl" else f" (REHEARSAL over {backend}, not a result)"),
             "config": {
                 "workload": f"{a.workload}-like graph (Chung-Lu, N={n}, nnz={nnz}), SpMM-{a.reduce} forward, K={k}, fp32"
                             + (", U(0,1) weights" if a.weighted else ", unit weights")
                             + ("" if a.scale == 1.0 else f", SCALED x{a.scale} (debug)"),
                 "schedule": f"{a.slices} column slices, XCD-affine" if a.slices > 0 else "row-per-wave, unsliced",
-                "partition": "none" if world == 1 else f"1-D rows by nnz, {world} ranks, one all-gather(X) per step",
+                "partition": "none" if world == 1 else f"1-D rows by nnz, {world} ranks, one all-gather(X) per step"
+                             + (", local column slices overlapped with the collective" if overlap else ", gather then SpMM"),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

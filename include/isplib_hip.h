@@ -127,6 +127,24 @@ int    fusedMM_csr_sliced_hip(int32_t imessage, int64_t m, int64_t n, int64_t k,
                               int64_t *z_arg, void *workspace,
                               size_t workspace_bytes, void *stream);
 
+/*
+ * The same computation in phases, for overlapping a collective with compute (1-D row
+ * partition: the slices that fall in this rank's own shard of y need no remote data).
+ * Runs the partial kernel over slices [slice_first, slice_first + slice_count) (count may
+ * be 0) and, when `combine` != 0, the fold over ALL `slices` planes afterwards.  Every
+ * slice must have been covered by some phase, with the same workspace, before the
+ * combining call.  `y` may differ between phases as long as y[indx[j]] addresses the right
+ * row for every column of the phase's slices (e.g. a base pointer shifted onto a shard).
+ */
+int    fusedMM_csr_sliced_phase_hip(int32_t imessage, int64_t m, int64_t n, int64_t k,
+                                    int64_t nnz, const float *val, const int64_t *indx,
+                                    const int64_t *pntrb, const int64_t *pntre,
+                                    const int64_t *sliceptr, int slices,
+                                    int slice_first, int slice_count, int combine,
+                                    const float *y, int64_t ldy, float *z, int64_t ldz,
+                                    int64_t *z_arg, void *workspace,
+                                    size_t workspace_bytes, void *stream);
+
 /* Tuning knob for experiments (key 0: lanes per row slot, 0 = choose by k). */
 int isplib_hip_tune(int key, int value);
 

@@ -29,7 +29,7 @@ EXPORTS = (
     "isplib_spmm_minmax_bw_hip", "isplib_sddmm_csr_hip", "isplib_csr_row_ids_hip",
     "isplib_csr2csc_workspace_bytes", "isplib_csr2csc_hip",
     "isplib_spmm_slices_bytes", "isplib_spmm_slices_build_hip", "isplib_spmm_sliced_workspace_bytes",
-    "fusedMM_csr_sliced_hip", "isplib_hip_tune",
+    "fusedMM_csr_sliced_hip", "fusedMM_csr_sliced_phase_hip", "isplib_hip_tune",
 )
 
 _i64, _f32, _vp, _i32 = ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_int32
@@ -67,6 +67,10 @@ def lib() -> ctypes.CDLL:
         L.fusedMM_csr_sliced_hip.restype = ctypes.c_int
         L.fusedMM_csr_sliced_hip.argtypes = [_i32, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, ctypes.c_int,
                                              _vp, _i64, _vp, _i64, _vp, _vp, ctypes.c_size_t, _vp]
+        L.fusedMM_csr_sliced_phase_hip.restype = ctypes.c_int
+        L.fusedMM_csr_sliced_phase_hip.argtypes = [_i32, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, ctypes.c_int,
+                                                   ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _i64, _vp, _i64, _vp,
+                                                   _vp, ctypes.c_size_t, _vp]
         L.isplib_hip_tune.restype = ctypes.c_int
         L.isplib_hip_tune.argtypes = [ctypes.c_int, ctypes.c_int]
         _sigs_set = True
@@ -256,3 +260,21 @@ def spmm_sliced(rowptr, col, val, sliceptr, slices: int, y, reduce: str = "sum",
         workspace = sliced_workspace(reduce, m, k, slices, y.device)
     fusedMM_csr_sliced_hip(MESSAGE[reduce], rowptr, col, val, sliceptr, slices, y, out, arg, workspace)
     return out, arg
+
+
+def fusedMM_csr_sliced_phase_hip(imessage: int, rowptr, col, val, sliceptr, slices: int, slice_first: int,
+                                 slice_count: int, combine: bool, y_ptr: int, n: int, k: int, ldy: int, z, z_arg,
+                                 workspace, check: bool = True) -> int:
+    """One phase of the column-sliced SpMM (include/isplib_hip.h).  ``y_ptr`` is a raw device address so
+    that a phase can read its columns through a base shifted onto a shard of the dense operand."""
+    m = rowptr.numel() - 1
+    rp = rowptr.data_ptr()
+    with torch.cuda.device(z.device):
+        st = lib().fusedMM_csr_sliced_phase_hip(
+            int(imessage), m, n, k, col.numel(), _ptr(val), _ptr(col), ctypes.c_void_p(rp), ctypes.c_void_p(rp + 8),
+            _ptr(sliceptr), slices, slice_first, slice_count, int(bool(combine)), ctypes.c_void_p(y_ptr), ldy, _ptr(z),
+            z.stride(0) if m > 1 else max(k, z.stride(0)), _ptr(z_arg), _ptr(workspace), workspace.numel(),
+            _stream(z.device))
+    if check:
+        _check(st, "fusedMM_csr_sliced_phase_hip")
+    return st

@@ -55,9 +55,10 @@ struct SpmmArgs {
    unsigned nblk;          // number of row blocks
    unsigned ybytes;        // n*ldy*4 when it fits the buffer-descriptor path, else 0
    // column-sliced mode (fusedMM_csr_sliced_hip): row i's edges with column in slice s are
-   // [sliceptr[i*(slices+1)+s], sliceptr[i*(slices+1)+s+1]); slice s is walked by XCD s / sl_per_xcd
+   // [sliceptr[i*(slices+1)+s], sliceptr[i*(slices+1)+s+1]); this launch walks slices
+   // [slice_first, slice_first + slice_count), dealt over the 8 XCDs (see the kernel)
    const int64_t *sliceptr;
-   int slices, sl_per_xcd;
+   int slices, slice_first, slice_count, combine;
    float *part_val;        // [slices][m][k] partial results
    int *part_idx;          // [slices][m][k] row-relative edge ids (max/min), INT_MAX = none
 };
@@ -351,15 +352,27 @@ __global__ __launch_bounds__(WAVES * 64, ((NCH == 1 && ADDR == 1 && LPR >= 16 &&
 
    // XCD-aware remap: physical blocks pb, pb+8, ... share one XCD (speed only, never correctness).
    //  plain : each XCD walks a contiguous range of row blocks.
-   //  sliced: each XCD walks ALL row blocks of its own column slice(s), so its L2 only
-   //          ever sees 1/8 of the rows of y; grid.x = 8 * sl_per_xcd * nblk.
+   //  sliced: each XCD walks ALL row blocks of its own column slice(s), so its L2 only ever sees a
+   //          fraction of the rows of y.  count >= 8: XCD x takes slices x, x+8, ... one after the
+   //          other; count < 8: the XCDs x = s, s+count, ... share slice s and split its row blocks.
    const unsigned pb = blockIdx.x, nb = a.nblk;
    const unsigned xcd = pb & 7u, within = pb >> 3;
    unsigned lb;
    int slice = 0;
    if (SLICED) {
-      slice = (int)xcd * a.sl_per_xcd + (int)(within / nb);
-      lb = within % nb;
+      const unsigned sc = (unsigned)a.slice_count;
+      unsigned sl;
+      if (sc >= 8u) {
+         sl = xcd + 8u * (within / nb);
+         lb = within % nb;
+         if (sl >= sc) return;
+      } else {
+         sl = xcd % sc;
+         const unsigned nshare = (8u - sl + sc - 1u) / sc;
+         lb = xcd / sc + nshare * within;
+         if (lb >= nb) return;
+      }
+      slice = a.slice_first + (int)sl;
    } else {
       const unsigned per = nb >> 3, rem = nb & 7u;
       lb = xcd * per + (xcd < rem ? xcd : rem) + within;
@@ -577,13 +590,17 @@ static int launch_addr(const SpmmArgs &a0, hipStream_t st) {
    constexpr int PANEL = LPR * VEC * NCH;
    const unsigned ny = (unsigned)((a.k + PANEL - 1) / PANEL);
    if (a.sliceptr) {
-      const int64_t gx = nb * a.slices;   // slices is a multiple of 8
-      if (gx > 0x7fffffffLL) return ISPLIB_FAIL;
-      hipLaunchKernelGGL((spmm_csr_kernel<OP, VEC, LPR, NCH, WAVES, true, ADDR>), dim3((unsigned)gx, ny, 1),
-                         dim3(WAVES * 64, 1, 1), 0, st, a);
-      int rc = check_launch("spmm_csr_kernel<sliced>");
-      if (rc) return rc;
-      return launch_combine<OP>(a, st);
+      if (a.slice_count > 0) {
+         const int64_t sc = a.slice_count;
+         const int64_t per_xcd = sc >= 8 ? ((sc + 7) / 8) * nb : (nb + (8 / sc) - 1) / (8 / sc);
+         const int64_t gx = 8 * per_xcd;
+         if (gx > 0x7fffffffLL) return ISPLIB_FAIL;
+         hipLaunchKernelGGL((spmm_csr_kernel<OP, VEC, LPR, NCH, WAVES, true, ADDR>), dim3((unsigned)gx, ny, 1),
+                            dim3(WAVES * 64, 1, 1), 0, st, a);
+         int rc = check_launch("spmm_csr_kernel<sliced>");
+         if (rc) return rc;
+      }
+      return a.combine ? launch_combine<OP>(a, st) : ISPLIB_SUCCESS;
    }
    hipLaunchKernelGGL((spmm_csr_kernel<OP, VEC, LPR, NCH, WAVES, false, ADDR>), dim3((unsigned)nb, ny, 1),
                       dim3(WAVES * 64, 1, 1), 0, st, a);
@@ -621,7 +638,8 @@ using namespace isplib;
 static int spmm_entry(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t nnz, const float *val,
                       const int64_t *indx, const int64_t *pntrb, const int64_t *pntre, const float *y, int64_t ldy,
                       float beta, float *z, int64_t ldz, int64_t *z_arg, const int64_t *sliceptr, int slices,
-                      void *workspace, size_t workspace_bytes, void *stream) {
+                      int slice_first, int slice_count, int combine, void *workspace, size_t workspace_bytes,
+                      void *stream) {
    clear_error();
    const int32_t vop = imessage & 0xF, rop = imessage & 0xF0, sop = imessage & 0xF00, vsc = imessage & 0xF000,
                  aop = imessage & 0xF0000;
@@ -652,13 +670,17 @@ static int spmm_entry(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t
       const unsigned long long yb = (unsigned long long)n * (unsigned long long)ldy * 4ull;
       a.ybytes = (yb <= BUF_LIMIT && g_addr_mode != 0) ? (unsigned)yb : 0u;
    }
-   a.sliceptr = nullptr; a.slices = 1; a.sl_per_xcd = 1; a.part_val = nullptr; a.part_idx = nullptr;
+   a.sliceptr = nullptr; a.slices = 1; a.slice_first = 0; a.slice_count = 0; a.combine = 0;
+   a.part_val = nullptr; a.part_idx = nullptr;
    if (sliceptr) {
       if (slices < 8 || slices % 8 != 0) return fail(ISPLIB_FAIL, "fusedMM_csr_sliced_hip: slices must be a positive multiple of 8");
       const size_t need = isplib_spmm_sliced_workspace_bytes(imessage, m, k, slices);
       if (!workspace || workspace_bytes < need) return fail(ISPLIB_NOT_ENOUGH_MEM, "fusedMM_csr_sliced_hip: workspace too small");
       if (((uintptr_t)workspace & 255) != 0) return fail(ISPLIB_FAIL, "fusedMM_csr_sliced_hip: workspace must be 256-byte aligned");
-      a.sliceptr = sliceptr; a.slices = slices; a.sl_per_xcd = slices / 8;
+      if (slice_first < 0 || slice_count < 0 || slice_first + slice_count > slices)
+         return fail(ISPLIB_FAIL, "fusedMM_csr_sliced_phase_hip: slice range outside [0, slices)");
+      a.sliceptr = sliceptr; a.slices = slices;
+      a.slice_first = slice_first; a.slice_count = slice_count; a.combine = combine ? 1 : 0;
       a.part_val = (float *)workspace;
       const size_t plane = ((size_t)slices * (size_t)m * (size_t)k * sizeof(float) + 255) & ~(size_t)255;
       a.part_idx = aop == ISPLIB_AOP_ADD ? nullptr : (int *)((char *)workspace + plane);
@@ -675,8 +697,8 @@ extern "C" int fusedMM_csr_hip(int32_t imessage, int64_t m, int64_t n, int64_t k
                                const float *y, int64_t ldy, float beta, float *z, int64_t ldz, int64_t *z_arg,
                                void *stream) {
    (void)alpha; (void)rows; (void)cols; (void)x; (void)ldx;
-   return spmm_entry(imessage, m, n, k, nnz, val, indx, pntrb, pntre, y, ldy, beta, z, ldz, z_arg, nullptr, 1, nullptr,
-                     0, stream);
+   return spmm_entry(imessage, m, n, k, nnz, val, indx, pntrb, pntre, y, ldy, beta, z, ldz, z_arg, nullptr, 1, 0, 0, 0,
+                     nullptr, 0, stream);
 }
 
 extern "C" size_t isplib_spmm_sliced_workspace_bytes(int32_t imessage, int64_t m, int64_t k, int slices) {
@@ -695,8 +717,22 @@ extern "C" int fusedMM_csr_sliced_hip(int32_t imessage, int64_t m, int64_t n, in
       clear_error();
       return fail(ISPLIB_FAIL, "fusedMM_csr_sliced_hip: sliceptr is required");
    }
+   return spmm_entry(imessage, m, n, k, nnz, val, indx, pntrb, pntre, y, ldy, 0.0f, z, ldz, z_arg, sliceptr, slices, 0,
+                     slices, 1, workspace, workspace_bytes, stream);
+}
+
+extern "C" int fusedMM_csr_sliced_phase_hip(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t nnz,
+                                            const float *val, const int64_t *indx, const int64_t *pntrb,
+                                            const int64_t *pntre, const int64_t *sliceptr, int slices,
+                                            int slice_first, int slice_count, int combine, const float *y,
+                                            int64_t ldy, float *z, int64_t ldz, int64_t *z_arg, void *workspace,
+                                            size_t workspace_bytes, void *stream) {
+   if (!sliceptr) {
+      clear_error();
+      return fail(ISPLIB_FAIL, "fusedMM_csr_sliced_phase_hip: sliceptr is required");
+   }
    return spmm_entry(imessage, m, n, k, nnz, val, indx, pntrb, pntre, y, ldy, 0.0f, z, ldz, z_arg, sliceptr, slices,
-                     workspace, workspace_bytes, stream);
+                     slice_first, slice_count, combine, workspace, workspace_bytes, stream);
 }
 
 extern "C" int isplib_hip_tune(int key, int value) {

@@ -58,7 +58,9 @@ class RowPartition:
         self.col = col[lo:hi].contiguous()
         self.val = None if val is None else val[lo:hi].contiguous()
         sizes = [self.x_cuts[p + 1] - self.x_cuts[p] for p in range(world)]
-        self.max_rows = max(max(sizes), 1)
+        # shard pitch of the gather buffer; a multiple of 192 so that any slice count that is a multiple
+        # of `world` (8..64 slices) cuts every shard into whole column slices (spmm_overlapped)
+        self.max_rows = (max(max(sizes), 1) + 191) // 192 * 192
         self.x_rows = sizes[rank]
         xc = torch.tensor(self.x_cuts, dtype=torch.int64, device=col.device)
         owner = torch.searchsorted(xc[1:].contiguous(), self.col, right=True).clamp_(max=world - 1)
@@ -102,3 +104,51 @@ class RowPartition:
         if arg is not None:
             arg = torch.where(arg == self.nnz, arg.new_full((), self.total_nnz), arg + self.edge0)
         return out, arg
+
+    # ---- overlapped form: local column slices run while the all-gather is in flight ----------------
+
+    def plan(self, k: int, reduce: str = "sum", slices: Optional[int] = None):
+        """Per-graph operands of the sliced path on this rank: (slices, table, workspace) or None.
+        The slice count is a multiple of `world`, so each shard of X holds whole slices."""
+        from . import cabi
+        from .plugin import suggest_slices
+        s = suggest_slices(self.rows, self.ncols_padded, self.nnz, k) if slices is None else slices
+        if s <= 0:
+            return None
+        s = max(8, (s + 7) // 8 * 8)
+        while s % self.world:
+            s += 8
+        table, ok = cabi.spmm_slices(self.rowptr, self.col_padded, self.ncols_padded, s)
+        if not ok:
+            return None
+        return s, table, cabi.sliced_workspace(reduce, self.rows, k, s, self.col.device)
+
+    def spmm_overlapped(self, x_shard: torch.Tensor, buf: torch.Tensor, out: torch.Tensor, plan,
+                        reduce: str = "sum", arg: Optional[torch.Tensor] = None, gather: bool = True):
+        """ONE all-gather of X, overlapped with compute: the column slices that lie in this rank's own
+        shard are aggregated straight from `x_shard` while the collective runs; the remaining slices and
+        the fold follow once it has landed.  Same slices and fold order as the non-overlapped sliced
+        call, so the result is bitwise identical to it."""
+        from . import cabi
+        s, table, work = plan
+        k = x_shard.size(1)
+        msg = cabi.MESSAGE[reduce]
+        q = s // self.world
+        first = self.rank * q
+        handle = None
+        if gather and self.world > 1:
+            handle = dist.all_gather_into_tensor(buf, x_shard, group=self.group, async_op=True)
+        elif gather:
+            buf.copy_(x_shard)
+        # local slices: column ids are in the padded layout, so shift the base onto the shard
+        y_local = x_shard.data_ptr() - self.rank * self.max_rows * x_shard.stride(0) * 4
+        common = (msg, self.rowptr, self.col_padded, self.val, table, s)
+        cabi.fusedMM_csr_sliced_phase_hip(*common, first, q, False, y_local, self.ncols_padded, k, x_shard.stride(0),
+                                          out, arg, work)
+        if handle is not None:
+            handle.wait()
+        cabi.fusedMM_csr_sliced_phase_hip(*common, 0, first, False, buf.data_ptr(), self.ncols_padded, k, buf.stride(0),
+                                          out, arg, work)
+        cabi.fusedMM_csr_sliced_phase_hip(*common, first + q, s - first - q, True, buf.data_ptr(), self.ncols_padded, k,
+                                          buf.stride(0), out, arg, work)
+        return out

@@ -226,3 +226,38 @@ def test_dword_aligned_rows_take_the_vector_path(gpu, oracle_mod):
         if ldz > k:
             pad = zbuf[shift: shift + 77 * ldz].view(77, ldz)[:, k:]
             assert torch.all(pad == -7.0), "wrote outside the k columns"
+
+
+@pytest.mark.parametrize("world", (2, 4, 8))
+def test_phased_sliced_spmm_equals_single_call(gpu, oracle_mod, world):
+    """The overlap schedule of the row-partitioned path (local column slices from the rank's own shard
+    first, remote slices after the all-gather, then the fold) is bitwise the one-call sliced SpMM."""
+    from isplib_amd import cabi
+    from isplib_amd.dist import RowPartition
+    rowptr, col = cases.random_csr(500, 500, 40.0, seed=world, empty_rows=(0, 250), hub=(77, 3000))
+    val = cases.weights(col.size, 4, "signed_int")      # integer weights and features: every sum is exact
+    x = cases.dense(500, 24, 3, "integer")
+    d_rowptr, d_col, d_val, d_x = (_t(a, gpu) for a in (rowptr, col, val, x))
+    for red in ("sum", "max"):
+        ref, ref_arg = oracle_mod.spmm_fw(rowptr, col, val, x, red)
+        for rank in range(world):
+            part = RowPartition(d_rowptr, d_col, d_val, 500, rank, world)
+            assert part.max_rows % 192 == 0
+            buf = part.gather_buffer(24)
+            buf.zero_()
+            for p in range(world):                     # what the all-gather leaves behind
+                r0, r1 = part.x_cuts[p], part.x_cuts[p + 1]
+                buf[p * part.max_rows: p * part.max_rows + (r1 - r0)] = d_x[r0:r1]
+            plan = part.plan(24, red, slices=16)
+            s, table, work = plan
+            one, one_arg = cabi.spmm_sliced(part.rowptr, part.col_padded, part.val, table, s, buf, red, work)
+            out = torch.empty_like(one)
+            arg = torch.empty_like(one_arg) if one_arg is not None else None
+            part.spmm_overlapped(part.shard(d_x), buf, out, plan, red, arg, gather=False)
+            assert torch.equal(out, one)
+            r0, r1 = part.row_cuts[rank], part.row_cuts[rank + 1]
+            assert np.array_equal(out.cpu().numpy(), ref[r0:r1])          # integer data: exact
+            if arg is not None:
+                assert torch.equal(arg, one_arg)
+                garg = torch.where(arg == part.nnz, arg.new_full((), part.total_nnz), arg + part.edge0)
+                assert np.array_equal(garg.cpu().numpy(), ref_arg[r0:r1])
