@@ -124,7 +124,7 @@ def main():
     from isplib_amd.plugin import suggest_slices
     table = work = plan = None
     if a.slices < 0:
-        a.slices = suggest_slices(m_local, x_in.size(0), l_col.numel(), k)
+        a.slices = suggest_slices(m_local, x_in.size(0), l_col.numel(), k, a.reduce in ("max", "min"))
     if world > 1 and a.slices > 0:
         plan = part.plan(k, a.reduce, slices=a.slices)     # slice count rounded to a multiple of world
         if plan is not None:

@@ -112,7 +112,7 @@ class RowPartition:
         The slice count is a multiple of `world`, so each shard of X holds whole slices."""
         from . import cabi
         from .plugin import suggest_slices
-        s = suggest_slices(self.rows, self.ncols_padded, self.nnz, k) if slices is None else slices
+        s = suggest_slices(self.rows, self.ncols_padded, self.nnz, k, reduce in ("max", "min")) if slices is None else slices
         if s <= 0:
             return None
         s = max(8, (s + 7) // 8 * 8)

@@ -92,22 +92,23 @@ def suggest_slices(m: int, n: int, nnz: int, k: int, minmax: bool = False) -> in
     graph) and a (row, slice) segment must keep >= ~30 edges or per-wave overhead and the partial
     planes (S * M * K * 4 B written and re-read) eat the gain.  Reddit-shaped: K=32 -> 0, K=64 -> 8,
     K=128 -> 16, K=256 -> 16; ogbn-products-shaped (mean degree 50) -> 0."""
-    del minmax
     if m <= 0 or n <= 0:
         return 0
-    by_cache = (n * k * 4) / float(8 << 20)
+    # max/min also write and re-read an int32 id plane per slice: fewer, larger slices pay (measured
+    # K=64/128/256: 8/8/16 slices for max against 8/16/16 for sum)
+    by_cache = (n * k * 4) / float(8 << 20) * (0.6 if minmax else 1.0)
     by_degree = (nnz / m) / 30.0
     s = int(min(by_cache, by_degree) / 8.0 + 0.5) * 8
     return min(s, 64) if s >= 8 else 0
 
 
-def choose_slices(storage: SparseStorage, rows: int, k: int) -> int:
+def choose_slices(storage: SparseStorage, rows: int, k: int, minmax: bool = False) -> int:
     """suggest_slices for a graph held in `storage`; ISPLIB_SLICES=<n> overrides (0 disables)."""
     env = os.environ.get("ISPLIB_SLICES")
     if env is not None:
         n = int(env)
         return n if n >= 8 and n % 8 == 0 else 0
-    return suggest_slices(storage._rowptr.numel() - 1, rows, storage._col.numel(), k)
+    return suggest_slices(storage._rowptr.numel() - 1, rows, storage._col.numel(), k, minmax)
 
 
 def spmm_autotuned(src, other: torch.Tensor, reduce: str = "sum") -> torch.Tensor:
@@ -127,7 +128,7 @@ def spmm_autotuned(src, other: torch.Tensor, reduce: str = "sum") -> torch.Tenso
     needs_grad = torch.is_grad_enabled() and mat.requires_grad       # :69-73
     ops = torch.ops.isplib
     k = mat.size(-1)
-    n_sl = choose_slices(s, mat.size(0), k)
+    n_sl = choose_slices(s, mat.size(0), k, reduce in ("max", "min"))
     table = s.slices(n_sl) if n_sl else None                         # per-graph, built once on the device
     if reduce in ("sum", "add", "mean"):
         colptr = val_t = row_t = table_t = None

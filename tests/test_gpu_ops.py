@@ -272,3 +272,36 @@ def test_two_epoch_gcn_loss_trajectory(gpu, oracle_mod):
     got = run(gpu, lambda m: isplib_amd.matmul(adj, m, "sum"))
     ref = run("cpu", OracleAgg.apply)
     assert np.allclose(got, ref, rtol=1e-4), (got, ref)
+
+
+def test_boundary_calls_are_hipgraph_capturable(gpu, oracle_mod):
+    """include/isplib_hip.h promises no allocation / synchronisation inside the entry points: capture the
+    plain and the sliced SpMM (two kernels) into one graph on a side stream and replay it on new inputs."""
+    from isplib_amd import cabi
+    rowptr, col = cases.random_csr(300, 300, 70.0, seed=41)
+    val = cases.weights(col.size, 4)
+    d_rowptr, d_col, d_val = _t(rowptr, gpu), _t(col, gpu), _t(val, gpu)
+    x = torch.zeros((300, 32), device=gpu)
+    out_a = torch.empty((300, 32), device=gpu)
+    out_b = torch.empty((300, 32), device=gpu)
+    table, ok = cabi.spmm_slices(d_rowptr, d_col, 300, 8)
+    work = cabi.sliced_workspace("sum", 300, 32, 8, gpu)
+    assert ok
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        cabi.fusedMM_csr_hip(cabi.MSG_SPMM_SUM, d_rowptr, d_col, d_val, x, out_a)      # warm-up outside capture
+        with torch.cuda.graph(graph, stream=side):
+            cabi.fusedMM_csr_hip(cabi.MSG_SPMM_SUM, d_rowptr, d_col, d_val, x, out_a)
+            cabi.fusedMM_csr_sliced_hip(cabi.MSG_SPMM_SUM, d_rowptr, d_col, d_val, table, 8, x, out_b, None, work)
+    torch.cuda.current_stream().wait_stream(side)
+    for seed in (3, 4):
+        xs = cases.dense(300, 32, seed)
+        x.copy_(_t(xs, gpu))
+        graph.replay()
+        torch.cuda.synchronize()
+        ref, _ = oracle_mod.spmm_fw(rowptr, col, val, xs, "sum")
+        tol = cases.sum_tolerance(oracle_mod, rowptr, col, val, xs)
+        assert np.all(np.abs(out_a.cpu().numpy() - ref) <= tol)
+        assert np.all(np.abs(out_b.cpu().numpy() - ref) <= tol)
