@@ -36,12 +36,18 @@ def parse():
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--workload", default="reddit", choices=["cora", "reddit", "products"])
+    p.add_argument("--generator", default="chunglu", choices=["chunglu", "rmat", "uniform"],
+                   help="graph model at the workload's N and nnz (rmat / uniform: locality best / worst case)")
     p.add_argument("--k", type=int, default=None, help="feature width (default: 128 reddit, 16 cora, 256 products)")
     p.add_argument("--reduce", default="sum", choices=["sum", "mean", "max", "min"])
     p.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only; result is then not the metric)")
     p.add_argument("--weighted", action="store_true", help="U(0,1) edge weights instead of unit weights")
     p.add_argument("--slices", type=int, default=-1,
                    help="column slices (multiple of 8; 0 = plain row kernel; -1 = isplib_amd.plugin.suggest_slices)")
+    p.add_argument("--schedule", default="tasks", choices=["sliced", "tasks"],
+                   help="sliced: (row, slice) segment per wave; tasks: explicit task list (isplib_amd/plan.py)")
+    p.add_argument("--chunk", type=int, default=1024, help="tasks: edges per task")
+    p.add_argument("--short", type=int, default=128, help="tasks: rows shorter than this are not sliced")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-backward", action="store_true")
     return p.parse_args()
@@ -96,7 +102,12 @@ def main():
 
     from isplib_amd import cabi, synth
     k = a.k or {"reddit": 128, "cora": 16, "products": 256}[a.workload]
-    rowptr, col, n = synth.dataset_like(a.workload, device=dev, scale=a.scale)
+    if a.generator == "chunglu":
+        rowptr, col, n = synth.dataset_like(a.workload, device=dev, scale=a.scale)
+    else:
+        n, target = synth.SHAPES[a.workload][0], synth.SHAPES[a.workload][1]
+        n, target = max(64, int(n * a.scale)), int(target * a.scale) // 2 * 2
+        rowptr, col = (synth.rmat_csr if a.generator == "rmat" else synth.uniform_csr)(n, target, device=dev)
     nnz = col.numel()
     x = synth.features(n, k, device=dev)
     val = synth.edge_weights(nnz, device=dev) if a.weighted else None
@@ -135,8 +146,16 @@ def main():
             raise SystemExit("synthetic graph rows are not column-sorted?")
         work = cabi.sliced_workspace(a.reduce, m_local, k, a.slices, dev)
 
+    tplan = twork = None
+    if world == 1 and a.schedule == "tasks" and a.slices > 0:
+        from isplib_amd.plan import build_task_plan
+        tplan = build_task_plan(l_rowptr, l_col, x_in.size(0), a.slices, a.chunk, a.short)
+        twork = tplan.workspace(a.reduce, k)
+
     def spmm(rp, cl, vl, tb, xin, o, ar):
-        if tb is not None:
+        if tplan is not None and rp is l_rowptr:
+            cabi.fusedMM_csr_tasks_hip(msg, rp, cl, vl, tplan, xin, o, ar, twork)
+        elif tb is not None:
             cabi.fusedMM_csr_sliced_hip(msg, rp, cl, vl, tb, a.slices, xin, o, ar, work)
         else:
             cabi.fusedMM_csr_hip(msg, rp, cl, vl, xin, o, ar)
@@ -239,10 +258,12 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" + ("" if backend == "nccl" else f" (REHEARSAL over {backend}, not a result)"),
             "config": {
-                "workload": f"{a.workload}-like graph (Chung-Lu, N={n}, nnz={nnz}), SpMM-{a.reduce} forward, K={k}, fp32"
+                "workload": f"{a.workload}-like graph ({a.generator}, N={n}, nnz={nnz}), SpMM-{a.reduce} forward, K={k}, fp32"
                             + (", U(0,1) weights" if a.weighted else ", unit weights")
                             + ("" if a.scale == 1.0 else f", SCALED x{a.scale} (debug)"),
-                "schedule": f"{a.slices} column slices, XCD-affine" if a.slices > 0 else "row-per-wave, unsliced",
+                "schedule": (f"task list: {a.slices} column slices, {tplan.n_tasks} tasks of <= {a.chunk} edges, rows < {a.short} unsliced"
+                             if tplan is not None else
+                             f"{a.slices} column slices, XCD-affine" if a.slices > 0 else "row-per-wave, unsliced"),
                 "partition": "none" if world == 1 else f"1-D rows by nnz, {world} ranks, one all-gather(X) per step"
                              + (", local column slices overlapped with the collective" if overlap else ", gather then SpMM"),
             },

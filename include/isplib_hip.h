@@ -145,6 +145,54 @@ int    fusedMM_csr_sliced_phase_hip(int32_t imessage, int64_t m, int64_t n, int6
                                     int64_t *z_arg, void *workspace,
                                     size_t workspace_bytes, void *stream);
 
+/*
+ * Task-list schedule: the most robust form of the sliced SpMM (hub rows, empty segments, short
+ * rows).  The caller supplies a per-graph plan (isplib_spmm_tasks_count_hip / _fill_hip below):
+ *   task t = edges [task_b[t], task_b[t] + task_len[t]) of row task_row[t], at most a few hundred
+ *   edges, all in one column slice; tasks are grouped by XCD lane: lane x (blocks with
+ *   blockIdx % 8 == x) runs tasks [lane_off[x], lane_off[x+1]) (lane_off: 9 HOST int64);
+ *   seg_off[(s' * m) + i] = first task of row i in plan slice position s'
+ *   (s' = (s % 8) * (slices / 8) + s / 8), slices*m + 1 entries.
+ * Each task writes one partial row into the workspace (isplib_spmm_tasks_workspace_bytes);
+ * a second kernel folds a row's partials in ascending CSR order.  Same results and conventions
+ * as fusedMM_csr_hip; requires k >= 4 and n*ldy*4 <= 3.5 GiB.
+ */
+typedef struct isplib_task_plan_info {
+   int64_t n_tasks;
+   int64_t lane_off[9];     /* tasks of XCD lane x: [lane_off[x], lane_off[x+1]) */
+   int32_t slices, chunk, short_row, reserved;
+} isplib_task_plan_info;
+
+/*
+ * Plan builder, two calls, once per graph (independent of k):
+ *   count: from the slice table (isplib_spmm_slices_build_hip) derives the number of tasks of every
+ *          (slice position, row) segment -- ceil(len / chunk), rows with fewer than short_row edges
+ *          kept whole on slice row % slices -- and its exclusive prefix seg_off[slices*m + 1].
+ *          Fills *info (HOST) and synchronises `stream` ONCE to do so.
+ *   fill : writes task_row / task_b / task_len (info->n_tasks entries each).
+ */
+size_t isplib_spmm_tasks_plan_workspace_bytes(int64_t m, int slices);
+int    isplib_spmm_tasks_count_hip(int64_t m, const int64_t *pntrb, const int64_t *pntre,
+                                   const int64_t *sliceptr, int slices, int chunk, int short_row,
+                                   int32_t *seg_off /*[dev] slices*m+1*/, void *workspace,
+                                   size_t workspace_bytes, isplib_task_plan_info *info /*host*/,
+                                   void *stream);
+int    isplib_spmm_tasks_fill_hip(int64_t m, const int64_t *pntrb, const int64_t *pntre,
+                                  const int64_t *sliceptr, const isplib_task_plan_info *info,
+                                  const int32_t *seg_off, int32_t *task_row, int64_t *task_b,
+                                  int32_t *task_len, void *stream);
+size_t isplib_spmm_tasks_workspace_bytes(int32_t imessage, int64_t n_tasks, int64_t k);
+int    fusedMM_csr_tasks_hip(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t nnz,
+                             const float *val, const int64_t *indx,
+                             const int64_t *pntrb, const int64_t *pntre,
+                             int64_t n_tasks, const int32_t *task_row,
+                             const int64_t *task_b, const int32_t *task_len,
+                             const int32_t *seg_off, int slices,
+                             const int64_t *lane_off_host /*9, host*/,
+                             const float *y, int64_t ldy, float *z, int64_t ldz,
+                             int64_t *z_arg, void *workspace, size_t workspace_bytes,
+                             void *stream);
+
 /* Tuning knob for experiments (key 0: lanes per row slot, 0 = choose by k). */
 int isplib_hip_tune(int key, int value);
 

@@ -30,9 +30,16 @@ EXPORTS = (
     "isplib_csr2csc_workspace_bytes", "isplib_csr2csc_hip",
     "isplib_spmm_slices_bytes", "isplib_spmm_slices_build_hip", "isplib_spmm_sliced_workspace_bytes",
     "fusedMM_csr_sliced_hip", "fusedMM_csr_sliced_phase_hip", "isplib_hip_tune",
+    "isplib_spmm_tasks_workspace_bytes", "fusedMM_csr_tasks_hip",
+    "isplib_spmm_tasks_plan_workspace_bytes", "isplib_spmm_tasks_count_hip", "isplib_spmm_tasks_fill_hip",
 )
 
 _i64, _f32, _vp, _i32 = ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_int32
+
+
+class TaskPlanInfo(ctypes.Structure):      # isplib_task_plan_info
+    _fields_ = [("n_tasks", ctypes.c_int64), ("lane_off", ctypes.c_int64 * 9), ("slices", ctypes.c_int32),
+                ("chunk", ctypes.c_int32), ("short_row", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 _sigs_set = False
 
 
@@ -71,6 +78,18 @@ def lib() -> ctypes.CDLL:
         L.fusedMM_csr_sliced_phase_hip.argtypes = [_i32, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, ctypes.c_int,
                                                    ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _i64, _vp, _i64, _vp,
                                                    _vp, ctypes.c_size_t, _vp]
+        L.isplib_spmm_tasks_workspace_bytes.restype = ctypes.c_size_t
+        L.isplib_spmm_tasks_workspace_bytes.argtypes = [_i32, _i64, _i64]
+        L.fusedMM_csr_tasks_hip.restype = ctypes.c_int
+        L.fusedMM_csr_tasks_hip.argtypes = [_i32, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp,
+                                            ctypes.c_int, _vp, _vp, _i64, _vp, _i64, _vp, _vp, ctypes.c_size_t, _vp]
+        L.isplib_spmm_tasks_plan_workspace_bytes.restype = ctypes.c_size_t
+        L.isplib_spmm_tasks_plan_workspace_bytes.argtypes = [_i64, ctypes.c_int]
+        L.isplib_spmm_tasks_count_hip.restype = ctypes.c_int
+        L.isplib_spmm_tasks_count_hip.argtypes = [_i64, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp,
+                                                  ctypes.c_size_t, ctypes.POINTER(TaskPlanInfo), _vp]
+        L.isplib_spmm_tasks_fill_hip.restype = ctypes.c_int
+        L.isplib_spmm_tasks_fill_hip.argtypes = [_i64, _vp, _vp, _vp, ctypes.POINTER(TaskPlanInfo), _vp, _vp, _vp, _vp, _vp]
         L.isplib_hip_tune.restype = ctypes.c_int
         L.isplib_hip_tune.argtypes = [ctypes.c_int, ctypes.c_int]
         _sigs_set = True
@@ -278,3 +297,37 @@ def fusedMM_csr_sliced_phase_hip(imessage: int, rowptr, col, val, sliceptr, slic
     if check:
         _check(st, "fusedMM_csr_sliced_phase_hip")
     return st
+
+
+def fusedMM_csr_tasks_hip(imessage: int, rowptr, col, val, plan, y, z, z_arg, workspace, check: bool = True) -> int:
+    """Raw boundary call of the task-list SpMM; ``plan`` is an isplib_amd.plan.TaskPlan."""
+    assert y.is_cuda and y.dtype == torch.float32 and y.dim() == 2 and y.stride(1) == 1
+    m, n, k = rowptr.numel() - 1, y.size(0), y.size(1)
+    rp = rowptr.data_ptr()
+    lane = (ctypes.c_int64 * 9)(*plan.lane_off)
+    with torch.cuda.device(y.device):
+        st = lib().fusedMM_csr_tasks_hip(int(imessage), m, n, k, col.numel(), _ptr(val), _ptr(col), ctypes.c_void_p(rp),
+                                         ctypes.c_void_p(rp + 8), plan.n_tasks, _ptr(plan.task_row), _ptr(plan.task_b),
+                                         _ptr(plan.task_len), _ptr(plan.seg_off), plan.slices, lane, _ptr(y),
+                                         y.stride(0) if n > 1 else max(k, y.stride(0)), _ptr(z),
+                                         z.stride(0) if m > 1 else max(k, z.stride(0)), _ptr(z_arg), _ptr(workspace),
+                                         workspace.numel(), _stream(y.device))
+    if check:
+        _check(st, "fusedMM_csr_tasks_hip")
+    return st
+
+
+def spmm_tasks(rowptr, col, val, plan, y, reduce: str = "sum", workspace=None):
+    """Allocate outputs (+ workspace) and call the task-list boundary; returns (out, arg|None)."""
+    rowptr = _dev(rowptr, "rowptr", torch.int64)
+    col = _dev(col, "col", torch.int64)
+    if val is not None:
+        val = _dev(val, "val", torch.float32)
+    y = y.contiguous()
+    m, k = rowptr.numel() - 1, y.size(1)
+    out = torch.empty((m, k), dtype=torch.float32, device=y.device)
+    arg = torch.empty((m, k), dtype=torch.int64, device=y.device) if reduce in ("max", "min") else None
+    if workspace is None:
+        workspace = plan.workspace(reduce, k)
+    fusedMM_csr_tasks_hip(MESSAGE[reduce], rowptr, col, val, plan, y, out, arg, workspace)
+    return out, arg

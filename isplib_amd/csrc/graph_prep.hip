@@ -122,6 +122,69 @@ __global__ __launch_bounds__(256) void sorted_check_kernel(int64_t m, const int6
    if (bad) atomicOr(flag, 1);
 }
 
+// ---- task plan of the task-list SpMM schedule (fusedMM_csr_tasks_hip) ------------------------
+// plan position sp holds slice s = (sp % per_lane) * 8 + sp / per_lane, so XCD lane x owns the
+// contiguous positions [x*per_lane, (x+1)*per_lane).  Rows with fewer than short_row edges are not
+// sliced: their whole row is one segment homed on slice row % slices.
+__device__ __forceinline__ void plan_segment(int64_t row, int sp, int slices, int short_row,
+                                             const int64_t *__restrict__ pntrb, const int64_t *__restrict__ pntre,
+                                             const int64_t *__restrict__ sliceptr, int64_t &b, int64_t &e) {
+   const int per_lane = slices / 8;
+   const int s = (sp % per_lane) * 8 + sp / per_lane;
+   const int64_t rb = pntrb[row], re = pntre[row];
+   if (re - rb < short_row) {
+      b = rb;
+      e = (int)(row % slices) == s ? re : rb;
+   } else {
+      const int64_t *t = sliceptr + (size_t)row * (size_t)(slices + 1) + s;
+      b = t[0];
+      e = t[1];
+   }
+}
+
+__global__ __launch_bounds__(256) void plan_count_kernel(int64_t m, int slices, int chunk, int short_row,
+                                                         const int64_t *__restrict__ pntrb,
+                                                         const int64_t *__restrict__ pntre,
+                                                         const int64_t *__restrict__ sliceptr, int *__restrict__ cnt) {
+   const int64_t total = m * slices;
+   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= total; i += stride) {
+      if (i == total) { cnt[i] = 0; continue; }
+      int64_t b, e;
+      plan_segment(i % m, (int)(i / m), slices, short_row, pntrb, pntre, sliceptr, b, e);
+      cnt[i] = (int)((e - b + chunk - 1) / chunk);
+   }
+}
+
+__global__ __launch_bounds__(256) void plan_fill_kernel(int64_t m, int slices, int chunk, int short_row,
+                                                        const int64_t *__restrict__ pntrb,
+                                                        const int64_t *__restrict__ pntre,
+                                                        const int64_t *__restrict__ sliceptr,
+                                                        const int *__restrict__ seg_off, int *__restrict__ task_row,
+                                                        int64_t *__restrict__ task_b, int *__restrict__ task_len) {
+   const int64_t total = m * slices;
+   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+      const int t0 = seg_off[i], t1 = seg_off[i + 1];
+      if (t1 == t0) continue;
+      int64_t b, e;
+      const int64_t row = i % m;
+      plan_segment(row, (int)(i / m), slices, short_row, pntrb, pntre, sliceptr, b, e);
+      for (int t = t0; t < t1; t++) {
+         const int64_t cb = b + (int64_t)(t - t0) * chunk;
+         task_row[t] = (int)row;
+         task_b[t] = cb;
+         task_len[t] = (int)((e - cb) < chunk ? (e - cb) : chunk);
+      }
+   }
+}
+
+static hipError_t plan_scan_temp_bytes(int64_t items, size_t *bytes) {
+   *bytes = 0;
+   return rocprim::exclusive_scan(nullptr, *bytes, (const int *)nullptr, (int *)nullptr, 0, (size_t)items,
+                                  rocprim::plus<int>(), (hipStream_t)0, false);
+}
+
 static inline unsigned grid_for(int64_t n) {
    int64_t b = (n + 255) / 256;
    if (b < 1) b = 1;
@@ -231,4 +294,69 @@ extern "C" int isplib_spmm_slices_build_hip(int64_t m, int64_t n, int64_t nnz, c
       rc = check_launch("sorted_check_kernel");
    }
    return rc;
+}
+
+extern "C" size_t isplib_spmm_tasks_plan_workspace_bytes(int64_t m, int slices) {
+   if (m <= 0 || slices <= 0) return 256;
+   const int64_t items = m * slices + 1;
+   size_t temp = 0;
+   if (plan_scan_temp_bytes(items, &temp) != hipSuccess) return 0;
+   return align_up((size_t)items * sizeof(int)) + align_up(temp) + 256;
+}
+
+extern "C" int isplib_spmm_tasks_count_hip(int64_t m, const int64_t *pntrb, const int64_t *pntre,
+                                           const int64_t *sliceptr, int slices, int chunk, int short_row,
+                                           int32_t *seg_off, void *workspace, size_t workspace_bytes,
+                                           isplib_task_plan_info *info, void *stream) {
+   clear_error();
+   if (m < 0) return fail(ISPLIB_FAIL, "isplib_spmm_tasks_count_hip: negative dimension");
+   if (slices < 8 || slices % 8 != 0) return fail(ISPLIB_FAIL, "isplib_spmm_tasks_count_hip: slices must be a positive multiple of 8");
+   if (chunk < 64 || short_row < 0) return fail(ISPLIB_FAIL, "isplib_spmm_tasks_count_hip: chunk >= 64 and short_row >= 0 required");
+   if (!info || !seg_off) return fail(ISPLIB_FAIL, "isplib_spmm_tasks_count_hip: null operand");
+   if (m * slices + 1 > 0x7fffffffLL) return fail(ISPLIB_FAIL, "isplib_spmm_tasks_count_hip: m*slices must be < 2^31");
+   hipStream_t st = (hipStream_t)stream;
+   memset(info, 0, sizeof(*info));
+   info->slices = slices; info->chunk = chunk; info->short_row = short_row;
+   if (m == 0) {
+      ISPLIB_HIP_TRY(hipMemsetAsync(seg_off, 0, sizeof(int32_t), st));
+      return ISPLIB_SUCCESS;
+   }
+   if (!pntrb || !pntre || !sliceptr || !workspace) return fail(ISPLIB_FAIL, "isplib_spmm_tasks_count_hip: null operand");
+   const int64_t items = m * slices + 1;
+   size_t temp = 0;
+   ISPLIB_HIP_TRY(plan_scan_temp_bytes(items, &temp));
+   const size_t cnt_bytes = align_up((size_t)items * sizeof(int));
+   if (workspace_bytes < cnt_bytes + align_up(temp)) return fail(ISPLIB_NOT_ENOUGH_MEM, "isplib_spmm_tasks_count_hip: workspace too small");
+   int *cnt = (int *)workspace;
+   void *tmp = (char *)workspace + cnt_bytes;
+   hipLaunchKernelGGL(plan_count_kernel, dim3(grid_for(items)), dim3(256), 0, st, m, slices, chunk, short_row, pntrb,
+                      pntre, sliceptr, cnt);
+   int rc = check_launch("plan_count_kernel");
+   if (rc) return rc;
+   ISPLIB_HIP_TRY(rocprim::exclusive_scan(tmp, temp, (const int *)cnt, (int *)seg_off, 0, (size_t)items,
+                                          rocprim::plus<int>(), st, false));
+   // the one host round trip of the plan: task count and the eight lane boundaries
+   int host[9];
+   const int64_t per_lane_items = (int64_t)(slices / 8) * m;
+   for (int x = 0; x < 9; x++)
+      ISPLIB_HIP_TRY(hipMemcpyAsync(&host[x], seg_off + x * per_lane_items, sizeof(int), hipMemcpyDeviceToHost, st));
+   ISPLIB_HIP_TRY(hipStreamSynchronize(st));
+   for (int x = 0; x < 9; x++) info->lane_off[x] = host[x];
+   info->n_tasks = host[8];
+   return ISPLIB_SUCCESS;
+}
+
+extern "C" int isplib_spmm_tasks_fill_hip(int64_t m, const int64_t *pntrb, const int64_t *pntre,
+                                          const int64_t *sliceptr, const isplib_task_plan_info *info,
+                                          const int32_t *seg_off, int32_t *task_row, int64_t *task_b,
+                                          int32_t *task_len, void *stream) {
+   clear_error();
+   if (!info) return fail(ISPLIB_FAIL, "isplib_spmm_tasks_fill_hip: null plan info");
+   if (m <= 0 || info->n_tasks == 0) return ISPLIB_SUCCESS;
+   if (!pntrb || !pntre || !sliceptr || !seg_off || !task_row || !task_b || !task_len)
+      return fail(ISPLIB_FAIL, "isplib_spmm_tasks_fill_hip: null operand");
+   hipLaunchKernelGGL(plan_fill_kernel, dim3(grid_for(m * info->slices)), dim3(256), 0, (hipStream_t)stream, m,
+                      info->slices, info->chunk, info->short_row, pntrb, pntre, sliceptr, seg_off, task_row, task_b,
+                      task_len);
+   return check_launch("plan_fill_kernel");
 }

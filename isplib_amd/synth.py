@@ -75,6 +75,53 @@ def chung_lu_csr(n: int, nnz: int, max_deg: int, sigma: float, seed: int, device
     return rowptr, col.contiguous()
 
 
+def _csr_from_pairs(a: torch.Tensor, b: torch.Tensor, n: int, und: int, gen: torch.Generator):
+    """Symmetric, loop-free, duplicate-free CSR from candidate undirected pairs (truncated to `und` edges)."""
+    keep = a != b
+    lo, hi = torch.minimum(a, b)[keep], torch.maximum(a, b)[keep]
+    keys = torch.unique(lo * n + hi)
+    if keys.numel() > und:
+        keys = keys[torch.randperm(keys.numel(), generator=gen, device=keys.device)[:und]]
+    lo, hi = keys // n, keys % n
+    full = torch.sort(torch.cat([lo * n + hi, hi * n + lo])).values
+    row, col = full // n, full % n
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=full.device)
+    torch.cumsum(torch.bincount(row, minlength=n), 0, out=rowptr[1:])
+    return rowptr, col.contiguous()
+
+
+def rmat_csr(n: int, nnz: int, seed: int = 7, device="cpu", abc=(0.57, 0.19, 0.19)):
+    """R-MAT (a,b,c = 0.57,0.19,0.19): strong community / locality structure -- the friendly case for
+    caches.  Returns a symmetric CSR with ~nnz entries (duplicates dropped)."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    und = nnz // 2
+    draw = int(und * 1.6)
+    bits = max(1, (n - 1).bit_length())
+    a_, b_, c_ = abc
+    r = torch.zeros(draw, dtype=torch.int64, device=device)
+    c = torch.zeros(draw, dtype=torch.int64, device=device)
+    for _ in range(bits):
+        u = torch.rand(draw, generator=gen, device=device)
+        down = (u >= a_ + b_)                    # quadrants c, d: lower half
+        right = ((u >= a_) & (u < a_ + b_)) | (u >= a_ + b_ + c_)   # quadrants b, d: right half
+        r = r * 2 + down.long()
+        c = c * 2 + right.long()
+    r, c = r % n, c % n
+    return _csr_from_pairs(r, c, n, und, gen)
+
+
+def uniform_csr(n: int, nnz: int, seed: int = 8, device="cpu"):
+    """Uniformly random endpoints: no hubs, no locality -- the cache-hostile case."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    und = nnz // 2
+    draw = int(und * 1.02) + 1024
+    a = torch.randint(0, n, (draw,), generator=gen, device=device)
+    b = torch.randint(0, n, (draw,), generator=gen, device=device)
+    return _csr_from_pairs(a, b, n, und, gen)
+
+
 def dataset_like(name: str, device="cpu", scale: float = 1.0) -> Tuple[torch.Tensor, torch.Tensor, int]:
     """(rowptr, col, n) of a Cora- / Reddit- / products-shaped graph.  ``scale`` < 1
     shrinks nodes and edges together (same mean degree) for CPU-sized tests."""

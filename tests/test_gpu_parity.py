@@ -261,3 +261,30 @@ def test_phased_sliced_spmm_equals_single_call(gpu, oracle_mod, world):
                 assert torch.equal(arg, one_arg)
                 garg = torch.where(arg == part.nnz, arg.new_full((), part.total_nnz), arg + part.edge0)
                 assert np.array_equal(garg.cpu().numpy(), ref_arg[r0:r1])
+
+
+@pytest.mark.parametrize("k", (4, 41, 64, 128, 300))
+def test_task_list_schedule(gpu, oracle_mod, k):
+    """fusedMM_csr_tasks_hip with plans that exercise chunked hub rows, unsliced short rows, empty rows."""
+    from isplib_amd import cabi
+    from isplib_amd.plan import build_task_plan
+    rowptr, col = cases.random_csr(400, 900, 30.0, seed=k, empty_rows=(0, 200, 399), hub=(123, 7000), duplicates=True)
+    val = cases.weights(col.size, 4, "signed_int" if k % 2 else "uniform")
+    x = cases.dense(900, k, 3, "integer" if k % 2 else "uniform")
+    d_rowptr, d_col, d_val, d_x = (_t(a, gpu) for a in (rowptr, col, val, x))
+    tol = cases.sum_tolerance(oracle_mod, rowptr, col, val, x)
+    for slices, chunk, short in ((8, 512, 256), (16, 64, 16), (8, 100, 0), (24, 512, 10 ** 9)):
+        plan = build_task_plan(d_rowptr, d_col, 900, slices, chunk, short)
+        assert plan is not None and plan.lane_off[0] == 0 and plan.lane_off[8] == plan.n_tasks
+        assert int(plan.task_len.sum()) == col.size and int(plan.task_len.max()) <= chunk
+        for red in cases.REDUCES:
+            for dv, hv in ((d_val, val), (None, np.ones_like(val))):
+                ref, ref_arg = oracle_mod.spmm_fw(rowptr, col, hv, x, red)
+                out, arg = cabi.spmm_tasks(d_rowptr, d_col, dv, plan, d_x, red)
+                again, _ = cabi.spmm_tasks(d_rowptr, d_col, dv, plan, d_x, red)
+                assert torch.equal(out, again)
+                if red in ("sum", "mean"):
+                    _assert_sum_close(out.cpu().numpy(), ref, tol if dv is not None else cases.sum_tolerance(oracle_mod, rowptr, col, hv, x))
+                else:
+                    assert np.array_equal(out.cpu().numpy().view(np.uint32), ref.view(np.uint32)), (red, slices)
+                    assert np.array_equal(arg.cpu().numpy(), ref_arg), (red, slices)
