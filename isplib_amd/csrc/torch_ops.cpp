@@ -27,6 +27,7 @@
 
 #include <initializer_list>
 #include <tuple>
+#include <vector>
 
 #include "../../include/isplib_hip.h"
 
@@ -59,9 +60,13 @@ void check_float(const Tensor &t, const char *name) {
 void *current_stream(const Tensor &t) { return (void *)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
 
 // fusedmm_spmm_fw, csrc/fusedmm.cpp:113-203
-// `slices_`: optional per-graph slice table (isplib_spmm_slices_build_hip) -> column-sliced kernel
+// `plan`: per-graph schedule operands (isplib_amd/plan.py, include/isplib_hip.h):
+//   {}                                                   plain row kernel
+//   {sliceptr}                                           column-sliced kernel
+//   {task_row, task_b, task_len, seg_off, lane_off_cpu}  task-list kernel
+using Plan = std::vector<Tensor>;
 std::tuple<Tensor, Tensor> spmm_fw(const Tensor &rowptr_, const Tensor &col_, const optional<Tensor> &value_,
-                                   const Tensor &mat_, int reduction, const Tensor &slices_ = Tensor()) {
+                                   const Tensor &mat_, int reduction, const Plan &plan = Plan()) {
    check_index(rowptr_, "rowptr");
    check_index(col_, "col");
    check_float(mat_, "mat");
@@ -85,9 +90,31 @@ std::tuple<Tensor, Tensor> spmm_fw(const Tensor &rowptr_, const Tensor &col_, co
    if (reduction == R_MEAN) msg = ISPLIB_MSG_SPMM_MEAN;
    if (reduction == R_MAX || reduction == R_MIN) arg = at::empty({M, K}, rowptr.options());
    const int64_t *rp = rowptr.data_ptr<int64_t>();
-   if (slices_.defined() && M > 0 && K > 0) {
-      check_index(slices_, "slices");
-      const Tensor table = slices_.contiguous();
+   const bool tasks_fit = K >= 4 && (double)N * (double)K * 4.0 <= 3.5 * 1073741824.0;
+   if (plan.size() == 5 && tasks_fit && M > 0 && K > 0) {
+      const Tensor &task_row = plan[0], &task_b = plan[1], &task_len = plan[2], &seg_off = plan[3], &lane = plan[4];
+      TORCH_CHECK(task_row.is_cuda() && task_row.scalar_type() == at::kInt && task_len.scalar_type() == at::kInt &&
+                      seg_off.scalar_type() == at::kInt && task_b.scalar_type() == at::kLong,
+                  "isplib: malformed task plan");
+      TORCH_CHECK(!lane.is_cuda() && lane.scalar_type() == at::kLong && lane.numel() == 9, "isplib: lane_off must be 9 host int64");
+      TORCH_CHECK((seg_off.numel() - 1) % M == 0, "isplib: task plan does not match rowptr");
+      const int nsl = (int)((seg_off.numel() - 1) / M);
+      const int64_t n_tasks = task_row.numel();
+      const size_t ws = isplib_spmm_tasks_workspace_bytes(msg, n_tasks, K);
+      Tensor work = at::empty({(int64_t)ws}, mat.options().dtype(at::kByte));
+      const int st = fusedMM_csr_tasks_hip(msg, M, N, K, nnz, value.defined() ? value.data_ptr<float>() : nullptr,
+                                           col.data_ptr<int64_t>(), rp, rp + 1, n_tasks, task_row.data_ptr<int32_t>(),
+                                           task_b.data_ptr<int64_t>(), task_len.data_ptr<int32_t>(),
+                                           seg_off.data_ptr<int32_t>(), nsl, lane.data_ptr<int64_t>(),
+                                           mat.data_ptr<float>(), K, out.data_ptr<float>(), K,
+                                           arg.defined() ? arg.data_ptr<int64_t>() : nullptr, work.data_ptr(), ws,
+                                           current_stream(mat));
+      check_status(st, "fusedMM_csr_tasks_hip");
+      return std::make_tuple(out, arg);
+   }
+   if (plan.size() == 1 && M > 0 && K > 0) {
+      check_index(plan[0], "slices");
+      const Tensor table = plan[0].contiguous();
       TORCH_CHECK(table.numel() % M == 0 && table.numel() / M >= 9, "isplib: slice table does not match rowptr");
       const int nsl = (int)(table.numel() / M - 1);
       const size_t ws = isplib_spmm_sliced_workspace_bytes(msg, M, K, nsl);
@@ -160,11 +187,10 @@ class SpmmSum : public torch::autograd::Function<SpmmSum> {
    static variable_list forward(AutogradContext *ctx, optional<Variable> opt_row, Variable rowptr, Variable col,
                                 optional<Variable> opt_value, optional<Variable> opt_colptr,
                                 optional<Variable> opt_csr2csc, Variable mat, optional<Variable> value_index_select,
-                                optional<Variable> row_index_select, optional<Variable> slices,
-                                optional<Variable> slices_t) {
+                                optional<Variable> row_index_select, Plan plan, Plan plan_t) {
       const bool has_value = opt_value.has_value() && opt_value->defined();
-      auto out = std::get<0>(spmm_fw(rowptr, col, opt_value, mat, R_SUM, or_undef(slices)));   // :244
-      ctx->saved_data["slices_t"] = or_undef(slices_t);
+      auto out = std::get<0>(spmm_fw(rowptr, col, opt_value, mat, R_SUM, plan));   // :244
+      ctx->saved_data["plan_t"] = plan_t;
       ctx->saved_data["has_value"] = has_value;
       ctx->saved_data["value_edge"] = edge_of({present(opt_row), true, true});
       ctx->saved_data["mat_edge"] =
@@ -190,7 +216,7 @@ class SpmmSum : public torch::autograd::Function<SpmmSum> {
          // :285  grad_mat = fusedmm_spmm_fw(colptr, row_index_select, value_index_select, grad_out)
          if (colptr.defined() && row_sel.defined() && (value_sel.defined() || !has_value)) {
             optional<Tensor> v = has_value ? optional<Tensor>(value_sel) : c10::nullopt;
-            grad_mat = std::get<0>(spmm_fw(colptr, row_sel, v, grad_out, R_SUM, ctx->saved_data["slices_t"].toTensor()));
+            grad_mat = std::get<0>(spmm_fw(colptr, row_sel, v, grad_out, R_SUM, ctx->saved_data["plan_t"].toTensorVector()));
          } else {
             auto t = build_transpose(rowptr, col, has_value ? value : Tensor(), mat.size(0), false);
             optional<Tensor> v = has_value ? optional<Tensor>(t.val_t) : c10::nullopt;
@@ -208,11 +234,10 @@ class SpmmMean : public torch::autograd::Function<SpmmMean> {
    static variable_list forward(AutogradContext *ctx, optional<Variable> opt_row, Variable rowptr, Variable col,
                                 optional<Variable> opt_value, optional<Variable> opt_rowcount,
                                 optional<Variable> opt_colptr, optional<Variable> opt_csr2csc, Variable mat,
-                                optional<Variable> new_row, optional<Variable> new_rowcount,
-                                optional<Variable> slices, optional<Variable> slices_t) {
+                                optional<Variable> new_row, optional<Variable> new_rowcount, Plan plan, Plan plan_t) {
       const bool has_value = opt_value.has_value() && opt_value->defined();
-      auto out = std::get<0>(spmm_fw(rowptr, col, opt_value, mat, R_MEAN, or_undef(slices)));   // :331
-      ctx->saved_data["slices_t"] = or_undef(slices_t);
+      auto out = std::get<0>(spmm_fw(rowptr, col, opt_value, mat, R_MEAN, plan));   // :331
+      ctx->saved_data["plan_t"] = plan_t;
       ctx->saved_data["has_value"] = has_value;
       ctx->saved_data["value_edge"] = edge_of({present(opt_row), true, true});
       ctx->saved_data["mat_edge"] = edge_of({present(opt_row), true, true, has_value, present(opt_rowcount),
@@ -242,7 +267,7 @@ class SpmmMean : public torch::autograd::Function<SpmmMean> {
                              new_rowcount.scalar_type() == at::kFloat && new_row.is_cuda();
          if (cached) {
             grad_mat = std::get<0>(spmm_fw(colptr, new_row, optional<Tensor>(new_rowcount), grad_out, R_SUM,
-                                           ctx->saved_data["slices_t"].toTensor()));
+                                           ctx->saved_data["plan_t"].toTensorVector()));
          } else {
             auto t = build_transpose(rowptr, col, has_value ? value : Tensor(), mat.size(0), true);
             grad_mat = std::get<0>(spmm_fw(t.colptr, t.row_t, optional<Tensor>(t.val_t), grad_out, R_SUM));
@@ -258,9 +283,9 @@ template <int RED>
 class SpmmMinMax : public torch::autograd::Function<SpmmMinMax<RED>> {
  public:
    static variable_list forward(AutogradContext *ctx, Variable rowptr, Variable col, optional<Variable> opt_value,
-                                Variable mat, optional<Variable> slices) {
+                                Variable mat, Plan plan) {
       const bool has_value = opt_value.has_value() && opt_value->defined();
-      auto result = spmm_fw(rowptr, col, opt_value, mat, RED, or_undef(slices));   // :397 / :465
+      auto result = spmm_fw(rowptr, col, opt_value, mat, RED, plan);   // :397 / :465
       auto out = std::get<0>(result);
       auto arg_out = std::get<1>(result);
       ctx->saved_data["has_value"] = has_value;
@@ -300,55 +325,54 @@ Tensor fusedmm_spmm_add(optional<Tensor> opt_row, Tensor rowptr, Tensor col, opt
                         optional<Tensor> opt_colptr, optional<Tensor> opt_csr2csc, Tensor mat,
                         optional<Tensor> value_index_select, optional<Tensor> row_index_select) {
    return SpmmSum::apply(opt_row, rowptr, col, opt_value, opt_colptr, opt_csr2csc, mat, value_index_select,
-                         row_index_select, optional<Tensor>(), optional<Tensor>())[0];
+                         row_index_select, Plan(), Plan())[0];
 }
 
-// same op with the per-graph slice tables of A (forward) and A^T (backward): column-sliced kernels
-Tensor fusedmm_spmm_sliced(Tensor rowptr, Tensor col, optional<Tensor> opt_value, optional<Tensor> opt_colptr,
-                           Tensor mat, optional<Tensor> value_t, optional<Tensor> row_t, optional<Tensor> slices,
-                           optional<Tensor> slices_t) {
+// same operators fed with the per-graph schedule operands of A (forward) and A^T (backward)
+Tensor fusedmm_spmm_planned(Tensor rowptr, Tensor col, optional<Tensor> opt_value, optional<Tensor> opt_colptr,
+                            Tensor mat, optional<Tensor> value_t, optional<Tensor> row_t, Plan plan, Plan plan_t) {
    return SpmmSum::apply(optional<Tensor>(), rowptr, col, opt_value, opt_colptr, optional<Tensor>(), mat, value_t,
-                         row_t, slices, slices_t)[0];
+                         row_t, plan, plan_t)[0];
 }
 
-Tensor fusedmm_spmm_mean_sliced(Tensor rowptr, Tensor col, optional<Tensor> opt_value, optional<Tensor> opt_colptr,
-                                Tensor mat, optional<Tensor> row_t, optional<Tensor> mean_value_t,
-                                optional<Tensor> slices, optional<Tensor> slices_t) {
+Tensor fusedmm_spmm_mean_planned(Tensor rowptr, Tensor col, optional<Tensor> opt_value, optional<Tensor> opt_colptr,
+                                 Tensor mat, optional<Tensor> row_t, optional<Tensor> mean_value_t, Plan plan,
+                                 Plan plan_t) {
    return SpmmMean::apply(optional<Tensor>(), rowptr, col, opt_value, optional<Tensor>(), opt_colptr,
-                          optional<Tensor>(), mat, row_t, mean_value_t, slices, slices_t)[0];
+                          optional<Tensor>(), mat, row_t, mean_value_t, plan, plan_t)[0];
 }
 
-std::tuple<Tensor, Tensor> fusedmm_spmm_max_sliced(Tensor rowptr, Tensor col, optional<Tensor> opt_value, Tensor mat,
-                                                   optional<Tensor> slices);
-std::tuple<Tensor, Tensor> fusedmm_spmm_min_sliced(Tensor rowptr, Tensor col, optional<Tensor> opt_value, Tensor mat,
-                                                   optional<Tensor> slices);
+std::tuple<Tensor, Tensor> fusedmm_spmm_max_planned(Tensor rowptr, Tensor col, optional<Tensor> opt_value, Tensor mat,
+                                                    Plan plan);
+std::tuple<Tensor, Tensor> fusedmm_spmm_min_planned(Tensor rowptr, Tensor col, optional<Tensor> opt_value, Tensor mat,
+                                                    Plan plan);
 
 Tensor fusedmm_spmm_mean(optional<Tensor> opt_row, Tensor rowptr, Tensor col, optional<Tensor> opt_value,
                          optional<Tensor> opt_rowcount, optional<Tensor> opt_colptr, optional<Tensor> opt_csr2csc,
                          Tensor mat, optional<Tensor> new_row, optional<Tensor> new_rowcount) {
    return SpmmMean::apply(opt_row, rowptr, col, opt_value, opt_rowcount, opt_colptr, opt_csr2csc, mat, new_row,
-                          new_rowcount, optional<Tensor>(), optional<Tensor>())[0];
+                          new_rowcount, Plan(), Plan())[0];
 }
 
 std::tuple<Tensor, Tensor> fusedmm_spmm_max(Tensor rowptr, Tensor col, optional<Tensor> opt_value, Tensor mat) {
-   auto r = SpmmMinMax<R_MAX>::apply(rowptr, col, opt_value, mat, optional<Tensor>());
+   auto r = SpmmMinMax<R_MAX>::apply(rowptr, col, opt_value, mat, Plan());
    return std::make_tuple(r[0], r[1]);
 }
 
-std::tuple<Tensor, Tensor> fusedmm_spmm_max_sliced(Tensor rowptr, Tensor col, optional<Tensor> opt_value, Tensor mat,
-                                                   optional<Tensor> slices) {
-   auto r = SpmmMinMax<R_MAX>::apply(rowptr, col, opt_value, mat, slices);
+std::tuple<Tensor, Tensor> fusedmm_spmm_max_planned(Tensor rowptr, Tensor col, optional<Tensor> opt_value, Tensor mat,
+                                                    Plan plan) {
+   auto r = SpmmMinMax<R_MAX>::apply(rowptr, col, opt_value, mat, plan);
    return std::make_tuple(r[0], r[1]);
 }
 
-std::tuple<Tensor, Tensor> fusedmm_spmm_min_sliced(Tensor rowptr, Tensor col, optional<Tensor> opt_value, Tensor mat,
-                                                   optional<Tensor> slices) {
-   auto r = SpmmMinMax<R_MIN>::apply(rowptr, col, opt_value, mat, slices);
+std::tuple<Tensor, Tensor> fusedmm_spmm_min_planned(Tensor rowptr, Tensor col, optional<Tensor> opt_value, Tensor mat,
+                                                    Plan plan) {
+   auto r = SpmmMinMax<R_MIN>::apply(rowptr, col, opt_value, mat, plan);
    return std::make_tuple(r[0], r[1]);
 }
 
 std::tuple<Tensor, Tensor> fusedmm_spmm_min(Tensor rowptr, Tensor col, optional<Tensor> opt_value, Tensor mat) {
-   auto r = SpmmMinMax<R_MIN>::apply(rowptr, col, opt_value, mat, optional<Tensor>());
+   auto r = SpmmMinMax<R_MIN>::apply(rowptr, col, opt_value, mat, Plan());
    return std::make_tuple(r[0], r[1]);
 }
 
@@ -369,15 +393,16 @@ TORCH_LIBRARY(isplib, m) {
    m.def("fusedmm_spmm_min(Tensor rowptr, Tensor col, Tensor? value, Tensor mat) -> (Tensor, Tensor)",
          &fusedmm_spmm_min);
    m.def("performDummySpMM(int flag) -> ()", &performDummySpMM);
-   // additions (not in the reference): the same operators fed with per-graph slice tables
-   m.def("fusedmm_spmm_sliced(Tensor rowptr, Tensor col, Tensor? value, Tensor? colptr, Tensor mat, Tensor? value_t, "
-         "Tensor? row_t, Tensor? slices, Tensor? slices_t) -> Tensor",
-         &fusedmm_spmm_sliced);
-   m.def("fusedmm_spmm_mean_sliced(Tensor rowptr, Tensor col, Tensor? value, Tensor? colptr, Tensor mat, Tensor? row_t, "
-         "Tensor? mean_value_t, Tensor? slices, Tensor? slices_t) -> Tensor",
-         &fusedmm_spmm_mean_sliced);
-   m.def("fusedmm_spmm_max_sliced(Tensor rowptr, Tensor col, Tensor? value, Tensor mat, Tensor? slices) -> (Tensor, Tensor)",
-         &fusedmm_spmm_max_sliced);
-   m.def("fusedmm_spmm_min_sliced(Tensor rowptr, Tensor col, Tensor? value, Tensor mat, Tensor? slices) -> (Tensor, Tensor)",
-         &fusedmm_spmm_min_sliced);
+   // additions (not in the reference): the same operators fed with per-graph schedule operands
+   // (plan = [] | [sliceptr] | [task_row, task_b, task_len, seg_off, lane_off_cpu]; plan_t: the same for A^T)
+   m.def("fusedmm_spmm_planned(Tensor rowptr, Tensor col, Tensor? value, Tensor? colptr, Tensor mat, Tensor? value_t, "
+         "Tensor? row_t, Tensor[] plan, Tensor[] plan_t) -> Tensor",
+         &fusedmm_spmm_planned);
+   m.def("fusedmm_spmm_mean_planned(Tensor rowptr, Tensor col, Tensor? value, Tensor? colptr, Tensor mat, Tensor? row_t, "
+         "Tensor? mean_value_t, Tensor[] plan, Tensor[] plan_t) -> Tensor",
+         &fusedmm_spmm_mean_planned);
+   m.def("fusedmm_spmm_max_planned(Tensor rowptr, Tensor col, Tensor? value, Tensor mat, Tensor[] plan) -> (Tensor, Tensor)",
+         &fusedmm_spmm_max_planned);
+   m.def("fusedmm_spmm_min_planned(Tensor rowptr, Tensor col, Tensor? value, Tensor mat, Tensor[] plan) -> (Tensor, Tensor)",
+         &fusedmm_spmm_min_planned);
 }

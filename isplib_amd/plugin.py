@@ -129,22 +129,22 @@ def spmm_autotuned(src, other: torch.Tensor, reduce: str = "sum") -> torch.Tenso
     ops = torch.ops.isplib
     k = mat.size(-1)
     n_sl = choose_slices(s, mat.size(0), k, reduce in ("max", "min"))
-    table = s.slices(n_sl) if n_sl else None                         # per-graph, built once on the device
+    plan = s.plan(n_sl)                                              # per-graph, built once on the device
     if reduce in ("sum", "add", "mean"):
-        colptr = val_t = row_t = table_t = None
+        colptr = val_t = row_t = None
+        plan_t = []
         if needs_grad:                                               # :76-80 / :83-99 (built once per graph)
             colptr, row_t = s.colptr(), s.row_t()
             val_t = s.mean_val_t() if reduce == "mean" else s.val_t()   # mean: intended pairing
-            n_sl_t = choose_slices(s, rowptr.numel() - 1, k)
-            table_t = s.slices_t(n_sl_t) if n_sl_t else None
+            plan_t = s.plan_t(choose_slices(s, rowptr.numel() - 1, k))
         if reduce == "mean":
-            out = ops.fusedmm_spmm_mean_sliced(rowptr, col, value, colptr, mat, row_t, val_t, table, table_t)
+            out = ops.fusedmm_spmm_mean_planned(rowptr, col, value, colptr, mat, row_t, val_t, plan, plan_t)
         else:
-            out = ops.fusedmm_spmm_sliced(rowptr, col, value, colptr, mat, val_t, row_t, table, table_t)
+            out = ops.fusedmm_spmm_planned(rowptr, col, value, colptr, mat, val_t, row_t, plan, plan_t)
     elif reduce == "max":
-        out = ops.fusedmm_spmm_max_sliced(rowptr, col, value, mat, table)[0]   # :143
+        out = ops.fusedmm_spmm_max_planned(rowptr, col, value, mat, plan)[0]   # :143
     else:
-        out = ops.fusedmm_spmm_min_sliced(rowptr, col, value, mat, table)[0]   # :145
+        out = ops.fusedmm_spmm_min_planned(rowptr, col, value, mat, plan)[0]   # :145
     return out.squeeze(-1) if squeeze else out
 
 

@@ -42,6 +42,8 @@ class SparseStorage:
         # slice tables of the column-sliced kernels, {n_slices: table | None (rows not sorted)}
         self._slices = {}
         self._slices_t = {}
+        self._plans = {}
+        self._plans_t = {}
 
     def sparse_sizes(self) -> Tuple[int, int]:
         return self._sparse_sizes
@@ -90,6 +92,28 @@ class SparseStorage:
         if self._value is not None and self._val_t is None:
             self._build_transpose()
         return self._val_t
+
+    def plan(self, n_slices: int):
+        """Schedule operands of A for the `_planned` operators: [] (plain kernel) or the task plan
+        [task_row, task_b, task_len, seg_off, lane_off_cpu]; built once per graph and slice count."""
+        return self._plan_for(self._plans, n_slices, self._rowptr, self._col, self._sparse_sizes[1])
+
+    def plan_t(self, n_slices: int):
+        """The same for A^T (CSC operands)."""
+        if n_slices <= 0:
+            return []
+        return self._plan_for(self._plans_t, n_slices, self.colptr(), self.row_t(), self._sparse_sizes[0])
+
+    @staticmethod
+    def _plan_for(cache, n_slices, rowptr, col, ncols):
+        if n_slices <= 0:
+            return []
+        if n_slices not in cache:
+            from .plan import build_task_plan
+            p = build_task_plan(rowptr, col, ncols, n_slices)
+            cache[n_slices] = [] if p is None else [p.task_row, p.task_b, p.task_len, p.seg_off,
+                                                    torch.tensor(p.lane_off, dtype=torch.int64)]
+        return cache[n_slices]
 
     def slices(self, n_slices: int) -> Optional[torch.Tensor]:
         """Slice table of A for fusedMM_csr_sliced_hip, or None when rows are not column-sorted."""
