@@ -87,19 +87,20 @@ def _storage_of(src, other: torch.Tensor) -> SparseStorage:
 def suggest_slices(m: int, n: int, nnz: int, k: int, minmax: bool = False) -> int:
     """Column-slice count for an M x N, nnz-entry SpMM over K fp32 features (0 = plain kernel).
 
-    Two measured constraints on MI355X: a slice of the dense operand should
-    be about 8 MB (2x an XCD's 4 MiB L2: hot rows stay resident, 72 % L2 hits on the Reddit-shaped
-    graph) and a (row, slice) segment must keep >= ~30 edges or per-wave overhead and the partial
-    planes (S * M * K * 4 B written and re-read) eat the gain.  Reddit-shaped: K=32 -> 0, K=64 -> 8,
-    K=128 -> 16, K=256 -> 16; ogbn-products-shaped (mean degree 50) -> 0."""
+    Two measured constraints on MI355X (task-list schedule): a slice of the dense
+    operand should be about 8 MB (2x an XCD's 4 MiB L2: the hot rows stay resident) and a row must keep
+    ~20 edges per slice or per-task overhead and the partial rows eat the gain.  Reddit-shaped graph
+    (mean degree 492): K=32 -> 8, K=64 -> 8, K=128 -> 16, K=256 -> 24 (same optimum for max/min);
+    ogbn-products-shaped (mean degree 50) -> 0; anything whose dense operand is under 16 MB -> 0."""
+    del minmax
     if m <= 0 or n <= 0:
         return 0
-    # max/min also write and re-read an int32 id plane per slice: fewer, larger slices pay (measured
-    # K=64/128/256: 8/8/16 slices for max against 8/16/16 for sum)
-    by_cache = (n * k * 4) / float(8 << 20) * (0.6 if minmax else 1.0)
-    by_degree = (nnz / m) / 30.0
-    s = int(min(by_cache, by_degree) / 8.0 + 0.5) * 8
-    return min(s, 64) if s >= 8 else 0
+    by_cache = (n * k * 4) / float(8 << 20)
+    avg_deg = nnz / m
+    if by_cache < 2.0 or avg_deg < 64:
+        return 0
+    s = int(min(by_cache, avg_deg / 20.0) / 8.0 + 0.5) * 8
+    return min(max(s, 8), 64)
 
 
 def choose_slices(storage: SparseStorage, rows: int, k: int, minmax: bool = False) -> int:
