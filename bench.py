@@ -152,9 +152,10 @@ def main():
         tplan = build_task_plan(l_rowptr, l_col, x_in.size(0), a.slices, a.chunk, a.short)
         twork = tplan.workspace(a.reduce, k)
 
-    def spmm(rp, cl, vl, tb, xin, o, ar):
-        if tplan is not None and rp is l_rowptr:
-            cabi.fusedMM_csr_tasks_hip(msg, rp, cl, vl, tplan, xin, o, ar, twork)
+    def spmm(rp, cl, vl, tb, xin, o, ar, tp=None):
+        tp = tplan if (tp is None and rp is l_rowptr) else tp
+        if tp is not None:
+            cabi.fusedMM_csr_tasks_hip(msg, rp, cl, vl, tp, xin, o, ar, twork)
         elif tb is not None:
             cabi.fusedMM_csr_sliced_hip(msg, rp, cl, vl, tb, a.slices, xin, o, ar, work)
         else:
@@ -225,12 +226,16 @@ def main():
         dy = synth.features(n, k, seed=5, device=dev)
         dx = torch.empty((n, k), dtype=torch.float32, device=dev)
         table_t = cabi.spmm_slices(colptr, row_t, n, a.slices)[0] if a.slices > 0 else None
+        tplan_t = None
+        if tplan is not None:
+            tplan_t = build_task_plan(colptr, row_t, n, a.slices, a.chunk, a.short)
+            twork = tplan_t.workspace(a.reduce, k) if tplan_t.n_tasks > tplan.n_tasks else twork
         for _ in range(2):
-            spmm(colptr, row_t, val_t, table_t, dy, dx, None)
+            spmm(colptr, row_t, val_t, table_t, dy, dx, None, tplan_t)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         for _ in range(5):
-            spmm(colptr, row_t, val_t, table_t, dy, dx, None)
+            spmm(colptr, row_t, val_t, table_t, dy, dx, None, tplan_t)
         e.record()
         torch.cuda.synchronize()
         bms = s.elapsed_time(e) / 5
@@ -246,9 +251,10 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         # measured offline (separate --pmc passes cannot run inside this process): profiles/traffic.json
-        if os.path.exists(tpath) and world == 1 and a.scale == 1.0 and not a.weighted:
+        if os.path.exists(tpath) and world == 1 and a.scale == 1.0 and not a.weighted and a.generator == "chunglu" \
+                and (a.chunk, a.short) == (1024, 128):
             try:
-                rec = json.load(open(tpath)).get(f"{a.workload}-{a.reduce}-k{k}-s{a.slices}")
+                rec = json.load(open(tpath)).get(f"{a.workload}-{a.reduce}-k{k}-s{a.slices}" + ("-tasks" if tplan is not None else ""))
                 traffic = rec["hbm_bytes_per_launch"] if rec else None
             except Exception:
                 traffic = None
@@ -271,7 +277,8 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                 "traffic_source": None if traffic is None else "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, gfx950-corrected)",
-                "kernel": "spmm_csr_kernel" + (f"<sliced x{a.slices}> + combine_slices_kernel" if a.slices > 0 else ""),
+                "kernel": ("spmm_task_kernel + combine_tasks_kernel" if tplan is not None else
+                           "spmm_csr_kernel" + (f"<sliced x{a.slices}> + combine_slices_kernel" if a.slices > 0 else "")),
                 "kernel_avg_ms": kern_avg_ms, "algorithmic_bytes_per_launch": b_alg,
                 "gather_model_GBps": synth.gather_bytes(m_local, l_col.numel(), k) / (kern_avg_ms * 1e-3) / 1e9,
             },
