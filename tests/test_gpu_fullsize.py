@@ -25,11 +25,20 @@ def reddit(gpu):
     return rowptr, col, n, table
 
 
+@pytest.fixture(scope="module")
+def reddit_plan(reddit):
+    from isplib_amd.plan import build_task_plan
+    rowptr, col, n, _ = reddit
+    plan = build_task_plan(rowptr, col, n, 16)            # the default schedule of bench.py / the plug-in
+    assert plan is not None and int(plan.task_len.sum()) == col.numel() and int(plan.task_len.max()) <= 1024
+    return plan
+
+
 def _host(*ts):
     return [t.cpu().numpy() for t in ts]
 
 
-def test_config2_reddit_sum_k128_against_oracle(gpu, reddit, oracle_mod):
+def test_config2_reddit_sum_k128_against_oracle(gpu, reddit, reddit_plan, oracle_mod):
     from isplib_amd import cabi, synth
     rowptr, col, n, table = reddit
     k = 128
@@ -38,18 +47,21 @@ def test_config2_reddit_sum_k128_against_oracle(gpu, reddit, oracle_mod):
     sliced, _ = cabi.spmm_sliced(rowptr, col, None, table, 8, x, "sum")
     again, _ = cabi.spmm_sliced(rowptr, col, None, table, 8, x, "sum")
     assert torch.equal(sliced, again), "sliced path must be bitwise reproducible"
+    tasks, _ = cabi.spmm_tasks(rowptr, col, None, reddit_plan, x, "sum")
+    again, _ = cabi.spmm_tasks(rowptr, col, None, reddit_plan, x, "sum")
+    assert torch.equal(tasks, again), "task schedule must be bitwise reproducible"
     rp, cl, xx = _host(rowptr, col, x)
     ones = np.ones(cl.size, np.float32)
     ref, _ = oracle_mod.spmm_fw(rp, cl, ones, xx, "sum")
     mag, _ = oracle_mod.spmm_fw(rp, cl, ones, np.abs(xx), "sum")
-    for name, got in (("plain", plain), ("sliced", sliced)):
+    for name, got in (("plain", plain), ("sliced", sliced), ("tasks", tasks)):
         err = np.abs(got.cpu().numpy() - ref)
         assert np.all(err <= 1e-5 * mag + 1e-30), f"{name}: max err/bound {np.max(err / (1e-5 * mag + 1e-30)):.3f}"
     # checksum of checksums in fp64: sum_i out[i,:] == sum_j deg[j] * x[j,:]  (unit weights, symmetric graph)
     deg = (rowptr[1:] - rowptr[:-1]).double()
     expect = (deg[:, None] * x.double()).sum(0)
     slack = 1e-8 * (deg[:, None] * x.double().abs()).sum(0)      # fp32 rounding of 233K row sums, random sign
-    for got in (plain, sliced):
+    for got in (plain, sliced, tasks):
         assert bool(((got.double().sum(0) - expect).abs() <= slack).all())
     # linearity: A(x + 2y) == Ax + 2Ay within fp32 rounding of the sums
     y = synth.features(n, k, seed=11, device=gpu)
@@ -76,7 +88,7 @@ def test_config2_backward_on_symmetric_graph(gpu, reddit):
 
 
 @pytest.mark.parametrize("red", ("mean", "max", "min"))
-def test_config3_reddit_k64_against_oracle(gpu, reddit, oracle_mod, red):
+def test_config3_reddit_k64_against_oracle(gpu, reddit, reddit_plan, oracle_mod, red):
     from isplib_amd import cabi, synth
     rowptr, col, n, table = reddit
     k = 64
@@ -84,14 +96,15 @@ def test_config3_reddit_k64_against_oracle(gpu, reddit, oracle_mod, red):
     w = synth.edge_weights(col.numel(), device=gpu)
     plain, parg = cabi.spmm(rowptr, col, w, x, red)
     sliced, sarg = cabi.spmm_sliced(rowptr, col, w, table, 8, x, red)
+    tasks, targ = cabi.spmm_tasks(rowptr, col, w, reddit_plan, x, red)
     rp, cl, ww, xx = _host(rowptr, col, w, x)
     ref, ref_arg = oracle_mod.spmm_fw(rp, cl, ww, xx, red)
     if red == "mean":
         mag, _ = oracle_mod.spmm_fw(rp, cl, ww, np.abs(xx), "mean")
-        for got in (plain, sliced):
+        for got in (plain, sliced, tasks):
             assert np.all(np.abs(got.cpu().numpy() - ref) <= 1e-5 * mag + 1e-30)
     else:
-        for got, arg in ((plain, parg), (sliced, sarg)):
+        for got, arg in ((plain, parg), (sliced, sarg), (tasks, targ)):
             assert np.array_equal(got.cpu().numpy().view(np.uint32), ref.view(np.uint32)), "values must be bit-exact"
             assert np.array_equal(arg.cpu().numpy(), ref_arg), "arg indices must be bit-exact"
         # arg really points at an edge of its row that attains the value
