@@ -104,11 +104,15 @@ def suggest_slices(m: int, n: int, nnz: int, k: int, minmax: bool = False) -> in
 
 
 def choose_slices(storage: SparseStorage, rows: int, k: int, minmax: bool = False) -> int:
-    """suggest_slices for a graph held in `storage`; ISPLIB_SLICES=<n> overrides (0 disables)."""
+    """Slice count for a graph held in `storage`: ISPLIB_SLICES=<n> (0 disables) > a count measured by
+    `iSpLibPlugin.autotune` for this graph and width > the `suggest_slices` rule."""
     env = os.environ.get("ISPLIB_SLICES")
     if env is not None:
         n = int(env)
         return n if n >= 8 and n % 8 == 0 else 0
+    tuned = storage._tuned.get((rows, k, minmax))
+    if tuned is not None:
+        return tuned
     return suggest_slices(storage._rowptr.numel() - 1, rows, storage._col.numel(), k, minmax)
 
 
@@ -187,6 +191,37 @@ class iSpLibPlugin:
                 _pyg_typing.WITH_PT2 = pt2
             if pt20 is not None:
                 _pyg_typing.WITH_PT20 = pt20
+
+    @classmethod
+    def autotune(cls, src, k: int, reduce: str = "sum", candidates=(0, 8, 16, 24, 32), reps: int = 3, other_rows=None):
+        """Times the SpMM of `src` at width `k` for each candidate slice count on the actual graph and keeps
+        the fastest for every later call (the heir of the reference's tuning scripts: autotuner/findbestk.py:34-38
+        sweeps K and prints a table, gpu/kernels/codegen.py:30-41 sweeps a launch parameter).  Returns
+        {slices: milliseconds}.  Costs one plan build per candidate; results live on the graph's storage."""
+        rowptr, col, value = src.csr()
+        x = torch.zeros((other_rows or src.sparse_sizes()[1], k), dtype=torch.float32, device=col.device)
+        s = _storage_of(src, x)
+        minmax = reduce in ("max", "min")
+        key = (x.size(0), k, minmax)
+        times = {}
+        start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for cand in candidates:
+            s._tuned[key] = cand
+            try:
+                spmm_autotuned(src, x, reduce)                     # builds the plan, warms up
+                start.record()
+                for _ in range(reps):
+                    spmm_autotuned(src, x, reduce)
+                stop.record()
+                torch.cuda.synchronize()
+                times[cand] = start.elapsed_time(stop) / reps
+            except RuntimeError:
+                continue
+        if times:
+            s._tuned[key] = min(times, key=times.get)
+        else:
+            s._tuned.pop(key, None)
+        return times
 
     @classmethod
     def is_patched(cls) -> bool:

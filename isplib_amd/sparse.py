@@ -44,6 +44,7 @@ class SparseStorage:
         self._slices_t = {}
         self._plans = {}
         self._plans_t = {}
+        self._tuned = {}          # (dense rows, k, minmax) -> slice count measured by iSpLibPlugin.autotune
 
     def sparse_sizes(self) -> Tuple[int, int]:
         return self._sparse_sizes

@@ -305,3 +305,17 @@ def test_boundary_calls_are_hipgraph_capturable(gpu, oracle_mod):
         tol = cases.sum_tolerance(oracle_mod, rowptr, col, val, xs)
         assert np.all(np.abs(out_a.cpu().numpy() - ref) <= tol)
         assert np.all(np.abs(out_b.cpu().numpy() - ref) <= tol)
+
+
+def test_autotune_keeps_the_fastest_slice_count(gpu, oracle_mod):
+    import isplib_amd
+    rowptr, col = cases.random_csr(600, 600, 90.0, seed=17)
+    val = cases.weights(col.size, 4)
+    x = cases.dense(600, 64, 3)
+    adj = isplib_amd.SparseTensor.from_csr(_t(rowptr, gpu), _t(col, gpu), _t(val, gpu), (600, 600))
+    times = isplib_amd.iSpLibPlugin.autotune(adj, 64, "sum", candidates=(0, 8, 16))
+    assert set(times) == {0, 8, 16} and all(t > 0 for t in times.values())
+    assert adj.storage._tuned[(600, 64, False)] == min(times, key=times.get)
+    out = isplib_amd.matmul(adj, _t(x, gpu))
+    ref, _ = oracle_mod.spmm_fw(rowptr, col, val, x, "sum")
+    assert np.all(np.abs(out.cpu().numpy() - ref) <= cases.sum_tolerance(oracle_mod, rowptr, col, val, x))
