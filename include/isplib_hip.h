@@ -221,6 +221,15 @@ int isplib_sddmm_csr_hip(int64_t m, int64_t k, const int64_t *indx,
                          const int64_t *pntrb, const int64_t *pntre,
                          const float *y, int64_t ldy, const float *g,
                          int64_t ldg, int mean, float *dval, void *stream);
+/* The same over the task plan of the SpMM (one wave per task, XCD-lane grouping -> the L2 affinity of
+ * the task-list SpMM; dval is per edge, so no workspace and no combine).  4 <= k <= 1024. */
+int isplib_sddmm_csr_tasks_hip(int64_t m, int64_t n, int64_t k, const int64_t *indx,
+                               const int64_t *pntrb, const int64_t *pntre,
+                               int64_t n_tasks, const int32_t *task_row,
+                               const int64_t *task_b, const int32_t *task_len,
+                               const int64_t *lane_off_host /*9, host*/,
+                               const float *y, int64_t ldy, const float *g, int64_t ldg,
+                               int mean, float *dval, void *stream);
 
 /*
  * Graph preparation on the device (the step immediately before the path).

@@ -32,6 +32,7 @@ EXPORTS = (
     "fusedMM_csr_sliced_hip", "fusedMM_csr_sliced_phase_hip", "isplib_hip_tune",
     "isplib_spmm_tasks_workspace_bytes", "fusedMM_csr_tasks_hip",
     "isplib_spmm_tasks_plan_workspace_bytes", "isplib_spmm_tasks_count_hip", "isplib_spmm_tasks_fill_hip",
+    "isplib_sddmm_csr_tasks_hip",
 )
 
 _i64, _f32, _vp, _i32 = ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_int32
@@ -90,6 +91,9 @@ def lib() -> ctypes.CDLL:
                                                   ctypes.c_size_t, ctypes.POINTER(TaskPlanInfo), _vp]
         L.isplib_spmm_tasks_fill_hip.restype = ctypes.c_int
         L.isplib_spmm_tasks_fill_hip.argtypes = [_i64, _vp, _vp, _vp, ctypes.POINTER(TaskPlanInfo), _vp, _vp, _vp, _vp, _vp]
+        L.isplib_sddmm_csr_tasks_hip.restype = ctypes.c_int
+        L.isplib_sddmm_csr_tasks_hip.argtypes = [_i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp,
+                                                 _i64, ctypes.c_int, _vp, _vp]
         L.isplib_hip_tune.restype = ctypes.c_int
         L.isplib_hip_tune.argtypes = [ctypes.c_int, ctypes.c_int]
         _sigs_set = True
@@ -331,3 +335,21 @@ def spmm_tasks(rowptr, col, val, plan, y, reduce: str = "sum", workspace=None):
         workspace = plan.workspace(reduce, k)
     fusedMM_csr_tasks_hip(MESSAGE[reduce], rowptr, col, val, plan, y, out, arg, workspace)
     return out, arg
+
+
+def sddmm_tasks(rowptr, col, plan, y, g, mean: bool = False):
+    """dA over the task plan of the SpMM (isplib_sddmm_csr_tasks_hip)."""
+    rowptr = _dev(rowptr, "rowptr", torch.int64)
+    col = _dev(col, "col", torch.int64)
+    y = _dev(y, "y", torch.float32)
+    g = _dev(g, "g", torch.float32)
+    m, n, k = rowptr.numel() - 1, y.size(0), y.size(1)
+    dval = torch.empty(col.numel(), dtype=torch.float32, device=y.device)
+    rp = rowptr.data_ptr()
+    lane = (ctypes.c_int64 * 9)(*plan.lane_off)
+    with torch.cuda.device(y.device):
+        st = lib().isplib_sddmm_csr_tasks_hip(m, n, k, _ptr(col), ctypes.c_void_p(rp), ctypes.c_void_p(rp + 8), plan.n_tasks,
+                                              _ptr(plan.task_row), _ptr(plan.task_b), _ptr(plan.task_len), lane, _ptr(y), k,
+                                              _ptr(g), k, int(bool(mean)), _ptr(dval), _stream(y.device))
+    _check(st, "isplib_sddmm_csr_tasks_hip")
+    return dval

@@ -122,6 +122,101 @@ __global__ __launch_bounds__(WAVES * 64) void sddmm_csr_kernel(const SddmmArgs a
    }
 }
 
+// ---- SDDMM over the task plan of the SpMM (include/isplib_hip.h, fusedMM_csr_tasks_hip) ----------
+// One wave per task: the task's edges all lie in one column slice, tasks are grouped by XCD lane, so
+// the gathers of y enjoy the same L2 affinity as the task-list SpMM -- and since dval is per edge,
+// no partials and no combine are needed at all.  g[row, :] sits in registers for the whole task.
+constexpr unsigned SD_BUF_LIMIT = 0xE0000000u, SD_BUF_OOB = 0xF0000000u;
+typedef __attribute__((__vector_size__(4 * sizeof(int)))) int sd_v4i_t;
+
+struct SddmmTaskArgs {
+   int64_t k;
+   const int64_t *indx, *pntrb, *pntre;
+   const float *y;
+   int64_t ldy;
+   unsigned ybytes;
+   const float *g;
+   int64_t ldg;
+   int mean;
+   float *dval;
+   const int *task_row;
+   const int64_t *task_b;
+   const int *task_len;
+   int64_t lane_off[9];
+};
+
+template <int LPR, int NCH, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void sddmm_task_kernel(const SddmmTaskArgs a) {
+   constexpr int G = 64 / LPR, U = 4;
+   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+   const int g = lane / LPR, lc = lane % LPR;
+   const unsigned xcd = blockIdx.x & 7u, within = blockIdx.x >> 3;
+   const int64_t t = a.lane_off[xcd] + (int64_t)within * WAVES + wave;
+   if (t >= a.lane_off[xcd + 1]) return;
+   __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.y), 0, (int)a.ybytes, 0x00020000);
+   const int row = a.task_row[t];
+   const int64_t b = a.task_b[t], e = b + a.task_len[t];
+   const int64_t deg = a.pntre[row] - a.pntrb[row];
+   const float scale = a.mean ? 1.0f / (float)(deg > 1 ? deg : 1) : 1.0f;
+   // this lane's columns of g[row]; ragged k: the last vector is shifted back, its duplicate components zeroed
+   unsigned cbyte[NCH];
+   float gv[NCH][4];
+#pragma unroll
+   for (int j = 0; j < NCH; j++) {
+      int c = (j * LPR + lc) * 4;
+      int vfirst = 0;
+      const bool ok = c < (int)a.k;
+      if (ok && c + 4 > (int)a.k) { vfirst = c + 4 - (int)a.k; c = (int)a.k - 4; }
+      cbyte[j] = ok ? (unsigned)c * 4u : SD_BUF_OOB;
+      const float *gr = a.g + (size_t)row * (size_t)a.ldg + c;
+#pragma unroll
+      for (int v = 0; v < 4; v++) gv[j][v] = (ok && v >= vfirst) ? gr[v] : 0.0f;
+   }
+   const unsigned ldyb = (unsigned)a.ldy * 4u;
+   for (int64_t base = b; base < e; base += 64) {
+      const int64_t p = base + lane;
+      const unsigned off_l = p < e ? (unsigned)a.indx[p] * ldyb : SD_BUF_OOB;
+      const int64_t left = e - base;
+      const int cnt = left < 64 ? (int)left : 64;
+      for (int s = 0; s < cnt; s += G * U) {
+         sd_v4i_t yv[U][NCH];
+#pragma unroll
+         for (int u = 0; u < U; u++) {
+            const unsigned off = (unsigned)__shfl((int)off_l, (s + u * G + g) & 63);
+#pragma unroll
+            for (int j = 0; j < NCH; j++) {
+               const unsigned o = cbyte[j] >= SD_BUF_OOB ? SD_BUF_OOB : off + cbyte[j];
+               yv[u][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)o, 0, 0);
+            }
+         }
+#pragma unroll
+         for (int u = 0; u < U; u++) {
+            float d = 0.0f;
+#pragma unroll
+            for (int j = 0; j < NCH; j++)
+#pragma unroll
+               for (int v = 0; v < 4; v++) d = fmaf(__int_as_float(yv[u][j][v]), gv[j][v], d);
+#pragma unroll
+            for (int o = LPR / 2; o >= 1; o >>= 1) d += __shfl_xor(d, o);
+            const int ei = s + u * G + g;
+            if (lc == 0 && ei < cnt) a.dval[base + ei] = d * scale;
+         }
+      }
+   }
+}
+
+template <int LPR, int NCH>
+static int launch_sddmm_tasks(const SddmmTaskArgs &a, hipStream_t st) {
+   constexpr int WAVES = 4;
+   int64_t most = 0;
+   for (int x = 0; x < 8; x++) most = (a.lane_off[x + 1] - a.lane_off[x]) > most ? (a.lane_off[x + 1] - a.lane_off[x]) : most;
+   const int64_t gx = 8 * ((most + WAVES - 1) / WAVES);
+   if (gx > 0x7fffffffLL) return ISPLIB_FAIL;
+   if (gx == 0) return ISPLIB_SUCCESS;
+   hipLaunchKernelGGL((sddmm_task_kernel<LPR, NCH, WAVES>), dim3((unsigned)gx), dim3(WAVES * 64), 0, st, a);
+   return check_launch("sddmm_task_kernel");
+}
+
 template <int VEC, int LPR>
 static int launch_sddmm(const SddmmArgs &a, hipStream_t st) {
    constexpr int WAVES = 4;
@@ -180,4 +275,34 @@ extern "C" int isplib_sddmm_csr_hip(int64_t m, int64_t k, const int64_t *indx, c
    if (k <= 16) return launch_sddmm<1, 16>(a, st);
    if (k <= 32) return launch_sddmm<1, 32>(a, st);
    return launch_sddmm<1, 64>(a, st);
+}
+
+extern "C" int isplib_sddmm_csr_tasks_hip(int64_t m, int64_t n, int64_t k, const int64_t *indx, const int64_t *pntrb,
+                                          const int64_t *pntre, int64_t n_tasks, const int32_t *task_row,
+                                          const int64_t *task_b, const int32_t *task_len,
+                                          const int64_t *lane_off_host, const float *y, int64_t ldy, const float *g,
+                                          int64_t ldg, int mean, float *dval, void *stream) {
+   clear_error();
+   if (m < 0 || n < 0 || k < 0 || n_tasks < 0) return fail(ISPLIB_FAIL, "isplib_sddmm_csr_tasks_hip: negative dimension");
+   if (m == 0 || n_tasks == 0) return ISPLIB_SUCCESS;
+   if (k < 4 || k > 1024) return fail(ISPLIB_FAIL, "isplib_sddmm_csr_tasks_hip: 4 <= k <= 1024 required (use isplib_sddmm_csr_hip)");
+   const unsigned long long yb = (unsigned long long)n * (unsigned long long)ldy * 4ull;
+   if (yb > SD_BUF_LIMIT) return fail(ISPLIB_FAIL, "isplib_sddmm_csr_tasks_hip: dense operand larger than 3.5 GiB");
+   if (!indx || !pntrb || !pntre || !task_row || !task_b || !task_len || !lane_off_host || !y || !g || !dval)
+      return fail(ISPLIB_FAIL, "isplib_sddmm_csr_tasks_hip: null operand");
+   if (ldy < k || ldg < k) return fail(ISPLIB_FAIL, "isplib_sddmm_csr_tasks_hip: leading dimension smaller than k");
+   SddmmTaskArgs a;
+   a.k = k; a.indx = indx; a.pntrb = pntrb; a.pntre = pntre; a.y = y; a.ldy = ldy; a.ybytes = (unsigned)yb;
+   a.g = g; a.ldg = ldg; a.mean = mean ? 1 : 0; a.dval = dval;
+   a.task_row = task_row; a.task_b = task_b; a.task_len = task_len;
+   for (int x = 0; x < 9; x++) a.lane_off[x] = lane_off_host[x];
+   if (a.lane_off[0] != 0 || a.lane_off[8] != n_tasks) return fail(ISPLIB_FAIL, "isplib_sddmm_csr_tasks_hip: lane_off must run from 0 to n_tasks");
+   hipStream_t st = (hipStream_t)stream;
+   const int64_t w = (k + 3) / 4;
+   if (w <= 8) return launch_sddmm_tasks<8, 1>(a, st);
+   if (w <= 16) return launch_sddmm_tasks<16, 1>(a, st);
+   if (w <= 32) return launch_sddmm_tasks<32, 1>(a, st);
+   if (w <= 64) return launch_sddmm_tasks<64, 1>(a, st);
+   if (w <= 128) return launch_sddmm_tasks<64, 2>(a, st);
+   return launch_sddmm_tasks<64, 4>(a, st);
 }

@@ -158,12 +158,22 @@ Transposed build_transpose(const Tensor &rowptr, const Tensor &col, const Tensor
    return t;
 }
 
-Tensor sddmm(const Tensor &rowptr, const Tensor &col, const Tensor &mat, const Tensor &grad_out, bool mean) {
+Tensor sddmm(const Tensor &rowptr, const Tensor &col, const Tensor &mat, const Tensor &grad_out, bool mean,
+             const std::vector<Tensor> &plan = {}) {
    c10::DeviceGuard guard(mat.device());
    const Tensor g = grad_out.contiguous(), y = mat.contiguous();
-   const int64_t M = rowptr.numel() - 1, K = y.size(1);
+   const int64_t M = rowptr.numel() - 1, N = y.size(0), K = y.size(1);
    Tensor dval = at::empty({col.numel()}, y.options());
    const int64_t *rp = rowptr.data_ptr<int64_t>();
+   if (plan.size() == 5 && K >= 4 && K <= 1024 && (double)N * (double)K * 4.0 <= 3.5 * 1073741824.0) {
+      const int st = isplib_sddmm_csr_tasks_hip(M, N, K, col.data_ptr<int64_t>(), rp, rp + 1, plan[0].numel(),
+                                                plan[0].data_ptr<int32_t>(), plan[1].data_ptr<int64_t>(),
+                                                plan[2].data_ptr<int32_t>(), plan[4].data_ptr<int64_t>(),
+                                                y.data_ptr<float>(), K, g.data_ptr<float>(), K, mean ? 1 : 0,
+                                                dval.data_ptr<float>(), current_stream(y));
+      check_status(st, "isplib_sddmm_csr_tasks_hip");
+      return dval;
+   }
    const int st = isplib_sddmm_csr_hip(M, K, col.data_ptr<int64_t>(), rp, rp + 1, y.data_ptr<float>(), K,
                                        g.data_ptr<float>(), K, mean ? 1 : 0, dval.data_ptr<float>(), current_stream(y));
    check_status(st, "isplib_sddmm_csr_hip");
@@ -191,6 +201,7 @@ class SpmmSum : public torch::autograd::Function<SpmmSum> {
       const bool has_value = opt_value.has_value() && opt_value->defined();
       auto out = std::get<0>(spmm_fw(rowptr, col, opt_value, mat, R_SUM, plan));   // :244
       ctx->saved_data["plan_t"] = plan_t;
+      ctx->saved_data["plan"] = plan;
       ctx->saved_data["has_value"] = has_value;
       ctx->saved_data["value_edge"] = edge_of({present(opt_row), true, true});
       ctx->saved_data["mat_edge"] =
@@ -209,7 +220,7 @@ class SpmmSum : public torch::autograd::Function<SpmmSum> {
 
       auto grad_value = Variable();
       if (has_value && ctx->needs_input_grad(ctx->saved_data["value_edge"].toInt()))   // :269-272 (SDDMM, commented out there)
-         grad_value = sddmm(rowptr, col, mat, grad_out, false);
+         grad_value = sddmm(rowptr, col, mat, grad_out, false, ctx->saved_data["plan"].toTensorVector());
 
       auto grad_mat = Variable();
       if (ctx->needs_input_grad(ctx->saved_data["mat_edge"].toInt())) {
@@ -238,6 +249,7 @@ class SpmmMean : public torch::autograd::Function<SpmmMean> {
       const bool has_value = opt_value.has_value() && opt_value->defined();
       auto out = std::get<0>(spmm_fw(rowptr, col, opt_value, mat, R_MEAN, plan));   // :331
       ctx->saved_data["plan_t"] = plan_t;
+      ctx->saved_data["plan"] = plan;
       ctx->saved_data["has_value"] = has_value;
       ctx->saved_data["value_edge"] = edge_of({present(opt_row), true, true});
       ctx->saved_data["mat_edge"] = edge_of({present(opt_row), true, true, has_value, present(opt_rowcount),
@@ -257,7 +269,7 @@ class SpmmMean : public torch::autograd::Function<SpmmMean> {
 
       auto grad_value = Variable();
       if (has_value && ctx->needs_input_grad(ctx->saved_data["value_edge"].toInt()))
-         grad_value = sddmm(rowptr, col, mat, grad_out, true);   // :350-353
+         grad_value = sddmm(rowptr, col, mat, grad_out, true, ctx->saved_data["plan"].toTensorVector());   // :350-353
 
       auto grad_mat = Variable();
       if (ctx->needs_input_grad(ctx->saved_data["mat_edge"].toInt())) {

@@ -50,6 +50,11 @@ for k in (64, 128):
             res[f"{tag}/{red}/fwd+bwd_ms"] = timeit(fb)
         del adj
     res[f"k{k}/sddmm_ms"] = timeit(lambda: cabi.sddmm(rowptr, col, x, g))
+    from isplib_amd.plan import build_task_plan
+    from isplib_amd.plugin import suggest_slices
+    tp = build_task_plan(rowptr, col, n, suggest_slices(n, n, nnz, k))
+    res[f"k{k}/sddmm_tasks_ms"] = timeit(lambda: cabi.sddmm_tasks(rowptr, col, tp, x, g))
+    del tp
     out, arg = cabi.spmm(rowptr, col, w, x, "max")
     res[f"k{k}/minmax_bw_ms"] = timeit(lambda: cabi.spmm_minmax_bw(col, w, x, arg, g))
     del out, arg

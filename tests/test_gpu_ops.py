@@ -119,6 +119,35 @@ def test_sddmm_widths_and_hub(gpu, oracle_mod, k):
         assert np.max(np.abs(got.cpu().numpy() - ref)) <= 2e-6 * scale * max(1, k / 16)
 
 
+@pytest.mark.parametrize("k", (4, 41, 128, 300))
+def test_sddmm_over_task_plan(gpu, oracle_mod, k):
+    from isplib_amd import cabi
+    from isplib_amd.plan import build_task_plan
+    rowptr, col = cases.random_csr(200, 700, 25.0, seed=k, empty_rows=(0, 199), hub=(9, 6000))
+    x, g = cases.dense(700, k, 3), cases.dense(200, k, 5)
+    d = [_t(a, gpu) for a in (rowptr, col, x, g)]
+    for slices, chunk, short in ((8, 1024, 128), (16, 64, 0)):
+        plan = build_task_plan(d[0], d[1], 700, slices, chunk, short)
+        for mean in (False, True):
+            got = cabi.sddmm_tasks(d[0], d[1], plan, d[2], d[3], mean)
+            ref = oracle_mod.sddmm(rowptr, col, x, g, mean=mean)
+            scale = np.abs(ref).max() + 1e-6
+            assert np.max(np.abs(got.cpu().numpy() - ref)) <= 2e-6 * scale * max(1, k / 16)
+
+
+def test_value_gradient_through_planned_ops(gpu, oracle_mod, monkeypatch):
+    import isplib_amd
+    monkeypatch.setenv("ISPLIB_SLICES", "8")
+    rowptr, col = cases.random_csr(150, 150, 80.0, seed=23)
+    val, x, g = cases.weights(col.size, 4), cases.dense(150, 32, 3), cases.dense(150, 32, 5)
+    for red, mean in (("sum", False), ("mean", True)):
+        vs = _t(val, gpu).requires_grad_(True)
+        adj = isplib_amd.SparseTensor.from_csr(_t(rowptr, gpu), _t(col, gpu), vs, (150, 150))
+        xs = _t(x, gpu).requires_grad_(True)
+        isplib_amd.matmul(adj, xs, red).backward(_t(g, gpu))
+        _close(vs.grad, oracle_mod.sddmm(rowptr, col, x, g, mean=mean), rtol=1e-5, atol=1e-6)
+
+
 def test_minmax_backward_kernel(gpu, oracle_mod):
     from isplib_amd import cabi
     rowptr, col = cases.random_csr(90, 60, 8.0, seed=12, empty_rows=(1, 89), duplicates=True)
