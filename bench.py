@@ -48,6 +48,7 @@ def parse():
                    help="sliced: (row, slice) segment per wave; tasks: explicit task list (isplib_amd/plan.py)")
     p.add_argument("--chunk", type=int, default=1024, help="tasks: edges per task")
     p.add_argument("--short", type=int, default=128, help="tasks: rows shorter than this are not sliced")
+    p.add_argument("--tune", default="", help="debug: comma list of key=value for isplib_hip_tune")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-backward", action="store_true")
     return p.parse_args()
@@ -112,6 +113,9 @@ def main():
     x = synth.features(n, k, device=dev)
     val = synth.edge_weights(nnz, device=dev) if a.weighted else None
     msg = cabi.MESSAGE[a.reduce]
+    for kv in filter(None, a.tune.split(",")):
+        key, value = kv.split("=")
+        cabi.lib().isplib_hip_tune(int(key), int(value))
 
     if world == 1:
         l_rowptr, l_col, l_val, m_local, x_in = rowptr, col, val, n, x

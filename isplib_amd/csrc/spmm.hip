@@ -593,6 +593,7 @@ struct TaskArgs {
    const int *task_len;      // [n_tasks] edges (<= T)
    const int *seg_off;       // [slices*m + 1], lane-major (slice', row) -> first task of the segment
    int64_t lane_off[9];      // tasks of XCD lane x: [lane_off[x], lane_off[x+1])
+   int tpw;                  // tasks per wave (consecutive tasks of one lane)
    float *part_val;          // [n_tasks][k]
    int *part_idx;            // [n_tasks][k] row-relative edge ids (max/min)
 };
@@ -606,8 +607,9 @@ __global__ __launch_bounds__(WAVES * 64, (min_waves_of<OP, LPR, NCH, ADDR>())) v
    const int wave = threadIdx.x >> 6;
    const int g = lane / LPR, lc = lane % LPR;
    const unsigned xcd = blockIdx.x & 7u, within = blockIdx.x >> 3;
-   const int64_t t = a.lane_off[xcd] + (int64_t)within * WAVES + wave;
-   if (t >= a.lane_off[xcd + 1]) return;               // no barrier anywhere below
+   const int64_t t0 = a.lane_off[xcd] + ((int64_t)within * WAVES + wave) * a.tpw;
+   const int64_t t_end = (t0 + a.tpw) < a.lane_off[xcd + 1] ? (t0 + a.tpw) : a.lane_off[xcd + 1];
+   if (t0 >= t_end) return;                            // no barrier anywhere below
    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.y), 0, (int)a.ybytes, 0x00020000);
 
    int ccol[NCH], vfirst[NCH];
@@ -619,27 +621,29 @@ __global__ __launch_bounds__(WAVES * 64, (min_waves_of<OP, LPR, NCH, ADDR>())) v
       vfirst[j] = 0;
       if (cok[j] && ccol[j] + 4 > (int)a.k) { vfirst[j] = ccol[j] + 4 - (int)a.k; ccol[j] = (int)a.k - 4; }
    }
-   const int row = a.task_row[t];
-   const int64_t b = a.task_b[t], e = b + a.task_len[t];
-   const int64_t row_b = OP == OP_ADD ? b : a.pntrb[row];
-   float acc[NCH][VEC];
-   int bi[NCH][VEC];
+   for (int64_t t = t0; t < t_end; t++) {              // tpw consecutive tasks of this lane per wave
+      const int row = a.task_row[t];
+      const int64_t b = a.task_b[t], e = b + a.task_len[t];
+      const int64_t row_b = OP == OP_ADD ? b : a.pntrb[row];
+      float acc[NCH][VEC];
+      int bi[NCH][VEC];
 #pragma unroll
-   for (int j = 0; j < NCH; j++)
+      for (int j = 0; j < NCH; j++)
 #pragma unroll
-      for (int v = 0; v < VEC; v++) { acc[j][v] = identity<OP>(); bi[j][v] = INT_MAX; }
-   wave_edges_buf<OP, ADDR == 2, LPR, NCH, U>(a, rsrc, row_b, b, e, ccol, cok, acc, bi);
-   slot_reduce<OP, VEC, LPR, NCH>(acc, bi);
-   if (g == 0) {
-      const size_t off = (size_t)t * (size_t)a.k;
+         for (int v = 0; v < VEC; v++) { acc[j][v] = identity<OP>(); bi[j][v] = INT_MAX; }
+      wave_edges_buf<OP, ADDR == 2, LPR, NCH, U>(a, rsrc, row_b, b, e, ccol, cok, acc, bi);
+      slot_reduce<OP, VEC, LPR, NCH>(acc, bi);
+      if (g == 0) {
+         const size_t off = (size_t)t * (size_t)a.k;
 #pragma unroll
-      for (int j = 0; j < NCH; j++) {
-         if (!cok[j]) continue;
-         store_tail<VEC>(a.part_val + off + ccol[j], acc[j], vfirst[j]);
-         if (OP != OP_ADD) {
+         for (int j = 0; j < NCH; j++) {
+            if (!cok[j]) continue;
+            store_tail<VEC>(a.part_val + off + ccol[j], acc[j], vfirst[j]);
+            if (OP != OP_ADD) {
 #pragma unroll
-            for (int v = 0; v < VEC; v++)
-               if (v >= vfirst[j]) a.part_idx[off + ccol[j] + v] = bi[j][v];
+               for (int v = 0; v < VEC; v++)
+                  if (v >= vfirst[j]) a.part_idx[off + ccol[j] + v] = bi[j][v];
+            }
          }
       }
    }
@@ -705,7 +709,7 @@ static int launch_tasks_cfg(const TaskArgs &a, hipStream_t st) {
    constexpr int WAVES = 4;
    int64_t most = 0;
    for (int x = 0; x < 8; x++) most = (a.lane_off[x + 1] - a.lane_off[x]) > most ? (a.lane_off[x + 1] - a.lane_off[x]) : most;
-   const int64_t gx = 8 * ((most + WAVES - 1) / WAVES);
+   const int64_t gx = 8 * ((most + (int64_t)WAVES * a.tpw - 1) / ((int64_t)WAVES * a.tpw));
    if (gx > 0x7fffffffLL) return ISPLIB_FAIL;
    constexpr int PANEL = LPR * 4 * NCH;
    const unsigned ny = (unsigned)((a.k + PANEL - 1) / PANEL);
@@ -798,6 +802,7 @@ static int launch_addr(const SpmmArgs &a0, hipStream_t st) {
 
 int g_force_lpr = 0;   // tuning knob (isplib_hip_tune): lanes per row slot, 0 = by K
 int g_addr_mode = 1;   // tuning knob: 0 = always 64-bit addressing, 1 = buffer descriptors when they fit
+int g_tasks_per_wave = 1;   // tuning knob: consecutive tasks handled by one wave of the task kernel
 
 template <int OP, int VEC>
 static int launch_vec(const SpmmArgs &a, hipStream_t st) {
@@ -967,6 +972,7 @@ extern "C" int fusedMM_csr_tasks_hip(int32_t imessage, int64_t m, int64_t n, int
    if (a.lane_off[0] != 0 || a.lane_off[8] != n_tasks) return fail(ISPLIB_FAIL, "fusedMM_csr_tasks_hip: lane_off must run from 0 to n_tasks");
    for (int x = 0; x < 8; x++)
       if (a.lane_off[x + 1] < a.lane_off[x]) return fail(ISPLIB_FAIL, "fusedMM_csr_tasks_hip: lane_off must be non-decreasing");
+   a.tpw = g_tasks_per_wave > 0 ? g_tasks_per_wave : 1;
    a.part_val = (float *)workspace;
    const size_t plane = ((size_t)n_tasks * (size_t)k * sizeof(float) + 255) & ~(size_t)255;
    a.part_idx = aop == ISPLIB_AOP_ADD ? nullptr : (int *)((char *)workspace + plane);
@@ -979,6 +985,7 @@ extern "C" int fusedMM_csr_tasks_hip(int32_t imessage, int64_t m, int64_t n, int
 extern "C" int isplib_hip_tune(int key, int value) {
    if (key == 0) { g_force_lpr = value; return ISPLIB_SUCCESS; }
    if (key == 1) { g_addr_mode = value; return ISPLIB_SUCCESS; }
+   if (key == 2) { g_tasks_per_wave = value; return ISPLIB_SUCCESS; }
    return ISPLIB_FAIL;
 }
 

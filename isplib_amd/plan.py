@@ -46,6 +46,8 @@ def build_task_plan(rowptr: torch.Tensor, col: torch.Tensor, ncols: int, slices:
     assert slices >= 8 and slices % 8 == 0
     m = rowptr.numel() - 1
     dev = col.device
+    if m * slices + col.numel() // chunk + 1 >= 2 ** 31:        # task ids and seg_off are int32
+        return None
     table, ok = cabi.spmm_slices(rowptr, col, ncols, slices)
     if not ok:
         return None

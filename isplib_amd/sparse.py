@@ -111,7 +111,10 @@ class SparseStorage:
             return []
         if n_slices not in cache:
             from .plan import build_task_plan
-            p = build_task_plan(rowptr, col, ncols, n_slices)
+            try:
+                p = build_task_plan(rowptr, col, ncols, n_slices)
+            except RuntimeError:          # e.g. a graph too large for int32 task ids: plain kernel
+                p = None
             cache[n_slices] = [] if p is None else [p.task_row, p.task_b, p.task_len, p.seg_off,
                                                     torch.tensor(p.lane_off, dtype=torch.int64)]
         return cache[n_slices]
