@@ -152,3 +152,55 @@ class RowPartition:
         cabi.fusedMM_csr_sliced_phase_hip(*common, first + q, s - first - q, True, buf.data_ptr(), self.ncols_padded, k,
                                           buf.stride(0), out, arg, work)
         return out
+
+
+class _DistSpMM(torch.autograd.Function):
+    """out[R_p] = A[R_p, :] @ allgather(X);  dX[R_p] = A^T[R_p, :] @ allgather(dY)  (csrc/fusedmm.cpp:285)."""
+
+    @staticmethod
+    def forward(ctx, x_local, graph):
+        ctx.graph = graph
+        return graph.fwd.spmm_auto(x_local)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return ctx.graph.bwd.spmm_auto(grad_out.contiguous()), None
+
+
+class DistGraph:
+    """This rank's rows of A and of A^T (same row boundaries) for full-batch GNN training on one node:
+    `matmul(x_local)` is the sum-aggregation of the 1-D row-partitioned graph with autograd; every call
+    is ONE all-gather + the local SpMM, forward and backward alike.  Dense layer weights are replicated
+    by the caller and their gradients all-reduced (outside the SpMM path)."""
+
+    def __init__(self, rowptr, col, val, n, rank, world, group=None):
+        from . import cabi
+        self.fwd = RowPartition(rowptr, col, val, n, rank, world, group=group)
+        colptr, _, row_t, val_t = cabi.csr2csc(rowptr, col, val, n, want_perm=False, want_val=val is not None)
+        self.bwd = RowPartition(colptr, row_t, val_t, n, rank, world, cuts=self.fwd.row_cuts, group=group)
+        self.row0, self.rows = self.fwd.row0, self.fwd.rows
+
+    def matmul(self, x_local: torch.Tensor) -> torch.Tensor:
+        return _DistSpMM.apply(x_local, self)
+
+
+def _spmm_auto(self, x_local: torch.Tensor) -> torch.Tensor:
+    """Sum-SpMM of this partition on unpadded local rows [x_rows, K]: pads into the shard pitch, picks the
+    overlapped sliced schedule when the slice rule asks for slices, else gather + plain kernel."""
+    k = x_local.size(1)
+    cache = self.__dict__.setdefault("_auto", {})
+    if k not in cache:
+        cache[k] = (self.plan(k, "sum"), self.gather_buffer(k, x_local.device),
+                    torch.zeros((self.max_rows, k), dtype=torch.float32, device=x_local.device))
+    plan, buf, shard = cache[k]
+    shard[: self.x_rows].copy_(x_local)
+    out = torch.empty((self.rows, k), dtype=torch.float32, device=x_local.device)
+    if plan is not None:
+        return self.spmm_overlapped(shard, buf, out, plan, "sum")
+    from . import cabi
+    self.all_gather(shard, buf)
+    cabi.fusedMM_csr_hip(cabi.MSG_SPMM_SUM, self.rowptr, self.col_padded, self.val, buf, out)
+    return out
+
+
+RowPartition.spmm_auto = _spmm_auto

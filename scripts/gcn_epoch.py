@@ -51,18 +51,38 @@ def main():
     p.add_argument("--classes", type=int, default=41)
     a = p.parse_args()
     torch.manual_seed(0)                                    # tests/cpu/gcn-sparse.py:10-12
-    dev = torch.device("cuda:0")
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    backend = os.environ.get("ISPLIB_BENCH_BACKEND", "nccl")
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device("cuda", local if backend == "nccl" else local % max(torch.cuda.device_count(), 1))
+    torch.cuda.set_device(dev)
+    import torch.distributed as dist
+    if world > 1:       # torchrun --nproc-per-node N scripts/gcn_epoch.py: 1-D row partition, one process per GPU
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
     import isplib_amd
     from isplib_amd import synth
     rowptr, col, n = synth.dataset_like("reddit", device=dev, scale=a.scale)
-    adj_t = isplib_amd.SparseTensor.from_csr(rowptr, col, None, (n, n), validate=False)
+    nnz = col.numel()
     x = synth.features(n, a.features, device=dev)
     y = torch.randint(0, a.classes, (n,), device=dev)
     train_mask = torch.rand(n, device=dev) < 0.66
-    model = Net(a.features, a.hidden, a.classes).to(dev)
+    n_train = int(train_mask.sum())
+    model = Net(a.features, a.hidden, a.classes).to(dev)    # same seed on every rank: replicated weights
     opt = torch.optim.Adam(model.parameters(), lr=0.01, weight_decay=5e-4)
-    isplib_amd.iSpLibPlugin.patch_pyg()
-    matmul = isplib_amd.matmul
+    if world > 1:
+        from isplib_amd.dist import DistGraph
+        adj_t = DistGraph(rowptr, col, None, n, rank, world)
+        r0, r1 = adj_t.row0, adj_t.row0 + adj_t.rows
+        x, y, train_mask = x[r0:r1].contiguous(), y[r0:r1], train_mask[r0:r1]
+        del rowptr, col
+
+        def matmul(g, m, reduce):
+            return g.matmul(m)
+    else:
+        adj_t = isplib_amd.SparseTensor.from_csr(rowptr, col, None, (n, n), validate=False)
+        isplib_amd.iSpLibPlugin.patch_pyg()
+        matmul = isplib_amd.matmul
     times, losses = [], []
     for epoch in range(a.epochs + 1):                       # epoch 0 builds the per-graph operands; not timed
         torch.cuda.synchronize()
@@ -70,20 +90,37 @@ def main():
         model.train()
         opt.zero_grad()
         out = model(x, adj_t, matmul)
-        loss = F.nll_loss(out[train_mask], y[train_mask])
+        loss = F.nll_loss(out[train_mask], y[train_mask], reduction="sum") / n_train
         loss.backward()
+        if world > 1:                                       # replicated dense weights: sum the shard gradients
+            for prm in model.parameters():
+                dist.all_reduce(prm.grad)
+            dist.all_reduce(loss.detach_())
         opt.step()
         pred = model(x, adj_t, matmul).argmax(1)            # second forward, as at :89
-        acc = float((pred[train_mask] == y[train_mask]).float().mean())
+        hit = (pred[train_mask] == y[train_mask]).float().sum()
+        if world > 1:
+            dist.all_reduce(hit)
+        acc = float(hit) / n_train
         torch.cuda.synchronize()
         if epoch:
             times.append(time.perf_counter() - t0)
             losses.append(float(loss.detach()))
-    isplib_amd.iSpLibPlugin.unpatch_pyg()
-    print(json.dumps({"workload": f"2-layer GCN {a.features}->{a.hidden}->{a.classes}, reddit-like N={n} nnz={col.numel()}",
-                      "epochs": a.epochs, "epoch_ms_mean": statistics.mean(times) * 1e3,
-                      "epoch_ms_std": statistics.pstdev(times) * 1e3, "first_loss": losses[0], "last_loss": losses[-1],
-                      "train_acc": acc, "spmm_calls_per_epoch": 6}))
+    if world == 1:
+        isplib_amd.iSpLibPlugin.unpatch_pyg()
+    if world > 1:
+        t = torch.tensor([statistics.mean(times)], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        times = [float(t)] * len(times)
+    if rank == 0:
+        print(json.dumps({"workload": f"2-layer GCN {a.features}->{a.hidden}->{a.classes}, reddit-like N={n} nnz={nnz}",
+                          "epochs": a.epochs, "epoch_ms_mean": statistics.mean(times) * 1e3,
+                          "epoch_ms_std": statistics.pstdev(times) * 1e3, "first_loss": losses[0],
+                          "last_loss": losses[-1], "train_acc": acc, "spmm_calls_per_epoch": 6, "n_gpus": world,
+                          "backend": backend if world > 1 else None}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
