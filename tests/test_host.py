@@ -227,3 +227,32 @@ def test_nnz_balanced_cuts():
     assert cuts[0] == 0 and cuts[-1] == 1000 and cuts == sorted(cuts)
     per = [int(rowptr[cuts[i + 1]] - rowptr[cuts[i]]) for i in range(4)]
     assert max(per) - min(per) <= 5000 + 60
+
+
+def test_task_entry_argument_validation_without_gpu():
+    """fusedMM_csr_tasks_hip / plan builders: every rejection that is decided before a HIP call."""
+    import ctypes
+    from isplib_amd import cabi
+    L = cabi.lib()
+    lane = (ctypes.c_int64 * 9)(*([0] * 9))
+    one = ctypes.c_void_p(8)      # never dereferenced: validation fails first
+
+    def call(msg=cabi.MSG_SPMM_SUM, m=4, n=4, k=8, n_tasks=0, slices=8, ws=None, ws_bytes=0, lane_off=lane):
+        return L.fusedMM_csr_tasks_hip(msg, m, n, k, 0, None, one, one, one, n_tasks, one, one, one, one, slices, lane_off,
+                                       one, k, one, k, None, ws, ws_bytes, None)
+    assert call(msg=0x11103) == cabi.NO_OPT_IMPL
+    assert call(slices=12) == cabi.FAIL and "multiple of 8" in cabi.last_error()
+    assert call(k=3) == cabi.FAIL and "k >= 4" in cabi.last_error()
+    assert call(n=1 << 30, k=8) == cabi.FAIL and "3.5 GiB" in cabi.last_error()
+    assert call() == cabi.NOT_ENOUGH_MEM
+    assert call(m=0) == cabi.SUCCESS
+    bad = (ctypes.c_int64 * 9)(0, 0, 0, 0, 0, 0, 0, 0, 5)
+    assert call(ws=ctypes.c_void_p(256), ws_bytes=1 << 20, lane_off=bad) == cabi.FAIL and "lane_off" in cabi.last_error()
+    info = cabi.TaskPlanInfo()
+    assert L.isplib_spmm_tasks_count_hip(4, one, one, one, 12, 1024, 128, one, one, 1 << 20, ctypes.byref(info), None) == cabi.FAIL
+    assert L.isplib_spmm_tasks_count_hip(4, one, one, one, 8, 8, 128, one, one, 1 << 20, ctypes.byref(info), None) == cabi.FAIL
+    assert L.isplib_spmm_tasks_workspace_bytes(cabi.MSG_SPMM_MAX, 10, 16) >= 2 * 10 * 16 * 4
+    assert L.isplib_spmm_slices_build_hip(4, 4, 0, one, one, None, 9, one, None, None) == cabi.FAIL
+    assert L.fusedMM_csr_sliced_phase_hip(cabi.MSG_SPMM_SUM, 4, 4, 8, 0, None, one, one, one, one, 8, 6, 4, 1, one, 8, one, 8,
+                                          None, ctypes.c_void_p(256), 1 << 20, None) == cabi.FAIL
+    assert "slice range" in cabi.last_error()
