@@ -803,6 +803,7 @@ static int launch_addr(const SpmmArgs &a0, hipStream_t st) {
 int g_force_lpr = 0;   // tuning knob (isplib_hip_tune): lanes per row slot, 0 = by K
 int g_addr_mode = 1;   // tuning knob: 0 = always 64-bit addressing, 1 = buffer descriptors when they fit
 int g_tasks_per_wave = 1;   // tuning knob: consecutive tasks handled by one wave of the task kernel
+int g_panel_cols = 128;     // column-panel width of the task schedule for wide K (isplib_hip_tune(4, w); 0 = one pass)
 
 template <int OP, int VEC>
 static int launch_vec(const SpmmArgs &a, hipStream_t st) {
@@ -977,15 +978,37 @@ extern "C" int fusedMM_csr_tasks_hip(int32_t imessage, int64_t m, int64_t n, int
    const size_t plane = ((size_t)n_tasks * (size_t)k * sizeof(float) + 255) & ~(size_t)255;
    a.part_idx = aop == ISPLIB_AOP_ADD ? nullptr : (int *)((char *)workspace + plane);
    hipStream_t st = (hipStream_t)stream;
-   if (aop == ISPLIB_AOP_ADD) return val ? launch_tasks_op<OP_ADD, 2>(a, st) : launch_tasks_op<OP_ADD, 1>(a, st);
-   if (aop == ISPLIB_AOP_MAX) return val ? launch_tasks_op<OP_MAX, 2>(a, st) : launch_tasks_op<OP_MAX, 1>(a, st);
-   return val ? launch_tasks_op<OP_MIN, 2>(a, st) : launch_tasks_op<OP_MIN, 1>(a, st);
+   // Wide feature matrices are swept in column panels of g_panel_cols floats, one complete pass
+   // (task kernel + combine) per panel on the same stream: a panel of y is n*panel*4 bytes, which stays
+   // inside the 256 MiB Infinity Cache when the whole y does not, and every pass runs at the efficiency of
+   // the well-filled K = panel case.  Panels only change which columns a launch touches, never a result.
+   const int64_t pw = (g_panel_cols >= 4 && k >= g_panel_cols + g_panel_cols / 2) ? (int64_t)(g_panel_cols / 4 * 4) : k;
+   for (int64_t c0 = 0; c0 < k; c0 += pw) {
+      TaskArgs p = a;
+      p.k = (k - c0) < pw ? (k - c0) : pw;
+      if (p.k < 4) {                              // a sliver of 1-3 columns: widen it backwards (overlap is rewritten identically)
+         p.k = 4;
+         c0 = k - 4;
+      }
+      p.y = y + c0;
+      p.z = z + c0;
+      p.z_arg = z_arg ? z_arg + c0 : nullptr;
+      p.ybytes = (unsigned)(yb - (unsigned long long)c0 * 4ull);
+      int rc;
+      if (aop == ISPLIB_AOP_ADD) rc = val ? launch_tasks_op<OP_ADD, 2>(p, st) : launch_tasks_op<OP_ADD, 1>(p, st);
+      else if (aop == ISPLIB_AOP_MAX) rc = val ? launch_tasks_op<OP_MAX, 2>(p, st) : launch_tasks_op<OP_MAX, 1>(p, st);
+      else rc = val ? launch_tasks_op<OP_MIN, 2>(p, st) : launch_tasks_op<OP_MIN, 1>(p, st);
+      if (rc) return rc;
+      if (c0 + p.k >= k) break;
+   }
+   return ISPLIB_SUCCESS;
 }
 
 extern "C" int isplib_hip_tune(int key, int value) {
    if (key == 0) { g_force_lpr = value; return ISPLIB_SUCCESS; }
    if (key == 1) { g_addr_mode = value; return ISPLIB_SUCCESS; }
    if (key == 2) { g_tasks_per_wave = value; return ISPLIB_SUCCESS; }
+   if (key == 4) { g_panel_cols = value; return ISPLIB_SUCCESS; }
    return ISPLIB_FAIL;
 }
 

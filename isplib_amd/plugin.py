@@ -90,11 +90,13 @@ def suggest_slices(m: int, n: int, nnz: int, k: int, minmax: bool = False) -> in
     Two measured constraints on MI355X (task-list schedule): a slice of the dense
     operand should be about 8 MB (2x an XCD's 4 MiB L2: the hot rows stay resident) and a row must keep
     ~20 edges per slice or per-task overhead and the partial rows eat the gain.  Reddit-shaped graph
-    (mean degree 492): K=32 -> 8, K=64 -> 8, K=128 -> 16, K=256 -> 24 (same optimum for max/min);
+    (mean degree 492): K=32 -> 8, K=64 -> 8, K=128 and wider (128-column panels) -> 16, same for max/min;
     ogbn-products-shaped (mean degree 50) -> 0; anything whose dense operand is under 16 MB -> 0."""
     del minmax
     if m <= 0 or n <= 0:
         return 0
+    if k >= 192:          # the task entry sweeps wide K in 128-column panels: each pass is a K = 128 problem
+        k = 128
     by_cache = (n * k * 4) / float(8 << 20)
     avg_deg = nnz / m
     if by_cache < 2.0 or avg_deg < 64:
