@@ -1,32 +1,23 @@
-// spmm.hip -- SpMM (sum / mean / max / min) forward for gfx950 (MI355X, CDNA4).
+// spmm.hip -- SpMM (sum / mean / max / min) forward for gfx950 (MI355X, CDNA4): the plain and the
+// column-sliced schedules, and the entry points fusedMM_csr_hip / fusedMM_csr_sliced{,_phase}_hip.
 //
-// Replaces the body behind fusedMM_csr (reference csrc/fusedMM.h:77-99, called
-// at csrc/fusedmm.cpp:198) for device-resident operands.  Written for wave64.
+// Replaces the body behind fusedMM_csr (reference csrc/fusedMM.h:77-99, called at csrc/fusedmm.cpp:198)
+// for device-resident operands.  Written for wave64.  The gather loop itself lives in gather.h; the
+// task-list schedule (the default fast path) in spmm_tasks.hip.
 //
-// Mapping
-//   * one CSR row -> one wavefront; WAVES rows -> one workgroup.
-//   * the 64 lanes of a wave are split into G = 64/LPR edge slots of LPR lanes.
-//     A slot reads one dense row y[indx[j], :] per step, each lane VEC
-//     contiguous floats (VEC = 4 -> one global_load_dwordx4, 16 B/lane), so one
-//     wave-instruction moves G whole feature rows, coalesced along K.
-//     K = 128 fp32: LPR = 32, G = 2 -> two 512-B rows per 1-KiB instruction.
-//   * edge metadata (indx, val) for 64 edges is read with one coalesced load
-//     per wave and handed to the slots with ds_bpermute (__shfl); U steps are
-//     issued back to back so U*NCH gathers (up to 8 KiB per wave) are in flight.
-//   * rows longer than LONG_ROW are processed by all WAVES waves of the
-//     workgroup together (contiguous edge chunks, fixed-order LDS combine), so
-//     a hub row never serialises on one wave.  No atomics anywhere: results
-//     are bitwise reproducible run to run.
-//   * max/min carry (value, row-relative edge id) pairs; the comparator
-//     "strictly better value, else lower edge id" makes the result independent
-//     of the slot/wave split and identical to a sequential first-wins scan.
-//   * blockIdx is remapped so that each XCD (blocks b, b+8, ... share one)
-//     walks a contiguous range of rows: neighbouring rows of a real graph share
-//     neighbours, and then share that XCD's 4 MiB L2.  Speed only.
+// Mapping of this file's kernel (spmm_csr_kernel)
+//   * plain : one CSR row -> one wavefront, WAVES rows -> one workgroup; blockIdx is remapped so that each
+//     XCD (blocks b, b+8, ... share one) walks a contiguous range of rows (neighbouring rows of a real graph
+//     share neighbours, and then share that XCD's 4 MiB L2).  Speed only.
+//   * sliced: one (row, column-slice) segment -> one wavefront; each XCD walks ALL rows of its own slice(s),
+//     so its L2 only ever sees a fraction of the rows of y; per-slice partials go to a workspace and
+//     combine_slices_kernel folds them in slice order.
+//   * rows / segments longer than long_row edges are processed by all WAVES waves of the workgroup together
+//     (contiguous edge chunks, fixed-order LDS combine), so a hub row never serialises on one wave.
+//   * no atomics anywhere: results are bitwise reproducible run to run; max/min carry (value, row-relative
+//     edge id) pairs whose comparator makes the result independent of the slot / wave / slice split.
 //
-// Roofline: HBM-bound gather.  Algorithmic bytes per edge (reference dtypes):
-// 12 B streamed (int64 index + fp32 value) + amortised dense traffic; the
-// gather itself (4K B/edge) is served by L2 / Infinity Cache when y fits.
+// Roofline: gather-bound (L1->L2 request rate when sliced, Infinity-Cache rate when not); see DESIGN.md 5.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <float.h>
@@ -34,10 +25,9 @@
 
 #include "../../include/isplib_hip.h"
 #include "common.h"
+#include "gather.h"
 
 namespace isplib {
-
-enum { OP_ADD = 0, OP_MAX = 1, OP_MIN = 2 };
 
 struct SpmmArgs {
    int64_t m, k, nnz;
@@ -62,229 +52,6 @@ struct SpmmArgs {
    float *part_val;        // [slices][m][k] partial results
    int *part_idx;          // [slices][m][k] row-relative edge ids (max/min), INT_MAX = none
 };
-
-template <int VEC> __device__ __forceinline__ void load_vec(const float *p, float (&r)[VEC]);
-template <> __device__ __forceinline__ void load_vec<4>(const float *p, float (&r)[4]) {
-   const float4 t = *reinterpret_cast<const float4 *>(p);
-   r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
-}
-template <> __device__ __forceinline__ void load_vec<2>(const float *p, float (&r)[2]) {
-   const float2 t = *reinterpret_cast<const float2 *>(p);
-   r[0] = t.x; r[1] = t.y;
-}
-template <> __device__ __forceinline__ void load_vec<1>(const float *p, float (&r)[1]) { r[0] = *p; }
-
-template <int VEC> __device__ __forceinline__ void store_vec(float *p, const float (&r)[VEC]);
-template <> __device__ __forceinline__ void store_vec<4>(float *p, const float (&r)[4]) {
-   *reinterpret_cast<float4 *>(p) = make_float4(r[0], r[1], r[2], r[3]);
-}
-template <> __device__ __forceinline__ void store_vec<2>(float *p, const float (&r)[2]) {
-   *reinterpret_cast<float2 *>(p) = make_float2(r[0], r[1]);
-}
-template <> __device__ __forceinline__ void store_vec<1>(float *p, const float (&r)[1]) { *p = r[0]; }
-
-// 16-byte store that may sit on any 4-byte boundary (ragged K); vfirst leading components belong to
-// the neighbouring lane (the last vector of a row is shifted back to end at column k) and are skipped
-struct __attribute__((packed, aligned(4))) f4u_t { float x, y, z, w; };
-template <int VEC> __device__ __forceinline__ void store_tail(float *p, const float (&r)[VEC], int vfirst) {
-   if (VEC == 4) {
-      if (vfirst == 0 && ((uintptr_t)p & 15) == 0) {
-         store_vec<VEC>(p, r);
-      } else if (vfirst == 0) {
-         f4u_t t; t.x = r[0]; t.y = r[1]; t.z = r[2]; t.w = r[VEC - 1];
-         *reinterpret_cast<f4u_t *>(p) = t;
-      } else {
-#pragma unroll
-         for (int v = 1; v < VEC; v++) if (v >= vfirst) p[v] = r[v];
-      }
-   } else {
-      store_vec<VEC>(p, r);
-   }
-}
-
-// (value, edge id) comparator: does candidate (t, i) replace (bt, bi)?
-template <int OP> __device__ __forceinline__ bool better(float t, int i, float bt, int bi) {
-   if (OP == OP_MAX) return (t > bt) || (t == bt && i < bi);
-   return (t < bt) || (t == bt && i < bi);
-}
-
-template <int OP> __device__ __forceinline__ float identity() {
-   return OP == OP_ADD ? 0.0f : (OP == OP_MAX ? -FLT_MAX : FLT_MAX);
-}
-
-// One wave walks edges [rb, re) of a row that starts at CSR position row_b.
-// acc: running sum (OP_ADD) or running best value; bi: row-relative edge id of
-// the best (OP_MAX/MIN), INT_MAX = none yet.
-template <int OP, int VEC, int LPR, int NCH, int U>
-__device__ __forceinline__ void wave_edges(const SpmmArgs &a, int64_t row_b, int64_t rb, int64_t re,
-                                           const int (&ccol)[NCH], const bool (&cok)[NCH],
-                                           float (&acc)[NCH][VEC], int (&bi)[NCH][VEC]) {
-   constexpr int G = 64 / LPR;
-   const int lane = threadIdx.x & 63;
-   const int g = lane / LPR;
-   for (int64_t base = rb; base < re; base += 64) {
-      const int64_t p = base + lane;
-      int c_l = 0;
-      float v_l = 0.0f;
-      if (p < re) {
-         c_l = (int)a.indx[p];
-         v_l = a.val ? a.val[p] : 1.0f;
-      }
-      const int64_t left = re - base;
-      const int cnt = left < 64 ? (int)left : 64;
-      const int rel0 = (int)(base - row_b);
-      for (int s = 0; s < cnt; s += G * U) {
-         float t[U][NCH][VEC];
-         float vv[U];
-         bool ok[U];
-#pragma unroll
-         for (int u = 0; u < U; u++) {
-            const int ei = s + u * G + g;
-            ok[u] = ei < cnt;
-            const int cc = __shfl(c_l, ei & 63);
-            vv[u] = __shfl(v_l, ei & 63);
-            const float *yr = a.y + (size_t)cc * (size_t)a.ldy;
-#pragma unroll
-            for (int j = 0; j < NCH; j++) {
-               if (ok[u] && cok[j]) {
-                  load_vec<VEC>(yr + ccol[j], t[u][j]);
-               } else {
-#pragma unroll
-                  for (int v = 0; v < VEC; v++) t[u][j][v] = 0.0f;
-               }
-            }
-         }
-#pragma unroll
-         for (int u = 0; u < U; u++) {
-            const int ei = s + u * G + g;
-#pragma unroll
-            for (int j = 0; j < NCH; j++) {
-#pragma unroll
-               for (int v = 0; v < VEC; v++) {
-                  if (OP == OP_ADD) {
-                     acc[j][v] = ok[u] ? fmaf(vv[u], t[u][j][v], acc[j][v]) : acc[j][v];
-                  } else {
-                     const float tt = vv[u] * t[u][j][v];
-                     const bool win = ok[u] && cok[j] && (OP == OP_MAX ? tt > acc[j][v] : tt < acc[j][v]);
-                     acc[j][v] = win ? tt : acc[j][v];
-                     bi[j][v] = win ? rel0 + ei : bi[j][v];
-                  }
-               }
-            }
-         }
-      }
-   }
-}
-
-// Fast form of wave_edges for 16-B lanes when the whole dense operand is addressable with a
-// 32-bit byte offset (n*ldy*4 <= BUF_LIMIT): y is read through a buffer descriptor, so
-//   * the row offset is ONE 32-bit multiply per edge, done before the cross-lane hand-off
-//     (64 edges per coalesced metadata load), and one add per gather;
-//   * out-of-range lanes carry an offset past the descriptor's size: the hardware range
-//     check returns 0 for them, so the loop has no branches and no exec-mask flips;
-//   * HAS_VAL = false (unit weights) never touches the value stream and adds instead of fma.
-constexpr unsigned BUF_LIMIT = 0xE0000000u;   // bytes addressable; offsets >= BUF_OOB read as 0
-constexpr unsigned BUF_OOB = 0xF0000000u;     // + any column offset (< 2^24) stays < 2^32: never wraps
-
-typedef __attribute__((__vector_size__(4 * sizeof(int)))) int v4i_t;
-
-// UU gathers per slot issued back to back for the edges [s, s + G*UU) of the current 64-edge batch
-template <int OP, bool HAS_VAL, int LPR, int NCH, int UU>
-__device__ __forceinline__ void buf_step(const __amdgpu_buffer_rsrc_t rsrc, unsigned off_l, float v_l, int s, int cnt,
-                                         int rel0, int g, const unsigned (&cbyte)[NCH], const unsigned (&poison)[NCH],
-                                         const bool (&cok)[NCH], float (&acc)[NCH][4], int (&bi)[NCH][4]) {
-   constexpr int G = 64 / LPR;
-   v4i_t t[UU][NCH];
-   float vv[UU];
-#pragma unroll
-   for (int u = 0; u < UU; u++) {
-      const int ei = (s + u * G + g) & 63;
-      const unsigned off = (unsigned)__shfl((int)off_l, ei);
-      if (HAS_VAL) vv[u] = __shfl(v_l, ei);
-#pragma unroll
-      for (int j = 0; j < NCH; j++) {
-         // masked edge: off = BUF_OOB, + cbyte (< 2^24) cannot wrap; masked column: OR-ed past the limit
-         const unsigned o = (off + cbyte[j]) | poison[j];
-         t[u][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)o, 0, 0);
-      }
-   }
-#pragma unroll
-   for (int u = 0; u < UU; u++) {
-      const int ei = s + u * G + g;
-#pragma unroll
-      for (int j = 0; j < NCH; j++) {
-#pragma unroll
-         for (int v = 0; v < 4; v++) {
-            const float x = __int_as_float(t[u][j][v]);
-            if (OP == OP_ADD) {
-               acc[j][v] = HAS_VAL ? fmaf(vv[u], x, acc[j][v]) : acc[j][v] + x;
-            } else {
-               const float tt = HAS_VAL ? vv[u] * x : x;
-               const bool win = (ei < cnt) && cok[j] && (OP == OP_MAX ? tt > acc[j][v] : tt < acc[j][v]);
-               acc[j][v] = win ? tt : acc[j][v];
-               bi[j][v] = win ? rel0 + ei : bi[j][v];
-            }
-         }
-      }
-   }
-}
-
-template <int OP, bool HAS_VAL, int LPR, int NCH, int U, class Args>
-__device__ __forceinline__ void wave_edges_buf(const Args &a, const __amdgpu_buffer_rsrc_t rsrc, int64_t row_b,
-                                               int64_t rb, int64_t re, const int (&ccol)[NCH], const bool (&cok)[NCH],
-                                               float (&acc)[NCH][4], int (&bi)[NCH][4]) {
-   constexpr int G = 64 / LPR;
-   constexpr int UT = U >= 4 ? 2 : 1;   // tail granularity: fewer all-masked gathers on short segments
-   const int lane = threadIdx.x & 63;
-   const int g = lane / LPR;
-   const unsigned ldyb = (unsigned)a.ldy * 4u;
-   unsigned cbyte[NCH], poison[NCH];   // lanes whose columns lie beyond k read past the descriptor too
-#pragma unroll
-   for (int j = 0; j < NCH; j++) {
-      cbyte[j] = (unsigned)ccol[j] * 4u;
-      poison[j] = cok[j] ? 0u : BUF_OOB;
-   }
-   for (int64_t base = rb; base < re; base += 64) {
-      const int64_t p = base + lane;
-      unsigned off_l = BUF_OOB;
-      float v_l = 0.0f;
-      if (p < re) {
-         off_l = (unsigned)a.indx[p] * ldyb;
-         if (HAS_VAL) v_l = a.val[p];
-      }
-      const int64_t left = re - base;
-      const int cnt = left < 64 ? (int)left : 64;
-      const int rel0 = (int)(base - row_b);
-      int s = 0;
-      for (; s + G * U <= cnt; s += G * U)
-         buf_step<OP, HAS_VAL, LPR, NCH, U>(rsrc, off_l, v_l, s, cnt, rel0, g, cbyte, poison, cok, acc, bi);
-      for (; s < cnt; s += G * UT)
-         buf_step<OP, HAS_VAL, LPR, NCH, UT>(rsrc, off_l, v_l, s, cnt, rel0, g, cbyte, poison, cok, acc, bi);
-   }
-}
-
-// butterfly over the G edge slots of a wave; every lane ends with the result
-template <int OP, int VEC, int LPR, int NCH>
-__device__ __forceinline__ void slot_reduce(float (&acc)[NCH][VEC], int (&bi)[NCH][VEC]) {
-#pragma unroll
-   for (int off = LPR; off < 64; off <<= 1) {
-#pragma unroll
-      for (int j = 0; j < NCH; j++) {
-#pragma unroll
-         for (int v = 0; v < VEC; v++) {
-            const float ot = __shfl_xor(acc[j][v], off);
-            if (OP == OP_ADD) {
-               acc[j][v] += ot;
-            } else {
-               const int oi = __shfl_xor(bi[j][v], off);
-               const bool take = better<OP>(ot, oi, acc[j][v], bi[j][v]);
-               acc[j][v] = take ? ot : acc[j][v];
-               bi[j][v] = take ? oi : bi[j][v];
-            }
-         }
-      }
-   }
-}
 
 template <int OP, int VEC, int NCH>
 __device__ __forceinline__ void write_row(const SpmmArgs &a, int64_t row, int64_t row_b, int64_t deg,
@@ -334,21 +101,6 @@ __device__ __forceinline__ void write_partial(const SpmmArgs &a, int slice, int6
             if (v >= vfirst[j]) a.part_idx[off + ccol[j] + v] = bi[j][v];
       }
    }
-}
-
-// gathers issued back to back per slot (U) and the occupancy the register allocator is held to; both
-// measured on MI355X: the unit-weight sum kernel fits 8 waves/SIMD at U = 8 (62 VGPRs), the weighted
-// one needs U = 6 for 7, and max/min carry (value, id) pairs, so U = 4 keeps them at 8.
-template <int OP, int NCH, int ADDR> constexpr int unroll_of() {
-   if (NCH > 1) return (8 / NCH) > 2 ? 8 / NCH : 2;
-   if (ADDR != 0 && OP != OP_ADD) return 4;
-   if (ADDR == 2) return 6;
-   return 8;
-}
-template <int OP, int LPR, int NCH, int ADDR> constexpr int min_waves_of() {
-   if (NCH != 1 || ADDR == 0) return 1;
-   if (OP != OP_ADD) return 8;
-   return (ADDR == 1 && LPR >= 16) ? 8 : 7;
 }
 
 // ADDR: 0 = 64-bit addresses (any size, any VEC); 1 / 2 = buffer descriptor, unit weights / weighted (VEC = 4)
@@ -566,184 +318,6 @@ __global__ __launch_bounds__(256) void combine_slices_kernel(const SpmmArgs a) {
    }
 }
 
-// ---- task-list schedule -------------------------------------------------------------------
-// The per-graph plan (isplib_spmm_tasks_* / isplib_amd/plan.py) cuts every non-empty (row, column
-// slice) segment into chunks of at most T edges; a chunk is a TASK = one wave.  Tasks are stored
-// grouped by XCD lane (slices x, x+8, ... belong to lane x = blockIdx % 8), so the L2 affinity of
-// the sliced kernel is kept while
-//   * hub rows become many independent tasks (no 4-wave cooperative phase, no LDS, no barrier),
-//   * empty segments cost nothing (no wave, no partial plane to write and re-read),
-//   * short rows are not sliced at all (their whole row is one task on lane row % 8).
-// Task t writes partial[t][0:k]; combine_tasks_kernel folds a row's partials in slice order, then
-// chunk order (= ascending CSR position), so results stay bitwise reproducible and max/min ties
-// still go to the lowest edge id.
-struct TaskArgs {
-   int64_t m, k, nnz;
-   const float *val;
-   const int64_t *indx, *pntrb, *pntre;
-   const float *y;
-   int64_t ldy;
-   unsigned ybytes;
-   float *z;
-   int64_t ldz;
-   int64_t *z_arg;
-   int mean, slices;
-   const int *task_row;      // [n_tasks]
-   const int64_t *task_b;    // [n_tasks] first CSR position
-   const int *task_len;      // [n_tasks] edges (<= T)
-   const int *seg_off;       // [slices*m + 1], lane-major (slice', row) -> first task of the segment
-   int64_t lane_off[9];      // tasks of XCD lane x: [lane_off[x], lane_off[x+1])
-   int tpw;                  // tasks per wave (consecutive tasks of one lane)
-   float *part_val;          // [n_tasks][k]
-   int *part_idx;            // [n_tasks][k] row-relative edge ids (max/min)
-};
-
-template <int OP, int LPR, int NCH, int WAVES, int ADDR>
-__global__ __launch_bounds__(WAVES * 64, (min_waves_of<OP, LPR, NCH, ADDR>())) void spmm_task_kernel(const TaskArgs a) {
-   constexpr int VEC = 4;
-   constexpr int U = unroll_of<OP, NCH, ADDR>();
-   constexpr int PANEL = LPR * VEC * NCH;
-   const int lane = threadIdx.x & 63;
-   const int wave = threadIdx.x >> 6;
-   const int g = lane / LPR, lc = lane % LPR;
-   const unsigned xcd = blockIdx.x & 7u, within = blockIdx.x >> 3;
-   const int64_t t0 = a.lane_off[xcd] + ((int64_t)within * WAVES + wave) * a.tpw;
-   const int64_t t_end = (t0 + a.tpw) < a.lane_off[xcd + 1] ? (t0 + a.tpw) : a.lane_off[xcd + 1];
-   if (t0 >= t_end) return;                            // no barrier anywhere below
-   __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.y), 0, (int)a.ybytes, 0x00020000);
-
-   int ccol[NCH], vfirst[NCH];
-   bool cok[NCH];
-#pragma unroll
-   for (int j = 0; j < NCH; j++) {
-      ccol[j] = (int)blockIdx.y * PANEL + (j * LPR + lc) * VEC;
-      cok[j] = ccol[j] < a.k;
-      vfirst[j] = 0;
-      if (cok[j] && ccol[j] + 4 > (int)a.k) { vfirst[j] = ccol[j] + 4 - (int)a.k; ccol[j] = (int)a.k - 4; }
-   }
-   for (int64_t t = t0; t < t_end; t++) {              // tpw consecutive tasks of this lane per wave
-      const int row = a.task_row[t];
-      const int64_t b = a.task_b[t], e = b + a.task_len[t];
-      const int64_t row_b = OP == OP_ADD ? b : a.pntrb[row];
-      float acc[NCH][VEC];
-      int bi[NCH][VEC];
-#pragma unroll
-      for (int j = 0; j < NCH; j++)
-#pragma unroll
-         for (int v = 0; v < VEC; v++) { acc[j][v] = identity<OP>(); bi[j][v] = INT_MAX; }
-      wave_edges_buf<OP, ADDR == 2, LPR, NCH, U>(a, rsrc, row_b, b, e, ccol, cok, acc, bi);
-      slot_reduce<OP, VEC, LPR, NCH>(acc, bi);
-      if (g == 0) {
-         const size_t off = (size_t)t * (size_t)a.k;
-#pragma unroll
-         for (int j = 0; j < NCH; j++) {
-            if (!cok[j]) continue;
-            store_tail<VEC>(a.part_val + off + ccol[j], acc[j], vfirst[j]);
-            if (OP != OP_ADD) {
-#pragma unroll
-               for (int v = 0; v < VEC; v++)
-                  if (v >= vfirst[j]) a.part_idx[off + ccol[j] + v] = bi[j][v];
-            }
-         }
-      }
-   }
-}
-
-template <int OP, int VEC>
-__global__ __launch_bounds__(256) void combine_tasks_kernel(const TaskArgs a) {
-   const int64_t kv = a.k / VEC;
-   const int64_t total = a.m * kv;
-   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-   const int per_lane = a.slices / 8;
-   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-      const int64_t row = i / kv;
-      const int c = (int)(i - row * kv) * VEC;
-      float acc[VEC];
-      int bi[VEC];
-#pragma unroll
-      for (int v = 0; v < VEC; v++) { acc[v] = identity<OP>(); bi[v] = INT_MAX; }
-      for (int s = 0; s < a.slices; s++) {                 // natural slice order = ascending CSR position
-         const int sp = (s & 7) * per_lane + (s >> 3);      // where the plan stored slice s
-         const int *so = a.seg_off + (size_t)sp * (size_t)a.m + row;
-         const int t1 = so[1];
-         for (int t = so[0]; t < t1; t++) {
-            const size_t off = (size_t)t * (size_t)a.k + c;
-            float p[VEC];
-            load_vec<VEC>(a.part_val + off, p);
-#pragma unroll
-            for (int v = 0; v < VEC; v++) {
-               if (OP == OP_ADD) {
-                  acc[v] += p[v];
-               } else {
-                  const int oi = a.part_idx[off + v];
-                  const bool take = better<OP>(p[v], oi, acc[v], bi[v]);
-                  acc[v] = take ? p[v] : acc[v];
-                  bi[v] = take ? oi : bi[v];
-               }
-            }
-         }
-      }
-      const int64_t rb = a.pntrb[row];
-      const int64_t deg = a.pntre[row] - rb;
-      if (OP == OP_ADD) {
-         if (a.mean) {
-            const float d = (float)(deg > 1 ? deg : 1);
-#pragma unroll
-            for (int v = 0; v < VEC; v++) acc[v] = acc[v] / d;
-         }
-      } else if (deg <= 0) {
-#pragma unroll
-         for (int v = 0; v < VEC; v++) acc[v] = 0.0f;
-      }
-      store_vec<VEC>(a.z + (size_t)row * (size_t)a.ldz + c, acc);
-      if (OP != OP_ADD && a.z_arg) {
-         int64_t *ar = a.z_arg + (size_t)row * (size_t)a.ldz + c;
-#pragma unroll
-         for (int v = 0; v < VEC; v++) ar[v] = bi[v] == INT_MAX ? a.nnz : rb + (int64_t)bi[v];
-      }
-   }
-}
-
-template <int OP, int LPR, int NCH, int ADDR>
-static int launch_tasks_cfg(const TaskArgs &a, hipStream_t st) {
-   constexpr int WAVES = 4;
-   int64_t most = 0;
-   for (int x = 0; x < 8; x++) most = (a.lane_off[x + 1] - a.lane_off[x]) > most ? (a.lane_off[x + 1] - a.lane_off[x]) : most;
-   const int64_t gx = 8 * ((most + (int64_t)WAVES * a.tpw - 1) / ((int64_t)WAVES * a.tpw));
-   if (gx > 0x7fffffffLL) return ISPLIB_FAIL;
-   constexpr int PANEL = LPR * 4 * NCH;
-   const unsigned ny = (unsigned)((a.k + PANEL - 1) / PANEL);
-   if (gx > 0) {
-      hipLaunchKernelGGL((spmm_task_kernel<OP, LPR, NCH, WAVES, ADDR>), dim3((unsigned)gx, ny, 1), dim3(WAVES * 64), 0, st, a);
-      const int rc = check_launch("spmm_task_kernel");
-      if (rc) return rc;
-   }
-   const uintptr_t al = (uintptr_t)a.z;
-   int64_t blocks;
-   if (a.k % 4 == 0 && a.ldz % 4 == 0 && (al & 15) == 0) {
-      blocks = (a.m * (a.k / 4) + 255) / 256; if (blocks > 8192) blocks = 8192;
-      hipLaunchKernelGGL((combine_tasks_kernel<OP, 4>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-   } else if (a.k % 2 == 0 && a.ldz % 2 == 0 && (al & 7) == 0) {
-      blocks = (a.m * (a.k / 2) + 255) / 256; if (blocks > 8192) blocks = 8192;
-      hipLaunchKernelGGL((combine_tasks_kernel<OP, 2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-   } else {
-      blocks = (a.m * a.k + 255) / 256; if (blocks > 8192) blocks = 8192;
-      hipLaunchKernelGGL((combine_tasks_kernel<OP, 1>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-   }
-   return check_launch("combine_tasks_kernel");
-}
-
-template <int OP, int ADDR>
-static int launch_tasks_op(const TaskArgs &a, hipStream_t st) {
-   const int64_t width = (a.k + 3) / 4;
-   if (width <= 8) return launch_tasks_cfg<OP, 8, 1, ADDR>(a, st);
-   if (width <= 16) return launch_tasks_cfg<OP, 16, 1, ADDR>(a, st);
-   if (width <= 32) return launch_tasks_cfg<OP, 32, 1, ADDR>(a, st);
-   if (width <= 64) return launch_tasks_cfg<OP, 64, 1, ADDR>(a, st);
-   if (width <= 128) return launch_tasks_cfg<OP, 64, 2, ADDR>(a, st);
-   return launch_tasks_cfg<OP, 64, 4, ADDR>(a, st);
-}
-
 __global__ void dummy_kernel(int64_t flag) { (void)flag; }
 
 template <int OP, int VEC, int LPR, int NCH, int ADDR>
@@ -930,79 +504,6 @@ extern "C" int fusedMM_csr_sliced_phase_hip(int32_t imessage, int64_t m, int64_t
                      slice_first, slice_count, combine, workspace, workspace_bytes, stream);
 }
 
-
-extern "C" size_t isplib_spmm_tasks_workspace_bytes(int32_t imessage, int64_t n_tasks, int64_t k) {
-   if (n_tasks <= 0 || k <= 0) return 256;
-   const size_t plane = ((size_t)n_tasks * (size_t)k * sizeof(float) + 255) & ~(size_t)255;
-   return plane * (((imessage & 0xF0000) != ISPLIB_AOP_ADD) ? 2 : 1);
-}
-
-extern "C" int fusedMM_csr_tasks_hip(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t nnz, const float *val,
-                                     const int64_t *indx, const int64_t *pntrb, const int64_t *pntre,
-                                     int64_t n_tasks, const int32_t *task_row, const int64_t *task_b,
-                                     const int32_t *task_len, const int32_t *seg_off, int slices,
-                                     const int64_t *lane_off_host, const float *y, int64_t ldy, float *z,
-                                     int64_t ldz, int64_t *z_arg, void *workspace, size_t workspace_bytes,
-                                     void *stream) {
-   clear_error();
-   const int32_t vop = imessage & 0xF, rop = imessage & 0xF0, sop = imessage & 0xF00, vsc = imessage & 0xF000,
-                 aop = imessage & 0xF0000;
-   if (vop != ISPLIB_VOP_COPY_RHS || rop != ISPLIB_ROP_NOOP || sop != ISPLIB_SOP_COPY ||
-       (vsc != ISPLIB_VSC_MUL && vsc != ISPLIB_VSC_MEAN) ||
-       (aop != ISPLIB_AOP_ADD && aop != ISPLIB_AOP_MAX && aop != ISPLIB_AOP_MIN) ||
-       (vsc == ISPLIB_VSC_MEAN && aop != ISPLIB_AOP_ADD))
-      return fail(ISPLIB_NO_OPT_IMPL, "fusedMM_csr_tasks_hip: message outside the SpMM set");
-   if (m < 0 || n < 0 || k < 0 || nnz < 0 || n_tasks < 0) return fail(ISPLIB_FAIL, "fusedMM_csr_tasks_hip: negative dimension");
-   if (m == 0 || k == 0) return ISPLIB_SUCCESS;
-   if (slices < 8 || slices % 8 != 0) return fail(ISPLIB_FAIL, "fusedMM_csr_tasks_hip: slices must be a positive multiple of 8");
-   if (k < 4) return fail(ISPLIB_FAIL, "fusedMM_csr_tasks_hip: k >= 4 required (use fusedMM_csr_hip)");
-   if (ldy < k || ldz < k) return fail(ISPLIB_FAIL, "fusedMM_csr_tasks_hip: leading dimension smaller than k");
-   const unsigned long long yb = (unsigned long long)n * (unsigned long long)ldy * 4ull;
-   if (yb > BUF_LIMIT) return fail(ISPLIB_FAIL, "fusedMM_csr_tasks_hip: dense operand larger than 3.5 GiB (use fusedMM_csr_hip)");
-   if (!pntrb || !pntre || !z || !seg_off || !lane_off_host || (n_tasks > 0 && (!task_row || !task_b || !task_len || !indx || !y)))
-      return fail(ISPLIB_FAIL, "fusedMM_csr_tasks_hip: null operand");
-   const size_t need = isplib_spmm_tasks_workspace_bytes(imessage, n_tasks, k);
-   if (!workspace || workspace_bytes < need) return fail(ISPLIB_NOT_ENOUGH_MEM, "fusedMM_csr_tasks_hip: workspace too small");
-   if (((uintptr_t)workspace & 255) != 0) return fail(ISPLIB_FAIL, "fusedMM_csr_tasks_hip: workspace must be 256-byte aligned");
-   TaskArgs a;
-   a.m = m; a.k = k; a.nnz = nnz; a.val = val; a.indx = indx; a.pntrb = pntrb; a.pntre = pntre;
-   a.y = y; a.ldy = ldy; a.ybytes = (unsigned)yb; a.z = z; a.ldz = ldz; a.z_arg = z_arg;
-   a.mean = (vsc == ISPLIB_VSC_MEAN) ? 1 : 0; a.slices = slices;
-   a.task_row = task_row; a.task_b = task_b; a.task_len = task_len; a.seg_off = seg_off;
-   for (int x = 0; x < 9; x++) a.lane_off[x] = lane_off_host[x];
-   if (a.lane_off[0] != 0 || a.lane_off[8] != n_tasks) return fail(ISPLIB_FAIL, "fusedMM_csr_tasks_hip: lane_off must run from 0 to n_tasks");
-   for (int x = 0; x < 8; x++)
-      if (a.lane_off[x + 1] < a.lane_off[x]) return fail(ISPLIB_FAIL, "fusedMM_csr_tasks_hip: lane_off must be non-decreasing");
-   a.tpw = g_tasks_per_wave > 0 ? g_tasks_per_wave : 1;
-   a.part_val = (float *)workspace;
-   const size_t plane = ((size_t)n_tasks * (size_t)k * sizeof(float) + 255) & ~(size_t)255;
-   a.part_idx = aop == ISPLIB_AOP_ADD ? nullptr : (int *)((char *)workspace + plane);
-   hipStream_t st = (hipStream_t)stream;
-   // Wide feature matrices are swept in column panels of g_panel_cols floats, one complete pass
-   // (task kernel + combine) per panel on the same stream: a panel of y is n*panel*4 bytes, which stays
-   // inside the 256 MiB Infinity Cache when the whole y does not, and every pass runs at the efficiency of
-   // the well-filled K = panel case.  Panels only change which columns a launch touches, never a result.
-   const int64_t pw = (g_panel_cols >= 4 && k >= g_panel_cols + g_panel_cols / 2) ? (int64_t)(g_panel_cols / 4 * 4) : k;
-   for (int64_t c0 = 0; c0 < k; c0 += pw) {
-      TaskArgs p = a;
-      p.k = (k - c0) < pw ? (k - c0) : pw;
-      if (p.k < 4) {                              // a sliver of 1-3 columns: widen it backwards (overlap is rewritten identically)
-         p.k = 4;
-         c0 = k - 4;
-      }
-      p.y = y + c0;
-      p.z = z + c0;
-      p.z_arg = z_arg ? z_arg + c0 : nullptr;
-      p.ybytes = (unsigned)(yb - (unsigned long long)c0 * 4ull);
-      int rc;
-      if (aop == ISPLIB_AOP_ADD) rc = val ? launch_tasks_op<OP_ADD, 2>(p, st) : launch_tasks_op<OP_ADD, 1>(p, st);
-      else if (aop == ISPLIB_AOP_MAX) rc = val ? launch_tasks_op<OP_MAX, 2>(p, st) : launch_tasks_op<OP_MAX, 1>(p, st);
-      else rc = val ? launch_tasks_op<OP_MIN, 2>(p, st) : launch_tasks_op<OP_MIN, 1>(p, st);
-      if (rc) return rc;
-      if (c0 + p.k >= k) break;
-   }
-   return ISPLIB_SUCCESS;
-}
 
 extern "C" int isplib_hip_tune(int key, int value) {
    if (key == 0) { g_force_lpr = value; return ISPLIB_SUCCESS; }

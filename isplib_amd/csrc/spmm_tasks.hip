@@ -1,0 +1,267 @@
+// spmm_tasks.hip -- the task-list schedule of the SpMM (fusedMM_csr_tasks_hip): see include/isplib_hip.h and
+// DESIGN.md 4.2.  Shares the gather loop (gather.h) with the plain and column-sliced kernels of spmm.hip.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <float.h>
+#include <limits.h>
+
+#include "../../include/isplib_hip.h"
+#include "common.h"
+#include "gather.h"
+
+namespace isplib {
+
+// ---- task-list schedule -------------------------------------------------------------------
+// The per-graph plan (isplib_spmm_tasks_* / isplib_amd/plan.py) cuts every non-empty (row, column
+// slice) segment into chunks of at most T edges; a chunk is a TASK = one wave.  Tasks are stored
+// grouped by XCD lane (slices x, x+8, ... belong to lane x = blockIdx % 8), so the L2 affinity of
+// the sliced kernel is kept while
+//   * hub rows become many independent tasks (no 4-wave cooperative phase, no LDS, no barrier),
+//   * empty segments cost nothing (no wave, no partial plane to write and re-read),
+//   * short rows are not sliced at all (their whole row is one task on lane row % 8).
+// Task t writes partial[t][0:k]; combine_tasks_kernel folds a row's partials in slice order, then
+// chunk order (= ascending CSR position), so results stay bitwise reproducible and max/min ties
+// still go to the lowest edge id.
+struct TaskArgs {
+   int64_t m, k, nnz;
+   const float *val;
+   const int64_t *indx, *pntrb, *pntre;
+   const float *y;
+   int64_t ldy;
+   unsigned ybytes;
+   float *z;
+   int64_t ldz;
+   int64_t *z_arg;
+   int mean, slices;
+   const int *task_row;      // [n_tasks]
+   const int64_t *task_b;    // [n_tasks] first CSR position
+   const int *task_len;      // [n_tasks] edges (<= T)
+   const int *seg_off;       // [slices*m + 1], lane-major (slice', row) -> first task of the segment
+   int64_t lane_off[9];      // tasks of XCD lane x: [lane_off[x], lane_off[x+1])
+   int tpw;                  // tasks per wave (consecutive tasks of one lane)
+   float *part_val;          // [n_tasks][k]
+   int *part_idx;            // [n_tasks][k] row-relative edge ids (max/min)
+};
+
+template <int OP, int LPR, int NCH, int WAVES, int ADDR>
+__global__ __launch_bounds__(WAVES * 64, (min_waves_of<OP, LPR, NCH, ADDR>())) void spmm_task_kernel(const TaskArgs a) {
+   constexpr int VEC = 4;
+   constexpr int U = unroll_of<OP, NCH, ADDR>();
+   constexpr int PANEL = LPR * VEC * NCH;
+   const int lane = threadIdx.x & 63;
+   const int wave = threadIdx.x >> 6;
+   const int g = lane / LPR, lc = lane % LPR;
+   const unsigned xcd = blockIdx.x & 7u, within = blockIdx.x >> 3;
+   const int64_t t0 = a.lane_off[xcd] + ((int64_t)within * WAVES + wave) * a.tpw;
+   const int64_t t_end = (t0 + a.tpw) < a.lane_off[xcd + 1] ? (t0 + a.tpw) : a.lane_off[xcd + 1];
+   if (t0 >= t_end) return;                            // no barrier anywhere below
+   __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.y), 0, (int)a.ybytes, 0x00020000);
+
+   int ccol[NCH], vfirst[NCH];
+   bool cok[NCH];
+#pragma unroll
+   for (int j = 0; j < NCH; j++) {
+      ccol[j] = (int)blockIdx.y * PANEL + (j * LPR + lc) * VEC;
+      cok[j] = ccol[j] < a.k;
+      vfirst[j] = 0;
+      if (cok[j] && ccol[j] + 4 > (int)a.k) { vfirst[j] = ccol[j] + 4 - (int)a.k; ccol[j] = (int)a.k - 4; }
+   }
+   for (int64_t t = t0; t < t_end; t++) {              // tpw consecutive tasks of this lane per wave
+      const int row = a.task_row[t];
+      const int64_t b = a.task_b[t], e = b + a.task_len[t];
+      const int64_t row_b = OP == OP_ADD ? b : a.pntrb[row];
+      float acc[NCH][VEC];
+      int bi[NCH][VEC];
+#pragma unroll
+      for (int j = 0; j < NCH; j++)
+#pragma unroll
+         for (int v = 0; v < VEC; v++) { acc[j][v] = identity<OP>(); bi[j][v] = INT_MAX; }
+      wave_edges_buf<OP, ADDR == 2, LPR, NCH, U>(a, rsrc, row_b, b, e, ccol, cok, acc, bi);
+      slot_reduce<OP, VEC, LPR, NCH>(acc, bi);
+      if (g == 0) {
+         const size_t off = (size_t)t * (size_t)a.k;
+#pragma unroll
+         for (int j = 0; j < NCH; j++) {
+            if (!cok[j]) continue;
+            store_tail<VEC>(a.part_val + off + ccol[j], acc[j], vfirst[j]);
+            if (OP != OP_ADD) {
+#pragma unroll
+               for (int v = 0; v < VEC; v++)
+                  if (v >= vfirst[j]) a.part_idx[off + ccol[j] + v] = bi[j][v];
+            }
+         }
+      }
+   }
+}
+
+template <int OP, int VEC>
+__global__ __launch_bounds__(256) void combine_tasks_kernel(const TaskArgs a) {
+   const int64_t kv = a.k / VEC;
+   const int64_t total = a.m * kv;
+   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+   const int per_lane = a.slices / 8;
+   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+      const int64_t row = i / kv;
+      const int c = (int)(i - row * kv) * VEC;
+      float acc[VEC];
+      int bi[VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; v++) { acc[v] = identity<OP>(); bi[v] = INT_MAX; }
+      for (int s = 0; s < a.slices; s++) {                 // natural slice order = ascending CSR position
+         const int sp = (s & 7) * per_lane + (s >> 3);      // where the plan stored slice s
+         const int *so = a.seg_off + (size_t)sp * (size_t)a.m + row;
+         const int t1 = so[1];
+         for (int t = so[0]; t < t1; t++) {
+            const size_t off = (size_t)t * (size_t)a.k + c;
+            float p[VEC];
+            load_vec<VEC>(a.part_val + off, p);
+#pragma unroll
+            for (int v = 0; v < VEC; v++) {
+               if (OP == OP_ADD) {
+                  acc[v] += p[v];
+               } else {
+                  const int oi = a.part_idx[off + v];
+                  const bool take = better<OP>(p[v], oi, acc[v], bi[v]);
+                  acc[v] = take ? p[v] : acc[v];
+                  bi[v] = take ? oi : bi[v];
+               }
+            }
+         }
+      }
+      const int64_t rb = a.pntrb[row];
+      const int64_t deg = a.pntre[row] - rb;
+      if (OP == OP_ADD) {
+         if (a.mean) {
+            const float d = (float)(deg > 1 ? deg : 1);
+#pragma unroll
+            for (int v = 0; v < VEC; v++) acc[v] = acc[v] / d;
+         }
+      } else if (deg <= 0) {
+#pragma unroll
+         for (int v = 0; v < VEC; v++) acc[v] = 0.0f;
+      }
+      store_vec<VEC>(a.z + (size_t)row * (size_t)a.ldz + c, acc);
+      if (OP != OP_ADD && a.z_arg) {
+         int64_t *ar = a.z_arg + (size_t)row * (size_t)a.ldz + c;
+#pragma unroll
+         for (int v = 0; v < VEC; v++) ar[v] = bi[v] == INT_MAX ? a.nnz : rb + (int64_t)bi[v];
+      }
+   }
+}
+
+template <int OP, int LPR, int NCH, int ADDR>
+static int launch_tasks_cfg(const TaskArgs &a, hipStream_t st) {
+   constexpr int WAVES = 4;
+   int64_t most = 0;
+   for (int x = 0; x < 8; x++) most = (a.lane_off[x + 1] - a.lane_off[x]) > most ? (a.lane_off[x + 1] - a.lane_off[x]) : most;
+   const int64_t gx = 8 * ((most + (int64_t)WAVES * a.tpw - 1) / ((int64_t)WAVES * a.tpw));
+   if (gx > 0x7fffffffLL) return ISPLIB_FAIL;
+   constexpr int PANEL = LPR * 4 * NCH;
+   const unsigned ny = (unsigned)((a.k + PANEL - 1) / PANEL);
+   if (gx > 0) {
+      hipLaunchKernelGGL((spmm_task_kernel<OP, LPR, NCH, WAVES, ADDR>), dim3((unsigned)gx, ny, 1), dim3(WAVES * 64), 0, st, a);
+      const int rc = check_launch("spmm_task_kernel");
+      if (rc) return rc;
+   }
+   const uintptr_t al = (uintptr_t)a.z;
+   int64_t blocks;
+   if (a.k % 4 == 0 && a.ldz % 4 == 0 && (al & 15) == 0) {
+      blocks = (a.m * (a.k / 4) + 255) / 256; if (blocks > 8192) blocks = 8192;
+      hipLaunchKernelGGL((combine_tasks_kernel<OP, 4>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+   } else if (a.k % 2 == 0 && a.ldz % 2 == 0 && (al & 7) == 0) {
+      blocks = (a.m * (a.k / 2) + 255) / 256; if (blocks > 8192) blocks = 8192;
+      hipLaunchKernelGGL((combine_tasks_kernel<OP, 2>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+   } else {
+      blocks = (a.m * a.k + 255) / 256; if (blocks > 8192) blocks = 8192;
+      hipLaunchKernelGGL((combine_tasks_kernel<OP, 1>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+   }
+   return check_launch("combine_tasks_kernel");
+}
+
+template <int OP, int ADDR>
+static int launch_tasks_op(const TaskArgs &a, hipStream_t st) {
+   const int64_t width = (a.k + 3) / 4;
+   if (width <= 8) return launch_tasks_cfg<OP, 8, 1, ADDR>(a, st);
+   if (width <= 16) return launch_tasks_cfg<OP, 16, 1, ADDR>(a, st);
+   if (width <= 32) return launch_tasks_cfg<OP, 32, 1, ADDR>(a, st);
+   if (width <= 64) return launch_tasks_cfg<OP, 64, 1, ADDR>(a, st);
+   if (width <= 128) return launch_tasks_cfg<OP, 64, 2, ADDR>(a, st);
+   return launch_tasks_cfg<OP, 64, 4, ADDR>(a, st);
+}
+
+}  // namespace isplib
+
+using namespace isplib;
+
+extern "C" size_t isplib_spmm_tasks_workspace_bytes(int32_t imessage, int64_t n_tasks, int64_t k) {
+   if (n_tasks <= 0 || k <= 0) return 256;
+   const size_t plane = ((size_t)n_tasks * (size_t)k * sizeof(float) + 255) & ~(size_t)255;
+   return plane * (((imessage & 0xF0000) != ISPLIB_AOP_ADD) ? 2 : 1);
+}
+
+extern "C" int fusedMM_csr_tasks_hip(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t nnz, const float *val,
+                                     const int64_t *indx, const int64_t *pntrb, const int64_t *pntre,
+                                     int64_t n_tasks, const int32_t *task_row, const int64_t *task_b,
+                                     const int32_t *task_len, const int32_t *seg_off, int slices,
+                                     const int64_t *lane_off_host, const float *y, int64_t ldy, float *z,
+                                     int64_t ldz, int64_t *z_arg, void *workspace, size_t workspace_bytes,
+                                     void *stream) {
+   clear_error();
+   const int32_t vop = imessage & 0xF, rop = imessage & 0xF0, sop = imessage & 0xF00, vsc = imessage & 0xF000,
+                 aop = imessage & 0xF0000;
+   if (vop != ISPLIB_VOP_COPY_RHS || rop != ISPLIB_ROP_NOOP || sop != ISPLIB_SOP_COPY ||
+       (vsc != ISPLIB_VSC_MUL && vsc != ISPLIB_VSC_MEAN) ||
+       (aop != ISPLIB_AOP_ADD && aop != ISPLIB_AOP_MAX && aop != ISPLIB_AOP_MIN) ||
+       (vsc == ISPLIB_VSC_MEAN && aop != ISPLIB_AOP_ADD))
+      return fail(ISPLIB_NO_OPT_IMPL, "fusedMM_csr_tasks_hip: message outside the SpMM set");
+   if (m < 0 || n < 0 || k < 0 || nnz < 0 || n_tasks < 0) return fail(ISPLIB_FAIL, "fusedMM_csr_tasks_hip: negative dimension");
+   if (m == 0 || k == 0) return ISPLIB_SUCCESS;
+   if (slices < 8 || slices % 8 != 0) return fail(ISPLIB_FAIL, "fusedMM_csr_tasks_hip: slices must be a positive multiple of 8");
+   if (k < 4) return fail(ISPLIB_FAIL, "fusedMM_csr_tasks_hip: k >= 4 required (use fusedMM_csr_hip)");
+   if (ldy < k || ldz < k) return fail(ISPLIB_FAIL, "fusedMM_csr_tasks_hip: leading dimension smaller than k");
+   const unsigned long long yb = (unsigned long long)n * (unsigned long long)ldy * 4ull;
+   if (yb > BUF_LIMIT) return fail(ISPLIB_FAIL, "fusedMM_csr_tasks_hip: dense operand larger than 3.5 GiB (use fusedMM_csr_hip)");
+   if (!pntrb || !pntre || !z || !seg_off || !lane_off_host || (n_tasks > 0 && (!task_row || !task_b || !task_len || !indx || !y)))
+      return fail(ISPLIB_FAIL, "fusedMM_csr_tasks_hip: null operand");
+   const size_t need = isplib_spmm_tasks_workspace_bytes(imessage, n_tasks, k);
+   if (!workspace || workspace_bytes < need) return fail(ISPLIB_NOT_ENOUGH_MEM, "fusedMM_csr_tasks_hip: workspace too small");
+   if (((uintptr_t)workspace & 255) != 0) return fail(ISPLIB_FAIL, "fusedMM_csr_tasks_hip: workspace must be 256-byte aligned");
+   TaskArgs a;
+   a.m = m; a.k = k; a.nnz = nnz; a.val = val; a.indx = indx; a.pntrb = pntrb; a.pntre = pntre;
+   a.y = y; a.ldy = ldy; a.ybytes = (unsigned)yb; a.z = z; a.ldz = ldz; a.z_arg = z_arg;
+   a.mean = (vsc == ISPLIB_VSC_MEAN) ? 1 : 0; a.slices = slices;
+   a.task_row = task_row; a.task_b = task_b; a.task_len = task_len; a.seg_off = seg_off;
+   for (int x = 0; x < 9; x++) a.lane_off[x] = lane_off_host[x];
+   if (a.lane_off[0] != 0 || a.lane_off[8] != n_tasks) return fail(ISPLIB_FAIL, "fusedMM_csr_tasks_hip: lane_off must run from 0 to n_tasks");
+   for (int x = 0; x < 8; x++)
+      if (a.lane_off[x + 1] < a.lane_off[x]) return fail(ISPLIB_FAIL, "fusedMM_csr_tasks_hip: lane_off must be non-decreasing");
+   a.tpw = g_tasks_per_wave > 0 ? g_tasks_per_wave : 1;
+   a.part_val = (float *)workspace;
+   const size_t plane = ((size_t)n_tasks * (size_t)k * sizeof(float) + 255) & ~(size_t)255;
+   a.part_idx = aop == ISPLIB_AOP_ADD ? nullptr : (int *)((char *)workspace + plane);
+   hipStream_t st = (hipStream_t)stream;
+   // Wide feature matrices are swept in column panels of g_panel_cols floats, one complete pass
+   // (task kernel + combine) per panel on the same stream: a panel of y is n*panel*4 bytes, which stays
+   // inside the 256 MiB Infinity Cache when the whole y does not, and every pass runs at the efficiency of
+   // the well-filled K = panel case.  Panels only change which columns a launch touches, never a result.
+   const int64_t pw = (g_panel_cols >= 4 && k >= g_panel_cols + g_panel_cols / 2) ? (int64_t)(g_panel_cols / 4 * 4) : k;
+   for (int64_t c0 = 0; c0 < k; c0 += pw) {
+      TaskArgs p = a;
+      p.k = (k - c0) < pw ? (k - c0) : pw;
+      if (p.k < 4) {                              // a sliver of 1-3 columns: widen it backwards (overlap is rewritten identically)
+         p.k = 4;
+         c0 = k - 4;
+      }
+      p.y = y + c0;
+      p.z = z + c0;
+      p.z_arg = z_arg ? z_arg + c0 : nullptr;
+      p.ybytes = (unsigned)(yb - (unsigned long long)c0 * 4ull);
+      int rc;
+      if (aop == ISPLIB_AOP_ADD) rc = val ? launch_tasks_op<OP_ADD, 2>(p, st) : launch_tasks_op<OP_ADD, 1>(p, st);
+      else if (aop == ISPLIB_AOP_MAX) rc = val ? launch_tasks_op<OP_MAX, 2>(p, st) : launch_tasks_op<OP_MAX, 1>(p, st);
+      else rc = val ? launch_tasks_op<OP_MIN, 2>(p, st) : launch_tasks_op<OP_MIN, 1>(p, st);
+      if (rc) return rc;
+      if (c0 + p.k >= k) break;
+   }
+   return ISPLIB_SUCCESS;
+}
