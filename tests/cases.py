@@ -44,6 +44,8 @@ def dense(n, k, seed, kind="uniform"):
         x = rng.integers(-1, 2, (n, k)).astype(np.float32)
         x[x == 0] = np.where(rng.random(np.count_nonzero(x == 0)) < 0.5, np.float32(0.0), np.float32(-0.0))
         return x
+    if kind == "denormal":     # products and sums in the fp32 subnormal range: no flush-to-zero anywhere
+        return ((rng.random((n, k), np.float32) * 2 - 1) * np.float32(3e-38)).astype(np.float32)
     if kind == "nonfinite":
         x = (rng.random((n, k), np.float32) * 2 - 1).astype(np.float32)
         flat = x.reshape(-1)

@@ -67,7 +67,7 @@ def test_unit_weights_skip_value_stream(gpu, oracle_mod, k):
     _run_all(gpu, oracle_mod, rowptr, col, val, x, unit=True)
 
 
-@pytest.mark.parametrize("kind", ("integer", "constant", "signed_zero", "nonfinite"))
+@pytest.mark.parametrize("kind", ("integer", "constant", "signed_zero", "nonfinite", "denormal"))
 @pytest.mark.parametrize("k", (64, 100))
 def test_ties_and_nonfinite(gpu, oracle_mod, kind, k):
     rowptr, col = cases.random_csr(128, 96, 20.0, seed=5, empty_rows=(3,), duplicates=True)

@@ -47,11 +47,11 @@ def test_unsupported_message_returns_no_opt_impl(oracle_mod):
     assert oracle_mod.fusedMM_csr(0x23102, 3, 3, 3, val, col, rowptr, x, z) == 128   # MEAN with MAX
 
 
-@pytest.mark.parametrize("kind", ("uniform", "integer", "constant", "signed_zero", "nonfinite"))
+@pytest.mark.parametrize("kind", ("uniform", "integer", "constant", "signed_zero", "nonfinite", "denormal"))
 @pytest.mark.parametrize("red", cases.REDUCES)
 def test_c_oracle_equals_naive_scan(oracle_mod, red, kind):
     rowptr, col = cases.random_csr(60, 45, 7.0, seed=31, empty_rows=(0, 30, 59), duplicates=True)
-    val = cases.weights(col.size, 4, "signed_int" if kind in ("integer", "signed_zero", "nonfinite") else "uniform")
+    val = cases.weights(col.size, 4, "signed_int" if kind in ("integer", "signed_zero", "nonfinite", "denormal") else "uniform")
     x = cases.dense(45, 19, 3, kind)
     out, arg = oracle_mod.spmm_fw(rowptr, col, val, x, red)
     out2, arg2 = oracle_mod.scan_spmm(rowptr, col, val, x, red)
