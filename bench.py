@@ -151,13 +151,14 @@ def main():
         work = cabi.sliced_workspace(a.reduce, m_local, k, a.slices, dev)
 
     tplan = twork = None
-    if world == 1 and a.schedule == "tasks" and a.slices > 0:
+    if a.schedule == "tasks" and a.slices > 0:
         from isplib_amd.plan import build_task_plan
         tplan = build_task_plan(l_rowptr, l_col, x_in.size(0), a.slices, a.chunk, a.short)
         twork = tplan.workspace(a.reduce, k)
+    use_tasks = tplan is not None and world == 1      # N > 1: decided by a short measurement below
 
     def spmm(rp, cl, vl, tb, xin, o, ar, tp=None):
-        tp = tplan if (tp is None and rp is l_rowptr) else tp
+        tp = tplan if (tp is None and rp is l_rowptr and use_tasks) else tp
         if tp is not None:
             cabi.fusedMM_csr_tasks_hip(msg, rp, cl, vl, tp, xin, o, ar, twork)
         elif tb is not None:
@@ -185,6 +186,36 @@ def main():
         overlap = bool(flag.item())
         if not overlap and rank == 0:
             print("[bench] overlapped schedule disabled (mismatch or error); using gather-then-SpMM", file=sys.stderr)
+
+    # N > 1: two validated schedules -- (a) gather, then the task-list SpMM; (b) the sliced SpMM with its local
+    # column slices overlapped with the gather.  Which one wins depends on how long the collective takes on
+    # this node, so both are timed for a few steps (max over ranks) and the faster one is kept.
+    if world > 1 and overlap and tplan is not None:
+        def timed(fn, reps=4):
+            fn()
+            torch.cuda.synchronize()
+            dist.barrier()
+            t_ = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            tt = torch.tensor([time.perf_counter() - t_], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt)
+
+        def gather_then_tasks():
+            gather()
+            cabi.fusedMM_csr_tasks_hip(msg, l_rowptr, l_col, l_val, tplan, x_in, out, arg, twork)
+
+        t_overlap = timed(lambda: part.spmm_overlapped(x_shard, x_in, out, plan, a.reduce, arg))
+        t_tasks = timed(gather_then_tasks)
+        if t_tasks < t_overlap:
+            overlap, use_tasks = False, True
+        if rank == 0:
+            print(f"[bench] N={world}: overlapped sliced {t_overlap * 250:.3f} ms/step, gather+tasks {t_tasks * 250:.3f} ms/step "
+                  f"-> {'gather+tasks' if use_tasks else 'overlapped sliced'}", file=sys.stderr)
+    elif world > 1 and tplan is not None and not overlap:
+        use_tasks = True
 
     def step(i=None):
         if overlap:
@@ -272,7 +303,7 @@ def main():
                             + (", U(0,1) weights" if a.weighted else ", unit weights")
                             + ("" if a.scale == 1.0 else f", SCALED x{a.scale} (debug)"),
                 "schedule": (f"task list: {a.slices} column slices, {tplan.n_tasks} tasks of <= {a.chunk} edges, rows < {a.short} unsliced"
-                             if tplan is not None else
+                             if use_tasks else
                              f"{a.slices} column slices, XCD-affine" if a.slices > 0 else "row-per-wave, unsliced"),
                 "partition": "none" if world == 1 else f"1-D rows by nnz, {world} ranks, one all-gather(X) per step"
                              + (", local column slices overlapped with the collective" if overlap else ", gather then SpMM"),
@@ -281,7 +312,7 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                 "traffic_source": None if traffic is None else "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, gfx950-corrected)",
-                "kernel": ("spmm_task_kernel + combine_tasks_kernel" if tplan is not None else
+                "kernel": ("spmm_task_kernel + combine_tasks_kernel" if use_tasks else
                            "spmm_csr_kernel" + (f"<sliced x{a.slices}> + combine_slices_kernel" if a.slices > 0 else "")),
                 "kernel_avg_ms": kern_avg_ms, "algorithmic_bytes_per_launch": b_alg,
                 "gather_model_GBps": synth.gather_bytes(m_local, l_col.numel(), k) / (kern_avg_ms * 1e-3) / 1e9,
