@@ -193,6 +193,31 @@ int    fusedMM_csr_tasks_hip(int32_t imessage, int64_t m, int64_t n, int64_t k, 
                              int64_t *z_arg, void *workspace, size_t workspace_bytes,
                              void *stream);
 
+/*
+ * The same with an epilogue fused into the fold (sum / mean only): the step right after the path in a GNN
+ * layer -- GCN's D^-1/2 (A + I) D^-1/2 X without materialising edge weights (y = D^-1/2 X, self = y,
+ * row_scale = D^-1/2), bias and ReLU (callers: tests/dist/gcn/pyg-sparse.py:61-62, normalize=True).
+ *     out[i,c] = act( row_scale[i] * (reduce[i,c] + self[i,c]) + bias[c] )        every member optional
+ */
+typedef struct isplib_epilogue {
+   const float *row_scale;   /* [dev] m, or NULL */
+   const float *self;        /* [dev] m x ld_self, or NULL */
+   int64_t      ld_self;
+   const float *bias;        /* [dev] k, or NULL */
+   int          relu;        /* nonzero: max(., 0) */
+} isplib_epilogue;
+int    fusedMM_csr_tasks_epilogue_hip(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t nnz,
+                                      const float *val, const int64_t *indx,
+                                      const int64_t *pntrb, const int64_t *pntre,
+                                      int64_t n_tasks, const int32_t *task_row,
+                                      const int64_t *task_b, const int32_t *task_len,
+                                      const int32_t *seg_off, int slices,
+                                      const int64_t *lane_off_host /*9, host*/,
+                                      const float *y, int64_t ldy, float *z, int64_t ldz,
+                                      void *workspace, size_t workspace_bytes,
+                                      const isplib_epilogue *epilogue /*host, may be NULL*/,
+                                      void *stream);
+
 /* Tuning knob for experiments (key 0: lanes per row slot, 0 = choose by k). */
 int isplib_hip_tune(int key, int value);
 

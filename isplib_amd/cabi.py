@@ -32,10 +32,15 @@ EXPORTS = (
     "fusedMM_csr_sliced_hip", "fusedMM_csr_sliced_phase_hip", "isplib_hip_tune",
     "isplib_spmm_tasks_workspace_bytes", "fusedMM_csr_tasks_hip",
     "isplib_spmm_tasks_plan_workspace_bytes", "isplib_spmm_tasks_count_hip", "isplib_spmm_tasks_fill_hip",
-    "isplib_sddmm_csr_tasks_hip",
+    "isplib_sddmm_csr_tasks_hip", "fusedMM_csr_tasks_epilogue_hip",
 )
 
 _i64, _f32, _vp, _i32 = ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_int32
+
+
+class Epilogue(ctypes.Structure):          # isplib_epilogue
+    _fields_ = [("row_scale", ctypes.c_void_p), ("self", ctypes.c_void_p), ("ld_self", ctypes.c_int64),
+                ("bias", ctypes.c_void_p), ("relu", ctypes.c_int)]
 
 
 class TaskPlanInfo(ctypes.Structure):      # isplib_task_plan_info
@@ -94,6 +99,10 @@ def lib() -> ctypes.CDLL:
         L.isplib_sddmm_csr_tasks_hip.restype = ctypes.c_int
         L.isplib_sddmm_csr_tasks_hip.argtypes = [_i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp,
                                                  _i64, ctypes.c_int, _vp, _vp]
+        L.fusedMM_csr_tasks_epilogue_hip.restype = ctypes.c_int
+        L.fusedMM_csr_tasks_epilogue_hip.argtypes = [_i32, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp,
+                                                     ctypes.c_int, _vp, _vp, _i64, _vp, _i64, _vp, ctypes.c_size_t,
+                                                     ctypes.POINTER(Epilogue), _vp]
         L.isplib_hip_tune.restype = ctypes.c_int
         L.isplib_hip_tune.argtypes = [ctypes.c_int, ctypes.c_int]
         _sigs_set = True
@@ -353,3 +362,24 @@ def sddmm_tasks(rowptr, col, plan, y, g, mean: bool = False):
                                               _ptr(g), k, int(bool(mean)), _ptr(dval), _stream(y.device))
     _check(st, "isplib_sddmm_csr_tasks_hip")
     return dval
+
+
+def spmm_tasks_epilogue(rowptr, col, val, plan, y, reduce="sum", row_scale=None, self_term=None, bias=None, relu=False):
+    """fusedMM_csr_tasks_epilogue_hip: out = act(row_scale * (reduce + self) + bias), sum / mean only."""
+    rowptr = _dev(rowptr, "rowptr", torch.int64)
+    col = _dev(col, "col", torch.int64)
+    y = y.contiguous()
+    m, n, k = rowptr.numel() - 1, y.size(0), y.size(1)
+    out = torch.empty((m, k), dtype=torch.float32, device=y.device)
+    work = plan.workspace(reduce, k)
+    ep = Epilogue(None if row_scale is None else row_scale.data_ptr(), None if self_term is None else self_term.data_ptr(),
+                  k if self_term is None else self_term.stride(0), None if bias is None else bias.data_ptr(), int(bool(relu)))
+    rp = rowptr.data_ptr()
+    lane = (ctypes.c_int64 * 9)(*plan.lane_off)
+    with torch.cuda.device(y.device):
+        st = lib().fusedMM_csr_tasks_epilogue_hip(MESSAGE[reduce], m, n, k, col.numel(), _ptr(val), _ptr(col), ctypes.c_void_p(rp),
+                                                  ctypes.c_void_p(rp + 8), plan.n_tasks, _ptr(plan.task_row), _ptr(plan.task_b),
+                                                  _ptr(plan.task_len), _ptr(plan.seg_off), plan.slices, lane, _ptr(y), k, _ptr(out),
+                                                  k, _ptr(work), work.numel(), ctypes.byref(ep), _stream(y.device))
+    _check(st, "fusedMM_csr_tasks_epilogue_hip")
+    return out

@@ -41,6 +41,10 @@ struct TaskArgs {
    int tpw;                  // tasks per wave (consecutive tasks of one lane)
    float *part_val;          // [n_tasks][k]
    int *part_idx;            // [n_tasks][k] row-relative edge ids (max/min)
+   // optional epilogue of the fold (sum / mean only; isplib_epilogue): out = act(row_scale[i] * (acc + self[i,c]) + bias[c])
+   const float *ep_row_scale, *ep_self, *ep_bias;
+   int64_t ep_ld_self;
+   int ep_relu;
 };
 
 template <int OP, int LPR, int NCH, int WAVES, int ADDR>
@@ -136,6 +140,24 @@ __global__ __launch_bounds__(256) void combine_tasks_kernel(const TaskArgs a) {
 #pragma unroll
             for (int v = 0; v < VEC; v++) acc[v] = acc[v] / d;
          }
+         if (a.ep_self) {                                   // e.g. the self loop of GCN's (A + I)
+            const float *sr = a.ep_self + (size_t)row * (size_t)a.ep_ld_self + c;
+#pragma unroll
+            for (int v = 0; v < VEC; v++) acc[v] += sr[v];
+         }
+         if (a.ep_row_scale) {                              // e.g. D^-1/2 on the left
+            const float rs = a.ep_row_scale[row];
+#pragma unroll
+            for (int v = 0; v < VEC; v++) acc[v] *= rs;
+         }
+         if (a.ep_bias) {
+#pragma unroll
+            for (int v = 0; v < VEC; v++) acc[v] += a.ep_bias[c + v];
+         }
+         if (a.ep_relu) {
+#pragma unroll
+            for (int v = 0; v < VEC; v++) acc[v] = acc[v] > 0.0f ? acc[v] : 0.0f;
+         }
       } else if (deg <= 0) {
 #pragma unroll
          for (int v = 0; v < VEC; v++) acc[v] = 0.0f;
@@ -199,13 +221,12 @@ extern "C" size_t isplib_spmm_tasks_workspace_bytes(int32_t imessage, int64_t n_
    return plane * (((imessage & 0xF0000) != ISPLIB_AOP_ADD) ? 2 : 1);
 }
 
-extern "C" int fusedMM_csr_tasks_hip(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t nnz, const float *val,
-                                     const int64_t *indx, const int64_t *pntrb, const int64_t *pntre,
-                                     int64_t n_tasks, const int32_t *task_row, const int64_t *task_b,
-                                     const int32_t *task_len, const int32_t *seg_off, int slices,
-                                     const int64_t *lane_off_host, const float *y, int64_t ldy, float *z,
-                                     int64_t ldz, int64_t *z_arg, void *workspace, size_t workspace_bytes,
-                                     void *stream) {
+static int tasks_entry(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t nnz, const float *val,
+                       const int64_t *indx, const int64_t *pntrb, const int64_t *pntre, int64_t n_tasks,
+                       const int32_t *task_row, const int64_t *task_b, const int32_t *task_len, const int32_t *seg_off,
+                       int slices, const int64_t *lane_off_host, const float *y, int64_t ldy, float *z, int64_t ldz,
+                       int64_t *z_arg, void *workspace, size_t workspace_bytes, const isplib_epilogue *ep,
+                       void *stream) {
    clear_error();
    const int32_t vop = imessage & 0xF, rop = imessage & 0xF0, sop = imessage & 0xF00, vsc = imessage & 0xF000,
                  aop = imessage & 0xF0000;
@@ -236,6 +257,13 @@ extern "C" int fusedMM_csr_tasks_hip(int32_t imessage, int64_t m, int64_t n, int
    for (int x = 0; x < 8; x++)
       if (a.lane_off[x + 1] < a.lane_off[x]) return fail(ISPLIB_FAIL, "fusedMM_csr_tasks_hip: lane_off must be non-decreasing");
    a.tpw = g_tasks_per_wave > 0 ? g_tasks_per_wave : 1;
+   a.ep_row_scale = a.ep_self = a.ep_bias = nullptr; a.ep_ld_self = 0; a.ep_relu = 0;
+   if (ep) {
+      if (aop != ISPLIB_AOP_ADD) return fail(ISPLIB_FAIL, "fusedMM_csr_tasks_epilogue_hip: the epilogue is defined for sum / mean only");
+      if (ep->self && ep->ld_self < k) return fail(ISPLIB_FAIL, "fusedMM_csr_tasks_epilogue_hip: ld_self smaller than k");
+      a.ep_row_scale = ep->row_scale; a.ep_self = ep->self; a.ep_ld_self = ep->ld_self; a.ep_bias = ep->bias;
+      a.ep_relu = ep->relu ? 1 : 0;
+   }
    a.part_val = (float *)workspace;
    const size_t plane = ((size_t)n_tasks * (size_t)k * sizeof(float) + 255) & ~(size_t)255;
    a.part_idx = aop == ISPLIB_AOP_ADD ? nullptr : (int *)((char *)workspace + plane);
@@ -254,6 +282,8 @@ extern "C" int fusedMM_csr_tasks_hip(int32_t imessage, int64_t m, int64_t n, int
       }
       p.y = y + c0;
       p.z = z + c0;
+      p.ep_self = a.ep_self ? a.ep_self + c0 : nullptr;
+      p.ep_bias = a.ep_bias ? a.ep_bias + c0 : nullptr;
       p.z_arg = z_arg ? z_arg + c0 : nullptr;
       p.ybytes = (unsigned)(yb - (unsigned long long)c0 * 4ull);
       int rc;
@@ -264,4 +294,26 @@ extern "C" int fusedMM_csr_tasks_hip(int32_t imessage, int64_t m, int64_t n, int
       if (c0 + p.k >= k) break;
    }
    return ISPLIB_SUCCESS;
+}
+
+extern "C" int fusedMM_csr_tasks_hip(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t nnz, const float *val,
+                                     const int64_t *indx, const int64_t *pntrb, const int64_t *pntre,
+                                     int64_t n_tasks, const int32_t *task_row, const int64_t *task_b,
+                                     const int32_t *task_len, const int32_t *seg_off, int slices,
+                                     const int64_t *lane_off_host, const float *y, int64_t ldy, float *z,
+                                     int64_t ldz, int64_t *z_arg, void *workspace, size_t workspace_bytes,
+                                     void *stream) {
+   return tasks_entry(imessage, m, n, k, nnz, val, indx, pntrb, pntre, n_tasks, task_row, task_b, task_len, seg_off, slices,
+                      lane_off_host, y, ldy, z, ldz, z_arg, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int fusedMM_csr_tasks_epilogue_hip(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t nnz,
+                                              const float *val, const int64_t *indx, const int64_t *pntrb,
+                                              const int64_t *pntre, int64_t n_tasks, const int32_t *task_row,
+                                              const int64_t *task_b, const int32_t *task_len, const int32_t *seg_off,
+                                              int slices, const int64_t *lane_off_host, const float *y, int64_t ldy,
+                                              float *z, int64_t ldz, void *workspace, size_t workspace_bytes,
+                                              const isplib_epilogue *epilogue, void *stream) {
+   return tasks_entry(imessage, m, n, k, nnz, val, indx, pntrb, pntre, n_tasks, task_row, task_b, task_len, seg_off, slices,
+                      lane_off_host, y, ldy, z, ldz, nullptr, workspace, workspace_bytes, epilogue, stream);
 }

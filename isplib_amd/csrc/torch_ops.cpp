@@ -180,6 +180,49 @@ Tensor sddmm(const Tensor &rowptr, const Tensor &col, const Tensor &mat, const T
    return dval;
 }
 
+// sum-SpMM with unit weights and the fused epilogue out = act(row_scale * (A y + self) + bias); the fold kernel
+// applies it when a task plan is given (isplib_epilogue), otherwise it is composed from ATen ops.
+Tensor epilogue_spmm(const Tensor &rowptr, const Tensor &col, const Plan &plan, const Tensor &y_, const Tensor &self_,
+                     const Tensor &row_scale, const Tensor &bias, bool relu) {
+   const Tensor y = y_.contiguous();
+   const int64_t M = rowptr.numel() - 1, N = y.size(0), K = y.size(1), nnz = col.numel();
+   const bool tasks_fit = plan.size() == 5 && K >= 4 && M > 0 && (double)N * (double)K * 4.0 <= 3.5 * 1073741824.0;
+   if (!tasks_fit) {
+      Tensor out = std::get<0>(spmm_fw(rowptr, col, c10::nullopt, y, R_SUM, plan));
+      if (self_.defined()) out = out + self_;
+      if (row_scale.defined()) out = out * row_scale.unsqueeze(1);
+      if (bias.defined()) out = out + bias;
+      return relu ? at::relu(out) : out;
+   }
+   c10::DeviceGuard guard(y.device());
+   const Tensor self = self_.defined() ? self_.contiguous() : Tensor();
+   const Tensor rs = row_scale.defined() ? row_scale.contiguous() : Tensor();
+   const Tensor bs = bias.defined() ? bias.contiguous() : Tensor();
+   if (self.defined()) TORCH_CHECK(self.size(0) == M && self.size(1) == K, "isplib: `self` must be [M, K]");
+   if (rs.defined()) TORCH_CHECK(rs.numel() == M, "isplib: `row_scale` must have M entries");
+   if (bs.defined()) TORCH_CHECK(bs.numel() == K, "isplib: `bias` must have K entries");
+   const Tensor rp_c = rowptr.contiguous(), col_c = col.contiguous();
+   Tensor out = at::empty({M, K}, y.options());
+   const int nsl = (int)((plan[3].numel() - 1) / M);
+   const int64_t n_tasks = plan[0].numel();
+   const size_t ws = isplib_spmm_tasks_workspace_bytes(ISPLIB_MSG_SPMM_SUM, n_tasks, K);
+   Tensor work = at::empty({(int64_t)ws}, y.options().dtype(at::kByte));
+   isplib_epilogue ep;
+   ep.row_scale = rs.defined() ? rs.data_ptr<float>() : nullptr;
+   ep.self = self.defined() ? self.data_ptr<float>() : nullptr;
+   ep.ld_self = K;
+   ep.bias = bs.defined() ? bs.data_ptr<float>() : nullptr;
+   ep.relu = relu ? 1 : 0;
+   const int64_t *rp = rp_c.data_ptr<int64_t>();
+   const int st = fusedMM_csr_tasks_epilogue_hip(
+       ISPLIB_MSG_SPMM_SUM, M, N, K, nnz, nullptr, col_c.data_ptr<int64_t>(), rp, rp + 1, n_tasks,
+       plan[0].data_ptr<int32_t>(), plan[1].data_ptr<int64_t>(), plan[2].data_ptr<int32_t>(), plan[3].data_ptr<int32_t>(), nsl,
+       plan[4].data_ptr<int64_t>(), y.data_ptr<float>(), K, out.data_ptr<float>(), K, work.data_ptr(), ws, &ep,
+       current_stream(y));
+   check_status(st, "fusedMM_csr_tasks_epilogue_hip");
+   return out;
+}
+
 Tensor or_undef(const optional<Tensor> &t) { return t.has_value() ? *t : Tensor(); }
 
 // AutogradContext::needs_input_grad() is indexed by autograd EDGE, i.e. by position among
@@ -332,6 +375,51 @@ class SpmmMinMax : public torch::autograd::Function<SpmmMinMax<RED>> {
    }
 };
 
+// ---- GCN's normalised aggregation, fused: relu(D^-1/2 (A + I) D^-1/2 X + b) with unit-weight A ----------
+// (the `normalize=True` callers, tests/dist/gcn/pyg-sparse.py:61-62; not an operator of the reference)
+class GcnNormSpmm : public torch::autograd::Function<GcnNormSpmm> {
+ public:
+   static variable_list forward(AutogradContext *ctx, Variable rowptr, Variable col, Variable mat, Variable dinv,
+                                optional<Variable> opt_colptr, optional<Variable> opt_row_t, Plan plan, Plan plan_t,
+                                optional<Variable> opt_bias, bool relu) {
+      check_index(rowptr, "rowptr"); check_index(col, "col"); check_float(mat, "mat"); check_float(dinv, "dinv");
+      TORCH_CHECK(mat.dim() == 2 && rowptr.numel() - 1 == mat.size(0), "isplib: gcn_norm_spmm needs a square graph and [N, K] features");
+      const Tensor bias = or_undef(opt_bias);
+      const Tensor y = mat * dinv.unsqueeze(1);
+      Tensor out = epilogue_spmm(rowptr, col, plan, y, y, dinv, bias, relu);
+      ctx->saved_data["relu"] = relu;
+      ctx->saved_data["plan_t"] = plan_t;
+      ctx->saved_data["bias_edge"] = (int64_t)(4 + (present(opt_colptr) ? 1 : 0) + (present(opt_row_t) ? 1 : 0));
+      ctx->saved_data["has_bias"] = bias.defined();
+      ctx->save_for_backward({rowptr, col, dinv, or_undef(opt_colptr), or_undef(opt_row_t), relu ? out : Tensor()});
+      return {out};
+   }
+
+   static variable_list backward(AutogradContext *ctx, variable_list grad_outs) {
+      auto saved = ctx->get_saved_variables();
+      auto rowptr = saved[0], col = saved[1], dinv = saved[2], colptr = saved[3], row_t = saved[4], out = saved[5];
+      Tensor g = grad_outs[0];
+      if (ctx->saved_data["relu"].toBool()) g = g * (out > 0).to(g.scalar_type());
+      auto grad_bias = Variable(), grad_mat = Variable();
+      if (ctx->saved_data["has_bias"].toBool() && ctx->needs_input_grad(ctx->saved_data["bias_edge"].toInt())) grad_bias = g.sum(0);
+      if (ctx->needs_input_grad(2)) {
+         Plan plan_t = ctx->saved_data["plan_t"].toTensorVector();
+         if (!colptr.defined() || !row_t.defined()) {
+            auto t = build_transpose(rowptr, col, Tensor(), rowptr.numel() - 1, false);
+            colptr = t.colptr; row_t = t.row_t; plan_t.clear();
+         }
+         const Tensor gy = g * dinv.unsqueeze(1);
+         grad_mat = epilogue_spmm(colptr, row_t, plan_t, gy, gy, dinv, Tensor(), false) ;   // D (A^T + I) D dZ
+      }
+      return {Variable(), Variable(), grad_mat, Variable(), Variable(), Variable(), Variable(), Variable(), grad_bias, Variable()};
+   }
+};
+
+Tensor gcn_norm_spmm(Tensor rowptr, Tensor col, Tensor mat, Tensor dinv, optional<Tensor> colptr, optional<Tensor> row_t,
+                     Plan plan, Plan plan_t, optional<Tensor> bias, bool relu) {
+   return GcnNormSpmm::apply(rowptr, col, mat, dinv, colptr, row_t, plan, plan_t, bias, relu)[0];
+}
+
 // ---- op wrappers: csrc/fusedmm.cpp:520-563 -------------------------------------------------
 Tensor fusedmm_spmm_add(optional<Tensor> opt_row, Tensor rowptr, Tensor col, optional<Tensor> opt_value,
                         optional<Tensor> opt_colptr, optional<Tensor> opt_csr2csc, Tensor mat,
@@ -417,4 +505,7 @@ TORCH_LIBRARY(isplib, m) {
          &fusedmm_spmm_max_planned);
    m.def("fusedmm_spmm_min_planned(Tensor rowptr, Tensor col, Tensor? value, Tensor mat, Tensor[] plan) -> (Tensor, Tensor)",
          &fusedmm_spmm_min_planned);
+   m.def("gcn_norm_spmm(Tensor rowptr, Tensor col, Tensor mat, Tensor dinv, Tensor? colptr, Tensor? row_t, Tensor[] plan, "
+         "Tensor[] plan_t, Tensor? bias, bool relu) -> Tensor",
+         &gcn_norm_spmm);
 }

@@ -158,6 +158,30 @@ def spmm_autotuned(src, other: torch.Tensor, reduce: str = "sum") -> torch.Tenso
 matmul = spmm_autotuned
 
 
+def gcn_norm_matmul(src, other: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
+    """relu(D^-1/2 (A + I) D^-1/2 @ other + bias) for an UNWEIGHTED square graph, without materialising the
+    normalised edge weights: the SpMM runs on the unit-weight fast path, the self loop, the left D^-1/2, bias
+    and ReLU are applied inside the fold kernel (include/isplib_hip.h: isplib_epilogue).  This is what a
+    GCNConv(normalize=True) layer aggregates (callers: tests/dist/gcn/pyg-sparse.py:61-62); differentiable in
+    `other` and `bias`.  Not part of the reference's surface."""
+    if not other.is_cuda or other.dtype != torch.float32 or other.dim() != 2:
+        raise RuntimeError("isplib_amd: gcn_norm_matmul needs a float32 GPU matrix [N, K] -- there is no CPU path")
+    s = _storage_of(src, other)
+    if s._value is not None:
+        raise ValueError("gcn_norm_matmul is defined for unweighted graphs (value=None)")
+    if s._sparse_sizes[0] != s._sparse_sizes[1]:
+        raise ValueError("gcn_norm_matmul needs a square adjacency")
+    k = other.size(1)
+    n_sl = choose_slices(s, other.size(0), k)
+    needs_grad = torch.is_grad_enabled() and other.requires_grad
+    colptr = row_t = None
+    plan_t = []
+    if needs_grad:
+        colptr, row_t, plan_t = s.colptr(), s.row_t(), s.plan_t(n_sl)
+    return torch.ops.isplib.gcn_norm_spmm(s._rowptr, s._col, other, s.gcn_dinv(), colptr, row_t, s.plan(n_sl), plan_t,
+                                          bias, relu)
+
+
 class iSpLibPlugin:
     backup = []          # LIFO of (torch_sparse.matmul | None, torch.sparse.mm, WITH_PT2, WITH_PT20)
 

@@ -133,6 +133,12 @@ class SparseStorage:
             self._slices_t[n_slices] = table if ok else None
         return self._slices_t[n_slices]
 
+    def gcn_dinv(self) -> torch.Tensor:
+        """(deg + 1)^-1/2 per row: the D^-1/2 of GCN's normalisation with self loops, unit weights."""
+        if getattr(self, "_gcn_dinv", None) is None:
+            self._gcn_dinv = (self.rowcount() + 1).to(torch.float32).pow(-0.5)
+        return self._gcn_dinv
+
     def mean_val_t(self) -> torch.Tensor:
         """value[csr2csc] / max(rowcount,1)[row[csr2csc]] (csrc/fusedmm.cpp:357-364)."""
         if self._mean_val_t is None:

@@ -32,11 +32,17 @@ class GCNConv(torch.nn.Module):
 
 
 class Net(torch.nn.Module):
-    def __init__(self, fin, hidden, classes):
+    def __init__(self, fin, hidden, classes, normalize=False):
         super().__init__()
         self.conv1, self.conv2 = GCNConv(fin, hidden), GCNConv(hidden, classes)
+        self.normalize = normalize      # GCNConv(normalize=True) of tests/dist/gcn/pyg-sparse.py:61-62
 
     def forward(self, x, adj_t, matmul):
+        if self.normalize:               # D^-1/2 (A+I) D^-1/2, bias and ReLU fused into the aggregation's fold kernel
+            import isplib_amd
+            x = isplib_amd.gcn_norm_matmul(adj_t, self.conv1.lin(x), self.conv1.bias, relu=True)
+            x = F.dropout(x, training=self.training)
+            return F.log_softmax(isplib_amd.gcn_norm_matmul(adj_t, self.conv2.lin(x), self.conv2.bias), dim=1)
         x = F.relu(self.conv1(x, adj_t, matmul))
         x = F.dropout(x, training=self.training)
         return F.log_softmax(self.conv2(x, adj_t, matmul), dim=1)
@@ -49,6 +55,7 @@ def main():
     p.add_argument("--hidden", type=int, default=32)        # EMBEDDING_SIZE, tests/cpu/gcn-sparse.py:4
     p.add_argument("--features", type=int, default=602)     # Reddit, tests/cpu/dataset_tester.ipynb:496
     p.add_argument("--classes", type=int, default=41)
+    p.add_argument("--normalize", action="store_true", help="GCN symmetric normalisation with self loops, fused (1 GPU)")
     a = p.parse_args()
     torch.manual_seed(0)                                    # tests/cpu/gcn-sparse.py:10-12
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -68,7 +75,7 @@ def main():
     y = torch.randint(0, a.classes, (n,), device=dev)
     train_mask = torch.rand(n, device=dev) < 0.66
     n_train = int(train_mask.sum())
-    model = Net(a.features, a.hidden, a.classes).to(dev)    # same seed on every rank: replicated weights
+    model = Net(a.features, a.hidden, a.classes, a.normalize and world == 1).to(dev)   # same seed on every rank
     opt = torch.optim.Adam(model.parameters(), lr=0.01, weight_decay=5e-4)
     if world > 1:
         from isplib_amd.dist import DistGraph
@@ -116,7 +123,7 @@ def main():
         print(json.dumps({"workload": f"2-layer GCN {a.features}->{a.hidden}->{a.classes}, reddit-like N={n} nnz={nnz}",
                           "epochs": a.epochs, "epoch_ms_mean": statistics.mean(times) * 1e3,
                           "epoch_ms_std": statistics.pstdev(times) * 1e3, "first_loss": losses[0],
-                          "last_loss": losses[-1], "train_acc": acc, "spmm_calls_per_epoch": 6, "n_gpus": world,
+                          "last_loss": losses[-1], "train_acc": acc, "spmm_calls_per_epoch": 6, "n_gpus": world, "normalize": bool(a.normalize and world == 1),
                           "backend": backend if world > 1 else None}))
     if world > 1:
         dist.barrier()

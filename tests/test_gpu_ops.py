@@ -348,3 +348,56 @@ def test_autotune_keeps_the_fastest_slice_count(gpu, oracle_mod):
     out = isplib_amd.matmul(adj, _t(x, gpu))
     ref, _ = oracle_mod.spmm_fw(rowptr, col, val, x, "sum")
     assert np.all(np.abs(out.cpu().numpy() - ref) <= cases.sum_tolerance(oracle_mod, rowptr, col, val, x))
+
+
+def _gcn_reference(oracle_mod, rowptr, col, x, bias, relu):
+    """relu(D^-1/2 (A + I) D^-1/2 x + b) composed from the oracle's unit-weight sum (fp32 steps like the kernel)."""
+    deg = np.diff(rowptr).astype(np.float32) + 1
+    dinv = (deg ** np.float32(-0.5)).astype(np.float32)
+    y = (x * dinv[:, None]).astype(np.float32)
+    agg, _ = oracle_mod.spmm_fw(rowptr, col, np.ones(col.size, np.float32), y, "sum")
+    out = (agg + y) * dinv[:, None] + (0 if bias is None else bias)
+    return (np.maximum(out, 0) if relu else out).astype(np.float32), dinv
+
+
+@pytest.mark.parametrize("forced", ("0", "8"))
+def test_fused_gcn_normalised_aggregation(gpu, oracle_mod, monkeypatch, forced):
+    """D^-1/2 (A+I) D^-1/2 X (+ bias, ReLU) without materialised edge weights; the epilogue is
+    applied by the fold kernel when a task plan is used (forced=8) and composed from ATen ops otherwise."""
+    import isplib_amd
+    monkeypatch.setenv("ISPLIB_SLICES", forced)
+    n, k = 300, 40
+    rowptr, col = cases.random_csr(n, n, 50.0, seed=19, empty_rows=(4,))
+    x, g = cases.dense(n, k, 3), cases.dense(n, k, 5)
+    bias = cases.dense(1, k, 7)[0]
+    adj = isplib_amd.SparseTensor.from_csr(_t(rowptr, gpu), _t(col, gpu), None, (n, n))
+    for use_bias, relu in ((False, False), (True, True)):
+        xs = _t(x, gpu).requires_grad_(True)
+        bs = _t(bias, gpu).requires_grad_(True) if use_bias else None
+        out = isplib_amd.gcn_norm_matmul(adj, xs, bs, relu)
+        out.backward(_t(g, gpu))
+        ref, dinv = _gcn_reference(oracle_mod, rowptr, col, x, bias if use_bias else None, relu)
+        _close(out, ref, rtol=1e-5, atol=1e-5)
+        dz = g * (ref > 0) if relu else g
+        gy = (dz * dinv[:, None]).astype(np.float32)
+        dref = (oracle_mod.spmm_sum_bw(rowptr, col, np.ones(col.size, np.float32), n, gy) + gy) * dinv[:, None]
+        _close(xs.grad, dref, rtol=1e-5, atol=1e-5)
+        if use_bias:
+            _close(bs.grad, dz.sum(0), rtol=1e-5, atol=1e-4)
+
+
+def test_task_epilogue_entry_point(gpu, oracle_mod):
+    from isplib_amd import cabi
+    from isplib_amd.plan import build_task_plan
+    rowptr, col = cases.random_csr(200, 260, 30.0, seed=29, empty_rows=(0,), hub=(5, 200))
+    x = cases.dense(260, 300, 3)                      # 300 columns: three 128-column panels
+    self_term, rs, bias = cases.dense(200, 300, 4), cases.dense(200, 1, 5)[:, 0].copy(), cases.dense(1, 300, 6)[0]
+    plan = build_task_plan(_t(rowptr, gpu), _t(col, gpu), 260, 8, 64, 16)
+    for red in ("sum", "mean"):
+        got = cabi.spmm_tasks_epilogue(_t(rowptr, gpu), _t(col, gpu), None, plan, _t(x, gpu), red, _t(rs, gpu),
+                                       _t(self_term, gpu), _t(bias, gpu), True)
+        base, _ = oracle_mod.spmm_fw(rowptr, col, np.ones(col.size, np.float32), x, red)
+        ref = np.maximum((base + self_term) * rs[:, None] + bias, 0)
+        _close(got, ref, rtol=1e-5, atol=2e-5)
+    with pytest.raises(RuntimeError, match="sum / mean only"):
+        cabi.spmm_tasks_epilogue(_t(rowptr, gpu), _t(col, gpu), None, plan, _t(x, gpu), "max", relu=True)
