@@ -39,9 +39,7 @@ class SparseStorage:
         self._row_t: Optional[torch.Tensor] = None
         self._val_t: Optional[torch.Tensor] = None
         self._mean_val_t: Optional[torch.Tensor] = None
-        # slice tables of the column-sliced kernels, {n_slices: table | None (rows not sorted)}
-        self._slices = {}
-        self._slices_t = {}
+        # task plans of A and A^T per slice count ([] when the rows are not column-sorted: plain kernel)
         self._plans = {}
         self._plans_t = {}
         self._tuned = {}          # (dense rows, k, minmax) -> slice count measured by iSpLibPlugin.autotune
@@ -118,20 +116,6 @@ class SparseStorage:
             cache[n_slices] = [] if p is None else [p.task_row, p.task_b, p.task_len, p.seg_off,
                                                     torch.tensor(p.lane_off, dtype=torch.int64)]
         return cache[n_slices]
-
-    def slices(self, n_slices: int) -> Optional[torch.Tensor]:
-        """Slice table of A for fusedMM_csr_sliced_hip, or None when rows are not column-sorted."""
-        if n_slices not in self._slices:
-            table, ok = cabi.spmm_slices(self._rowptr, self._col, self._sparse_sizes[1], n_slices)
-            self._slices[n_slices] = table if ok else None
-        return self._slices[n_slices]
-
-    def slices_t(self, n_slices: int) -> Optional[torch.Tensor]:
-        """Slice table of A^T (CSC operands are sorted by construction)."""
-        if n_slices not in self._slices_t:
-            table, ok = cabi.spmm_slices(self.colptr(), self.row_t(), self._sparse_sizes[0], n_slices)
-            self._slices_t[n_slices] = table if ok else None
-        return self._slices_t[n_slices]
 
     def gcn_dinv(self) -> torch.Tensor:
         """(deg + 1)^-1/2 per row: the D^-1/2 of GCN's normalisation with self loops, unit weights."""
