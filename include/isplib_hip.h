@@ -130,8 +130,9 @@ int    fusedMM_csr_sliced_hip(int32_t imessage, int64_t m, int64_t n, int64_t k,
 /*
  * The same computation in phases, for overlapping a collective with compute (1-D row
  * partition: the slices that fall in this rank's own shard of y need no remote data).
- * Runs the partial kernel over slices [slice_first, slice_first + slice_count) (count may
- * be 0) and, when `combine` != 0, the fold over ALL `slices` planes afterwards.  Every
+ * Runs the partial kernel over the slice_count slices slice_first, slice_first + 1, ... taken
+ * modulo `slices` (so "every slice but mine" is one call; count may be 0) and, when `combine`
+ * != 0, the fold over ALL `slices` planes afterwards.  Every
  * slice must have been covered by some phase, with the same workspace, before the
  * combining call.  `y` may differ between phases as long as y[indx[j]] addresses the right
  * row for every column of the phase's slices (e.g. a base pointer shifted onto a shard).

@@ -119,27 +119,23 @@ __global__ __launch_bounds__(WAVES * 64, (min_waves_of<OP, LPR, NCH, ADDR>())) v
 
    // XCD-aware remap: physical blocks pb, pb+8, ... share one XCD (speed only, never correctness).
    //  plain : each XCD walks a contiguous range of row blocks.
-   //  sliced: each XCD walks ALL row blocks of its own column slice(s), so its L2 only ever sees a
-   //          fraction of the rows of y.  count >= 8: XCD x takes slices x, x+8, ... one after the
-   //          other; count < 8: the XCDs x = s, s+count, ... share slice s and split its row blocks.
+   //  sliced: each XCD walks the row blocks of its own column slice(s), so its L2 only ever sees a
+   //          fraction of the rows of y.
    const unsigned pb = blockIdx.x, nb = a.nblk;
    const unsigned xcd = pb & 7u, within = pb >> 3;
    unsigned lb;
    int slice = 0;
    if (SLICED) {
-      const unsigned sc = (unsigned)a.slice_count;
-      unsigned sl;
-      if (sc >= 8u) {
-         sl = xcd + 8u * (within / nb);
-         lb = within % nb;
-         if (sl >= sc) return;
-      } else {
-         sl = xcd % sc;
-         const unsigned nshare = (8u - sl + sc - 1u) / sc;
-         lb = xcd / sc + nshare * within;
-         if (lb >= nb) return;
-      }
-      slice = a.slice_first + (int)sl;
+      // the (slice, row block) items of this launch, slice-major, are cut into 8 equal contiguous runs, one per
+      // XCD: an XCD walks at most a few slices one after the other (L2 affinity) and every XCD gets the same
+      // number of items whatever the slice count (16 -> two slices each, 2 -> a quarter of a slice each, 14 ->
+      // 1.75 each).  Slices wrap around modulo `slices`, so "all but my own" is one launch.
+      const uint64_t items = (uint64_t)a.slice_count * nb;
+      const uint64_t per_x = (items + 7u) / 8u;
+      const uint64_t item = (uint64_t)xcd * per_x + within;
+      if (within >= per_x || item >= items) return;
+      lb = (unsigned)(item % nb);
+      slice = (int)(((uint64_t)a.slice_first + item / nb) % (uint64_t)a.slices);
    } else {
       const unsigned per = nb >> 3, rem = nb & 7u;
       lb = xcd * per + (xcd < rem ? xcd : rem) + within;
@@ -358,9 +354,7 @@ static int launch_addr(const SpmmArgs &a0, hipStream_t st) {
    const unsigned ny = (unsigned)((a.k + PANEL - 1) / PANEL);
    if (a.sliceptr) {
       if (a.slice_count > 0) {
-         const int64_t sc = a.slice_count;
-         const int64_t per_xcd = sc >= 8 ? ((sc + 7) / 8) * nb : (nb + (8 / sc) - 1) / (8 / sc);
-         const int64_t gx = 8 * per_xcd;
+         const int64_t gx = 8 * (((int64_t)a.slice_count * nb + 7) / 8);
          if (gx > 0x7fffffffLL) return ISPLIB_FAIL;
          hipLaunchKernelGGL((spmm_csr_kernel<OP, VEC, LPR, NCH, WAVES, true, ADDR>), dim3((unsigned)gx, ny, 1),
                             dim3(WAVES * 64, 1, 1), 0, st, a);
@@ -446,7 +440,7 @@ static int spmm_entry(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t
       const size_t need = isplib_spmm_sliced_workspace_bytes(imessage, m, k, slices);
       if (!workspace || workspace_bytes < need) return fail(ISPLIB_NOT_ENOUGH_MEM, "fusedMM_csr_sliced_hip: workspace too small");
       if (((uintptr_t)workspace & 255) != 0) return fail(ISPLIB_FAIL, "fusedMM_csr_sliced_hip: workspace must be 256-byte aligned");
-      if (slice_first < 0 || slice_count < 0 || slice_first + slice_count > slices)
+      if (slice_first < 0 || slice_first >= slices || slice_count < 0 || slice_count > slices)
          return fail(ISPLIB_FAIL, "fusedMM_csr_sliced_phase_hip: slice range outside [0, slices)");
       a.sliceptr = sliceptr; a.slices = slices;
       a.slice_first = slice_first; a.slice_count = slice_count; a.combine = combine ? 1 : 0;

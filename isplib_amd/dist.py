@@ -147,9 +147,8 @@ class RowPartition:
                                           out, arg, work)
         if handle is not None:
             handle.wait()
-        cabi.fusedMM_csr_sliced_phase_hip(*common, 0, first, False, buf.data_ptr(), self.ncols_padded, k, buf.stride(0),
-                                          out, arg, work)
-        cabi.fusedMM_csr_sliced_phase_hip(*common, first + q, s - first - q, True, buf.data_ptr(), self.ncols_padded, k,
+        # every other slice (the range wraps around modulo s), evenly over the 8 XCDs, then the fold
+        cabi.fusedMM_csr_sliced_phase_hip(*common, (first + q) % s, s - q, True, buf.data_ptr(), self.ncols_padded, k,
                                           buf.stride(0), out, arg, work)
         return out
 

@@ -253,6 +253,6 @@ def test_task_entry_argument_validation_without_gpu():
     assert L.isplib_spmm_tasks_count_hip(4, one, one, one, 8, 8, 128, one, one, 1 << 20, ctypes.byref(info), None) == cabi.FAIL
     assert L.isplib_spmm_tasks_workspace_bytes(cabi.MSG_SPMM_MAX, 10, 16) >= 2 * 10 * 16 * 4
     assert L.isplib_spmm_slices_build_hip(4, 4, 0, one, one, None, 9, one, None, None) == cabi.FAIL
-    assert L.fusedMM_csr_sliced_phase_hip(cabi.MSG_SPMM_SUM, 4, 4, 8, 0, None, one, one, one, one, 8, 6, 4, 1, one, 8, one, 8,
+    assert L.fusedMM_csr_sliced_phase_hip(cabi.MSG_SPMM_SUM, 4, 4, 8, 0, None, one, one, one, one, 8, 8, 4, 1, one, 8, one, 8,
                                           None, ctypes.c_void_p(256), 1 << 20, None) == cabi.FAIL
     assert "slice range" in cabi.last_error()
