@@ -169,7 +169,8 @@ typedef struct isplib_task_plan_info {
  *   count: from the slice table (isplib_spmm_slices_build_hip) derives the number of tasks of every
  *          (slice position, row) segment -- ceil(len / chunk), rows with fewer than short_row edges
  *          kept whole on slice row % slices -- and its exclusive prefix seg_off[slices*m + 1].
- *          Fills *info (HOST) and synchronises `stream` ONCE to do so.
+ *          Fills *info (HOST) and synchronises `stream` ONCE to do so; info->lane_off cuts the task
+ *          list into eight contiguous runs of equal EDGE mass (one per XCD lane).
  *   fill : writes task_row / task_b / task_len (info->n_tasks entries each).
  */
 size_t isplib_spmm_tasks_plan_workspace_bytes(int64_t m, int slices);

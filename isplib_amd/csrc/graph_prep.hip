@@ -145,15 +145,33 @@ __device__ __forceinline__ void plan_segment(int64_t row, int sp, int slices, in
 __global__ __launch_bounds__(256) void plan_count_kernel(int64_t m, int slices, int chunk, int short_row,
                                                          const int64_t *__restrict__ pntrb,
                                                          const int64_t *__restrict__ pntre,
-                                                         const int64_t *__restrict__ sliceptr, int *__restrict__ cnt) {
+                                                         const int64_t *__restrict__ sliceptr, int *__restrict__ cnt,
+                                                         int64_t *__restrict__ ecnt) {
    const int64_t total = m * slices;
    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= total; i += stride) {
-      if (i == total) { cnt[i] = 0; continue; }
+      if (i == total) { cnt[i] = 0; ecnt[i] = 0; continue; }
       int64_t b, e;
       plan_segment(i % m, (int)(i / m), slices, short_row, pntrb, pntre, sliceptr, b, e);
       cnt[i] = (int)((e - b + chunk - 1) / chunk);
+      ecnt[i] = e - b;
    }
+}
+
+// lane boundaries by EDGE mass: lane x starts at the first segment whose edge prefix reaches x/8 of all edges
+// (a skewed graph -- R-MAT's low column ids carry most edges -- otherwise leaves most XCDs idle at the end)
+__global__ void plan_lanes_kernel(int64_t items, const int64_t *__restrict__ eoff, const int *__restrict__ seg_off,
+                                  int *__restrict__ lanes) {
+   const int x = threadIdx.x;
+   if (x > 8) return;
+   const int64_t total = eoff[items - 1];
+   const int64_t target = x == 8 ? total + 1 : (total / 8) * x;
+   int64_t lo = 0, hi = items - 1;           // first segment index whose exclusive edge prefix is >= target
+   while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (eoff[mid] < target) lo = mid + 1; else hi = mid;
+   }
+   lanes[x] = x == 0 ? 0 : seg_off[x == 8 ? items - 1 : lo];
 }
 
 __global__ __launch_bounds__(256) void plan_fill_kernel(int64_t m, int slices, int chunk, int short_row,
@@ -180,9 +198,14 @@ __global__ __launch_bounds__(256) void plan_fill_kernel(int64_t m, int slices, i
 }
 
 static hipError_t plan_scan_temp_bytes(int64_t items, size_t *bytes) {
-   *bytes = 0;
-   return rocprim::exclusive_scan(nullptr, *bytes, (const int *)nullptr, (int *)nullptr, 0, (size_t)items,
-                                  rocprim::plus<int>(), (hipStream_t)0, false);
+   size_t a = 0, b = 0;
+   hipError_t e = rocprim::exclusive_scan(nullptr, a, (const int *)nullptr, (int *)nullptr, 0, (size_t)items,
+                                          rocprim::plus<int>(), (hipStream_t)0, false);
+   if (e != hipSuccess) return e;
+   e = rocprim::exclusive_scan(nullptr, b, (const int64_t *)nullptr, (int64_t *)nullptr, (int64_t)0, (size_t)items,
+                               rocprim::plus<int64_t>(), (hipStream_t)0, false);
+   *bytes = a > b ? a : b;
+   return e;
 }
 
 static inline unsigned grid_for(int64_t n) {
@@ -301,7 +324,7 @@ extern "C" size_t isplib_spmm_tasks_plan_workspace_bytes(int64_t m, int slices) 
    const int64_t items = m * slices + 1;
    size_t temp = 0;
    if (plan_scan_temp_bytes(items, &temp) != hipSuccess) return 0;
-   return align_up((size_t)items * sizeof(int)) + align_up(temp) + 256;
+   return align_up((size_t)items * sizeof(int)) + 2 * align_up((size_t)items * sizeof(int64_t)) + align_up(temp) + 512;
 }
 
 extern "C" int isplib_spmm_tasks_count_hip(int64_t m, const int64_t *pntrb, const int64_t *pntre,
@@ -325,21 +348,28 @@ extern "C" int isplib_spmm_tasks_count_hip(int64_t m, const int64_t *pntrb, cons
    const int64_t items = m * slices + 1;
    size_t temp = 0;
    ISPLIB_HIP_TRY(plan_scan_temp_bytes(items, &temp));
-   const size_t cnt_bytes = align_up((size_t)items * sizeof(int));
-   if (workspace_bytes < cnt_bytes + align_up(temp)) return fail(ISPLIB_NOT_ENOUGH_MEM, "isplib_spmm_tasks_count_hip: workspace too small");
-   int *cnt = (int *)workspace;
-   void *tmp = (char *)workspace + cnt_bytes;
+   const size_t cnt_bytes = align_up((size_t)items * sizeof(int)), e_bytes = align_up((size_t)items * sizeof(int64_t));
+   if (workspace_bytes < cnt_bytes + 2 * e_bytes + align_up(temp) + 256)
+      return fail(ISPLIB_NOT_ENOUGH_MEM, "isplib_spmm_tasks_count_hip: workspace too small");
+   char *w = (char *)workspace;
+   int *cnt = (int *)w;
+   int64_t *ecnt = (int64_t *)(w + cnt_bytes), *eoff = (int64_t *)(w + cnt_bytes + e_bytes);
+   void *tmp = w + cnt_bytes + 2 * e_bytes;
+   int *lanes = (int *)(w + cnt_bytes + 2 * e_bytes + align_up(temp));
    hipLaunchKernelGGL(plan_count_kernel, dim3(grid_for(items)), dim3(256), 0, st, m, slices, chunk, short_row, pntrb,
-                      pntre, sliceptr, cnt);
+                      pntre, sliceptr, cnt, ecnt);
    int rc = check_launch("plan_count_kernel");
    if (rc) return rc;
    ISPLIB_HIP_TRY(rocprim::exclusive_scan(tmp, temp, (const int *)cnt, (int *)seg_off, 0, (size_t)items,
                                           rocprim::plus<int>(), st, false));
-   // the one host round trip of the plan: task count and the eight lane boundaries
+   ISPLIB_HIP_TRY(rocprim::exclusive_scan(tmp, temp, (const int64_t *)ecnt, eoff, (int64_t)0, (size_t)items,
+                                          rocprim::plus<int64_t>(), st, false));
+   hipLaunchKernelGGL(plan_lanes_kernel, dim3(1), dim3(64), 0, st, items, eoff, seg_off, lanes);
+   rc = check_launch("plan_lanes_kernel");
+   if (rc) return rc;
+   // the one host round trip of the plan: the task count and the eight (edge-balanced) lane boundaries
    int host[9];
-   const int64_t per_lane_items = (int64_t)(slices / 8) * m;
-   for (int x = 0; x < 9; x++)
-      ISPLIB_HIP_TRY(hipMemcpyAsync(&host[x], seg_off + x * per_lane_items, sizeof(int), hipMemcpyDeviceToHost, st));
+   ISPLIB_HIP_TRY(hipMemcpyAsync(host, lanes, 9 * sizeof(int), hipMemcpyDeviceToHost, st));
    ISPLIB_HIP_TRY(hipStreamSynchronize(st));
    for (int x = 0; x < 9; x++) info->lane_off[x] = host[x];
    info->n_tasks = host[8];
