@@ -85,6 +85,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    # ISPLIB_BENCH_FORCE_DIST=1 under `torch.distributed.run --nproc-per-node 1` walks the N > 1 code (RCCL init,
+    # partition, async all-gather, overlapped schedule) with a single rank: a rehearsal of the API calls on a
+    # 1-GPU box, labelled as such in the output line.
+    forced = world == 1 and os.environ.get("ISPLIB_BENCH_FORCE_DIST") == "1"
+    multi = world > 1 or forced
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
     # one process per GPU; backend "nccl" is RCCL over xGMI.  ISPLIB_BENCH_BACKEND=gloo lets several ranks
@@ -94,7 +99,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -117,7 +122,7 @@ def main():
         key, value = kv.split("=")
         cabi.lib().isplib_hip_tune(int(key), int(value))
 
-    if world == 1:
+    if not multi:
         l_rowptr, l_col, l_val, m_local, x_in = rowptr, col, val, n, x
         out = torch.empty((n, k), dtype=torch.float32, device=dev)
         arg = torch.empty((n, k), dtype=torch.int64, device=dev) if a.reduce in ("max", "min") else None
@@ -140,7 +145,7 @@ def main():
     table = work = plan = None
     if a.slices < 0:
         a.slices = suggest_slices(m_local, x_in.size(0), l_col.numel(), k, a.reduce in ("max", "min"))
-    if world > 1 and a.slices > 0:
+    if multi and a.slices > 0:
         plan = part.plan(k, a.reduce, slices=a.slices)     # slice count rounded to a multiple of world
         if plan is not None:
             a.slices, table, work = plan
@@ -155,7 +160,7 @@ def main():
         from isplib_amd.plan import build_task_plan
         tplan = build_task_plan(l_rowptr, l_col, x_in.size(0), a.slices, a.chunk, a.short)
         twork = tplan.workspace(a.reduce, k)
-    use_tasks = tplan is not None and world == 1      # N > 1: decided by a short measurement below
+    use_tasks = tplan is not None and not multi      # N > 1: decided by a short measurement below
 
     def spmm(rp, cl, vl, tb, xin, o, ar, tp=None):
         tp = tplan if (tp is None and rp is l_rowptr and use_tasks) else tp
@@ -168,7 +173,7 @@ def main():
 
     # N > 1: local column slices are aggregated while the all-gather is in flight (isplib_amd/dist.py).
     # Checked once against the plain "gather, then SpMM" order before it is trusted; ISPLIB_OVERLAP=0 disables.
-    overlap = world > 1 and plan is not None and os.environ.get("ISPLIB_OVERLAP", "1") != "0"
+    overlap = multi and plan is not None and os.environ.get("ISPLIB_OVERLAP", "1") != "0"
     if overlap:
         try:
             gather()
@@ -190,7 +195,7 @@ def main():
     # N > 1: two validated schedules -- (a) gather, then the task-list SpMM; (b) the sliced SpMM with its local
     # column slices overlapped with the gather.  Which one wins depends on how long the collective takes on
     # this node, so both are timed for a few steps (max over ranks) and the faster one is kept.
-    if world > 1 and overlap and tplan is not None:
+    if multi and overlap and tplan is not None:
         def timed(fn, reps=4):
             fn()
             torch.cuda.synchronize()
@@ -214,7 +219,7 @@ def main():
         if rank == 0:
             print(f"[bench] N={world}: overlapped sliced {t_overlap * 250:.3f} ms/step, gather+tasks {t_tasks * 250:.3f} ms/step "
                   f"-> {'gather+tasks' if use_tasks else 'overlapped sliced'}", file=sys.stderr)
-    elif world > 1 and tplan is not None and not overlap:
+    elif multi and tplan is not None and not overlap:
         use_tasks = True
 
     def step(i=None):
@@ -236,18 +241,18 @@ def main():
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -256,7 +261,7 @@ def main():
 
     # backward of SpMM-sum = the same kernel on A^T (csrc/fusedmm.cpp:285); reported beside the metric
     bwd = None
-    if world == 1 and not a.no_backward and a.reduce == "sum":
+    if not multi and not a.no_backward and a.reduce == "sum":
         colptr, _, row_t, val_t = cabi.csr2csc(rowptr, col, val, n, want_perm=False, want_val=val is not None)
         dy = synth.features(n, k, seed=5, device=dev)
         dx = torch.empty((n, k), dtype=torch.float32, device=dev)
@@ -286,7 +291,7 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         # measured offline (separate --pmc passes cannot run inside this process): profiles/traffic.json
-        if os.path.exists(tpath) and world == 1 and a.scale == 1.0 and not a.weighted and a.generator == "chunglu" \
+        if os.path.exists(tpath) and not multi and a.scale == 1.0 and not a.weighted and a.generator == "chunglu" \
                 and (a.chunk, a.short) == (1024, 128):
             try:
                 rec = json.load(open(tpath)).get(f"{a.workload}-{a.reduce}-k{k}-s{a.slices}" + ("-tasks" if tplan is not None else ""))
@@ -297,7 +302,7 @@ def main():
             "metric": "edges_aggregated_per_sec", "value": nnz / (elapsed / a.steps), "unit": "edges/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic" + ("" if backend == "nccl" else f" (REHEARSAL over {backend}, not a result)"),
+            "data": "synthetic" + (" (REHEARSAL of the N>1 path on one rank, not a result)" if forced else "" if backend == "nccl" else f" (REHEARSAL over {backend}, not a result)"),
             "config": {
                 "workload": f"{a.workload}-like graph ({a.generator}, N={n}, nnz={nnz}), SpMM-{a.reduce} forward, K={k}, fp32"
                             + (", U(0,1) weights" if a.weighted else ", unit weights")
@@ -305,7 +310,7 @@ def main():
                 "schedule": (f"task list: {a.slices} column slices, {tplan.n_tasks} tasks of <= {a.chunk} edges, rows < {a.short} unsliced"
                              if use_tasks else
                              f"{a.slices} column slices, XCD-affine" if a.slices > 0 else "row-per-wave, unsliced"),
-                "partition": "none" if world == 1 else f"1-D rows by nnz, {world} ranks, one all-gather(X) per step"
+                "partition": "none" if not multi else f"1-D rows by nnz, {world} ranks, one all-gather(X) per step"
                              + (", local column slices overlapped with the collective" if overlap else ", gather then SpMM"),
             },
             "roofline": {
@@ -320,10 +325,10 @@ def main():
         }
         if bwd:
             res["backward"] = bwd
-        if world == 1 and not a.no_cpu_baseline:
+        if not multi and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(rowptr, col, x, nnz)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 
