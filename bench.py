@@ -259,6 +259,33 @@ def main():
     kern_ms = [s.elapsed_time(e) for s, e in ev]
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
 
+    # SURVEY.md 8(d) extras, outside the timed region, N=1 only: (i) the same launch with L2 + Infinity Cache
+    # flushed first (a 1 GiB fill evicts the 256 MiB MALL), (ii) this box's device-to-device copy rate, the
+    # "measured peak" the roofline fraction is also quoted against.
+    cold_ms = copy_gbps = None
+    if not multi:
+        scratch = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+        colds = []
+        for _ in range(3):
+            scratch.fill_(1.0)
+            s0, e0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s0.record()
+            spmm(l_rowptr, l_col, l_val, table, x_in, out, arg)
+            e0.record()
+            torch.cuda.synchronize()
+            colds.append(s0.elapsed_time(e0))
+        cold_ms = sorted(colds)[1]
+        half = scratch.numel() // 2
+        s0, e0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        scratch[half:].copy_(scratch[:half])
+        s0.record()
+        for _ in range(10):
+            scratch[half:].copy_(scratch[:half])
+        e0.record()
+        torch.cuda.synchronize()
+        copy_gbps = 10 * 2 * half * 4 / (s0.elapsed_time(e0) * 1e-3) / 1e9      # bytes read + written
+        del scratch
+
     # backward of SpMM-sum = the same kernel on A^T (csrc/fusedmm.cpp:285); reported beside the metric
     bwd = None
     if not multi and not a.no_backward and a.reduce == "sum":
@@ -319,7 +346,10 @@ def main():
                 "traffic_source": None if traffic is None else "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, gfx950-corrected)",
                 "kernel": ("spmm_task_kernel + combine_tasks_kernel" if use_tasks else
                            "spmm_csr_kernel" + (f"<sliced x{a.slices}> + combine_slices_kernel" if a.slices > 0 else "")),
-                "kernel_avg_ms": kern_avg_ms, "algorithmic_bytes_per_launch": b_alg,
+                "kernel_avg_ms": kern_avg_ms, "kernel_median_ms": sorted(kern_ms)[len(kern_ms) // 2], "kernel_min_ms": min(kern_ms),
+                "kernel_cold_cache_ms": cold_ms, "peak_measured_copy": copy_gbps,
+                "frac_of_measured_copy": None if not copy_gbps else achieved / copy_gbps,
+                "algorithmic_bytes_per_launch": b_alg,
                 "gather_model_GBps": synth.gather_bytes(m_local, l_col.numel(), k) / (kern_avg_ms * 1e-3) / 1e9,
             },
         }
