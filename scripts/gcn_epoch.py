@@ -6,7 +6,11 @@ report :114-125).  PyG is not in this image, so GCNConv(cached=True, normalize=F
     out = matmul(adj_t, x @ W) + b                       (aggregate AFTER the linear layer: K = 32, then C)
 with `matmul` = isplib_amd.matmul, i.e. what torch_sparse.matmul becomes after iSpLibPlugin.patch_pyg().
 
-    python scripts/gcn_epoch.py [--epochs 10] [--scale 1.0] [--hidden 32]
+    python scripts/gcn_epoch.py [--epochs 10] [--scale 1.0] [--hidden 32] [--model gcn|sage|gin] [--aggr sum|mean|max]
+
+--model sage / gin restate the other two callers (tests/cpu/graphSAGE-sparse.py:65-78, tests/cpu/gin-sparse.py:59-78):
+they aggregate at the INPUT width (use --features 608, the padded Reddit width), 5 SpMM per epoch (the
+input features need no gradient, so layer 1 has no backward SpMM).
 """
 import argparse
 import json
@@ -48,8 +52,56 @@ class Net(torch.nn.Module):
         return F.log_softmax(self.conv2(x, adj_t, matmul), dim=1)
 
 
+class SAGEConv(torch.nn.Module):
+    """PyG SAGEConv(aggr=sum|mean, normalize=False): lin_l(aggregate(x)) + lin_r(x); aggregation at the INPUT width
+    (608 on padded Reddit, tests/cpu/graphSAGE-sparse.py:65-78, dataset_loader.py:145-160)."""
+
+    def __init__(self, fin, fout, aggr):
+        super().__init__()
+        self.lin_l, self.lin_r, self.aggr = torch.nn.Linear(fin, fout), torch.nn.Linear(fin, fout, bias=False), aggr
+
+    def forward(self, x, adj_t, matmul):
+        return self.lin_l(matmul(adj_t, x, self.aggr)) + self.lin_r(x)
+
+
+class SAGENet(torch.nn.Module):
+    def __init__(self, fin, hidden, classes, aggr):
+        super().__init__()
+        self.conv1, self.conv2 = SAGEConv(fin, hidden, aggr), SAGEConv(hidden, classes, aggr)
+
+    def forward(self, x, adj_t, matmul):
+        x = F.dropout(F.relu(self.conv1(x, adj_t, matmul)), training=self.training)
+        return F.log_softmax(self.conv2(x, adj_t, matmul), dim=1)
+
+
+class GINConv(torch.nn.Module):
+    """PyG GINConv(nn), eps = 0: nn(x + sum_j x_j) (tests/cpu/gin-sparse.py:59-78)."""
+
+    def __init__(self, fin, hidden):
+        super().__init__()
+        self.nn = torch.nn.Sequential(torch.nn.Linear(fin, hidden), torch.nn.ReLU(), torch.nn.Linear(hidden, hidden))
+
+    def forward(self, x, adj_t, matmul):
+        return self.nn(x + matmul(adj_t, x, "sum"))
+
+
+class GINNet(torch.nn.Module):
+    def __init__(self, fin, hidden, classes):
+        super().__init__()
+        self.conv1, self.bn1 = GINConv(fin, hidden), torch.nn.BatchNorm1d(hidden)
+        self.conv2, self.bn2 = GINConv(hidden, hidden), torch.nn.BatchNorm1d(hidden)
+        self.fc1, self.fc2 = torch.nn.Linear(hidden, hidden), torch.nn.Linear(hidden, classes)
+
+    def forward(self, x, adj_t, matmul):
+        x = self.bn1(self.conv1(x, adj_t, matmul))
+        x = self.bn2(self.conv2(x, adj_t, matmul))
+        return F.log_softmax(self.fc2(self.fc1(x).relu()), dim=1)
+
+
 def main():
     p = argparse.ArgumentParser()
+    p.add_argument("--model", choices=("gcn", "sage", "gin"), default="gcn")
+    p.add_argument("--aggr", choices=("sum", "mean", "max", "min"), default="sum", help="SAGE aggregation")
     p.add_argument("--epochs", type=int, default=10)
     p.add_argument("--scale", type=float, default=1.0)
     p.add_argument("--hidden", type=int, default=32)        # EMBEDDING_SIZE, tests/cpu/gcn-sparse.py:4
@@ -75,7 +127,14 @@ def main():
     y = torch.randint(0, a.classes, (n,), device=dev)
     train_mask = torch.rand(n, device=dev) < 0.66
     n_train = int(train_mask.sum())
-    model = Net(a.features, a.hidden, a.classes, a.normalize and world == 1).to(dev)   # same seed on every rank
+    if a.model != "gcn" and world > 1:
+        raise SystemExit("--model sage/gin: single GPU only")
+    if a.model == "sage":
+        model = SAGENet(a.features, a.hidden, a.classes, a.aggr).to(dev)
+    elif a.model == "gin":
+        model = GINNet(a.features, a.hidden, a.classes).to(dev)
+    else:
+        model = Net(a.features, a.hidden, a.classes, a.normalize and world == 1).to(dev)   # same seed on every rank
     opt = torch.optim.Adam(model.parameters(), lr=0.01, weight_decay=5e-4)
     if world > 1:
         from isplib_amd.dist import DistGraph
@@ -120,10 +179,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         times = [float(t)] * len(times)
     if rank == 0:
-        print(json.dumps({"workload": f"2-layer GCN {a.features}->{a.hidden}->{a.classes}, reddit-like N={n} nnz={nnz}",
+        name = {"gcn": "GCN", "sage": f"SAGE({a.aggr})", "gin": "GIN"}[a.model]
+        print(json.dumps({"workload": f"2-layer {name} {a.features}->{a.hidden}->{a.classes}, reddit-like N={n} nnz={nnz}",
                           "epochs": a.epochs, "epoch_ms_mean": statistics.mean(times) * 1e3,
                           "epoch_ms_std": statistics.pstdev(times) * 1e3, "first_loss": losses[0],
-                          "last_loss": losses[-1], "train_acc": acc, "spmm_calls_per_epoch": 6, "n_gpus": world, "normalize": bool(a.normalize and world == 1),
+                          "last_loss": losses[-1], "train_acc": acc, "spmm_calls_per_epoch": 6 if a.model == "gcn" else 5, "n_gpus": world, "normalize": bool(a.normalize and world == 1),
                           "backend": backend if world > 1 else None}))
     if world > 1:
         dist.barrier()
