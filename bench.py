@@ -43,7 +43,7 @@ def parse():
     p.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only; result is then not the metric)")
     p.add_argument("--weighted", action="store_true", help="U(0,1) edge weights instead of unit weights")
     p.add_argument("--slices", type=int, default=-1,
-                   help="column slices (multiple of 8; 0 = plain row kernel; -1 = isplib_amd.plugin.suggest_slices)")
+                   help="column slices (0 = plain row kernel; -1 = isplib_amd.plugin.suggest_slices)")
     p.add_argument("--schedule", default="tasks", choices=["sliced", "tasks"],
                    help="sliced: (row, slice) segment per wave; tasks: explicit task list (isplib_amd/plan.py)")
     p.add_argument("--chunk", type=int, default=1024, help="tasks: edges per task")

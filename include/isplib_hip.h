@@ -36,6 +36,7 @@ extern "C" {
 #endif
 
 #define ISPLIB_HIP_ABI_VERSION 1
+#define ISPLIB_MAX_SLICES 4096       /* column-slice counts accepted by the sliced / task-list entries: 1..4096 */
 
 /* ---- FusedMM op message (values fixed by csrc/fusedMM.h:18-74) ---------- */
 #define ISPLIB_VOP_COPY_RHS 0x2
@@ -96,8 +97,8 @@ int fusedMM_csr_hip(int32_t imessage, int64_t m, int64_t n, int64_t k,
 /*
  * Column-sliced SpMM: same result as fusedMM_csr_hip, faster when y does not fit an
  * XCD's 4 MiB L2 and rows are long (Reddit-like graphs).  The columns of A (= rows of
- * y) are cut into `slices` (a multiple of 8) equal ranges; every XCD of the MI355X
- * walks all rows of its own slice(s), so its L2 holds 1/slices of y instead of all of
+ * y) are cut into `slices` (1..ISPLIB_MAX_SLICES) equal ranges; every XCD of the MI355X
+ * walks all rows of its own share of the slices, so its L2 holds 1/slices of y instead of all of
  * it; the per-slice partials (workspace) are folded in slice order by a second kernel.
  * No atomics: bitwise reproducible; max/min still resolve ties to the lowest CSR
  * position.  Requires column indices sorted within each row (torch_sparse order; the

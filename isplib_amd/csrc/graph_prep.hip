@@ -123,14 +123,13 @@ __global__ __launch_bounds__(256) void sorted_check_kernel(int64_t m, const int6
 }
 
 // ---- task plan of the task-list SpMM schedule (fusedMM_csr_tasks_hip) ------------------------
-// plan position sp holds slice s = (sp % per_lane) * 8 + sp / per_lane, so XCD lane x owns the
-// contiguous positions [x*per_lane, (x+1)*per_lane).  Rows with fewer than short_row edges are not
-// sliced: their whole row is one segment homed on slice row % slices.
+// Segments are listed slice-major (slice s holds positions [s*m, (s+1)*m)); the eight XCD lanes own contiguous
+// runs of that list cut at equal edge mass (plan_lanes_kernel), so any slice count >= 1 works.  Rows with fewer
+// than short_row edges are not sliced: their whole row is one segment homed on slice row % slices.
 __device__ __forceinline__ void plan_segment(int64_t row, int sp, int slices, int short_row,
                                              const int64_t *__restrict__ pntrb, const int64_t *__restrict__ pntre,
                                              const int64_t *__restrict__ sliceptr, int64_t &b, int64_t &e) {
-   const int per_lane = slices / 8;
-   const int s = (sp % per_lane) * 8 + sp / per_lane;
+   const int s = sp;
    const int64_t rb = pntrb[row], re = pntre[row];
    if (re - rb < short_row) {
       b = rb;
@@ -301,7 +300,7 @@ extern "C" int isplib_spmm_slices_build_hip(int64_t m, int64_t n, int64_t nnz, c
                                             int32_t *unsorted_flag, void *stream) {
    clear_error();
    if (m < 0 || n < 0 || nnz < 0) return fail(ISPLIB_FAIL, "isplib_spmm_slices_build_hip: negative dimension");
-   if (slices < 8 || slices % 8 != 0) return fail(ISPLIB_FAIL, "isplib_spmm_slices_build_hip: slices must be a positive multiple of 8");
+   if (slices < 1 || slices > ISPLIB_MAX_SLICES) return fail(ISPLIB_FAIL, "isplib_spmm_slices_build_hip: slices must be in [1, 4096]");
    hipStream_t st = (hipStream_t)stream;
    if (unsorted_flag) ISPLIB_HIP_TRY(hipMemsetAsync(unsorted_flag, 0, sizeof(int32_t), st));
    if (m == 0) return ISPLIB_SUCCESS;
@@ -333,7 +332,7 @@ extern "C" int isplib_spmm_tasks_count_hip(int64_t m, const int64_t *pntrb, cons
                                            isplib_task_plan_info *info, void *stream) {
    clear_error();
    if (m < 0) return fail(ISPLIB_FAIL, "isplib_spmm_tasks_count_hip: negative dimension");
-   if (slices < 8 || slices % 8 != 0) return fail(ISPLIB_FAIL, "isplib_spmm_tasks_count_hip: slices must be a positive multiple of 8");
+   if (slices < 1 || slices > ISPLIB_MAX_SLICES) return fail(ISPLIB_FAIL, "isplib_spmm_tasks_count_hip: slices must be in [1, 4096]");
    if (chunk < 64 || short_row < 0) return fail(ISPLIB_FAIL, "isplib_spmm_tasks_count_hip: chunk >= 64 and short_row >= 0 required");
    if (!info || !seg_off) return fail(ISPLIB_FAIL, "isplib_spmm_tasks_count_hip: null operand");
    if (m * slices + 1 > 0x7fffffffLL) return fail(ISPLIB_FAIL, "isplib_spmm_tasks_count_hip: m*slices must be < 2^31");

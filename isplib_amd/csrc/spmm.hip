@@ -436,7 +436,7 @@ static int spmm_entry(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t
    a.sliceptr = nullptr; a.slices = 1; a.slice_first = 0; a.slice_count = 0; a.combine = 0;
    a.part_val = nullptr; a.part_idx = nullptr;
    if (sliceptr) {
-      if (slices < 8 || slices % 8 != 0) return fail(ISPLIB_FAIL, "fusedMM_csr_sliced_hip: slices must be a positive multiple of 8");
+      if (slices < 1 || slices > ISPLIB_MAX_SLICES) return fail(ISPLIB_FAIL, "fusedMM_csr_sliced_hip: slices must be in [1, 4096]");
       const size_t need = isplib_spmm_sliced_workspace_bytes(imessage, m, k, slices);
       if (!workspace || workspace_bytes < need) return fail(ISPLIB_NOT_ENOUGH_MEM, "fusedMM_csr_sliced_hip: workspace too small");
       if (((uintptr_t)workspace & 255) != 0) return fail(ISPLIB_FAIL, "fusedMM_csr_sliced_hip: workspace must be 256-byte aligned");

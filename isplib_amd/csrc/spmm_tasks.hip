@@ -14,11 +14,11 @@ namespace isplib {
 // ---- task-list schedule -------------------------------------------------------------------
 // The per-graph plan (isplib_spmm_tasks_* / isplib_amd/plan.py) cuts every non-empty (row, column
 // slice) segment into chunks of at most T edges; a chunk is a TASK = one wave.  Tasks are stored
-// grouped by XCD lane (slices x, x+8, ... belong to lane x = blockIdx % 8), so the L2 affinity of
-// the sliced kernel is kept while
+// slice-major and cut into eight contiguous runs of equal edge mass, one per XCD lane (blockIdx % 8),
+// so the L2 affinity of the sliced kernel is kept while
 //   * hub rows become many independent tasks (no 4-wave cooperative phase, no LDS, no barrier),
 //   * empty segments cost nothing (no wave, no partial plane to write and re-read),
-//   * short rows are not sliced at all (their whole row is one task on lane row % 8).
+//   * short rows are not sliced at all (their whole row is one task, homed on slice row % slices).
 // Task t writes partial[t][0:k]; combine_tasks_kernel folds a row's partials in slice order, then
 // chunk order (= ascending CSR position), so results stay bitwise reproducible and max/min ties
 // still go to the lowest edge id.
@@ -36,7 +36,7 @@ struct TaskArgs {
    const int *task_row;      // [n_tasks]
    const int64_t *task_b;    // [n_tasks] first CSR position
    const int *task_len;      // [n_tasks] edges (<= T)
-   const int *seg_off;       // [slices*m + 1], lane-major (slice', row) -> first task of the segment
+   const int *seg_off;       // [slices*m + 1], slice-major (slice, row) -> first task of the segment
    int64_t lane_off[9];      // tasks of XCD lane x: [lane_off[x], lane_off[x+1])
    int tpw;                  // tasks per wave (consecutive tasks of one lane)
    float *part_val;          // [n_tasks][k]
@@ -103,7 +103,6 @@ __global__ __launch_bounds__(256) void combine_tasks_kernel(const TaskArgs a) {
    const int64_t kv = a.k / VEC;
    const int64_t total = a.m * kv;
    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-   const int per_lane = a.slices / 8;
    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
       const int64_t row = i / kv;
       const int c = (int)(i - row * kv) * VEC;
@@ -112,8 +111,7 @@ __global__ __launch_bounds__(256) void combine_tasks_kernel(const TaskArgs a) {
 #pragma unroll
       for (int v = 0; v < VEC; v++) { acc[v] = identity<OP>(); bi[v] = INT_MAX; }
       for (int s = 0; s < a.slices; s++) {                 // natural slice order = ascending CSR position
-         const int sp = (s & 7) * per_lane + (s >> 3);      // where the plan stored slice s
-         const int *so = a.seg_off + (size_t)sp * (size_t)a.m + row;
+         const int *so = a.seg_off + (size_t)s * (size_t)a.m + row;
          const int t1 = so[1];
          for (int t = so[0]; t < t1; t++) {
             const size_t off = (size_t)t * (size_t)a.k + c;
@@ -237,7 +235,7 @@ static int tasks_entry(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_
       return fail(ISPLIB_NO_OPT_IMPL, "fusedMM_csr_tasks_hip: message outside the SpMM set");
    if (m < 0 || n < 0 || k < 0 || nnz < 0 || n_tasks < 0) return fail(ISPLIB_FAIL, "fusedMM_csr_tasks_hip: negative dimension");
    if (m == 0 || k == 0) return ISPLIB_SUCCESS;
-   if (slices < 8 || slices % 8 != 0) return fail(ISPLIB_FAIL, "fusedMM_csr_tasks_hip: slices must be a positive multiple of 8");
+   if (slices < 1 || slices > ISPLIB_MAX_SLICES) return fail(ISPLIB_FAIL, "fusedMM_csr_tasks_hip: slices must be in [1, 4096]");
    if (k < 4) return fail(ISPLIB_FAIL, "fusedMM_csr_tasks_hip: k >= 4 required (use fusedMM_csr_hip)");
    if (ldy < k || ldz < k) return fail(ISPLIB_FAIL, "fusedMM_csr_tasks_hip: leading dimension smaller than k");
    const unsigned long long yb = (unsigned long long)n * (unsigned long long)ldy * 4ull;

@@ -115,9 +115,7 @@ class RowPartition:
         s = suggest_slices(self.rows, self.ncols_padded, self.nnz, k, reduce in ("max", "min")) if slices is None else slices
         if s <= 0:
             return None
-        s = max(8, (s + 7) // 8 * 8)
-        while s % self.world:
-            s += 8
+        s = (s + self.world - 1) // self.world * self.world
         table, ok = cabi.spmm_slices(self.rowptr, self.col_padded, self.ncols_padded, s)
         if not ok:
             return None

@@ -4,9 +4,10 @@ Built ONCE per graph and slice count, on the device, independent of K.  Every no
 (row, column-slice) segment is cut into chunks of at most ``chunk`` edges; a chunk is a task
 (= one wavefront).  Rows shorter than ``short_row`` are not sliced: the whole row is one segment,
 homed on slice ``row % slices`` so short rows spread over the eight XCD lanes.  Tasks are stored
-lane-major -- the slices x, x+8, ... of XCD lane x are contiguous -- and ``seg_off`` maps
-(slice', row) to the segment's first task so the combine kernel can fold a row's partials in
-ascending CSR order.
+slice-major; ``lane_off`` cuts the list into eight contiguous runs of equal edge mass (one per XCD lane)
+and ``seg_off`` maps (slice, row) to the segment's first task so the combine kernel can fold a row's
+partials in ascending CSR order.  Any slice count from 1 (pure load balancing: hub rows become many
+tasks) to 4096 is accepted.
 
 Everything is built on the device through the C ABI (``isplib_spmm_slices_build_hip``,
 ``isplib_spmm_tasks_count_hip``, ``isplib_spmm_tasks_fill_hip``); this module only owns the buffers.
@@ -28,7 +29,7 @@ class TaskPlan:
     task_row: torch.Tensor     # int32 [n_tasks]
     task_b: torch.Tensor       # int64 [n_tasks]
     task_len: torch.Tensor     # int32 [n_tasks]
-    seg_off: torch.Tensor      # int32 [slices*m + 1], lane-major
+    seg_off: torch.Tensor      # int32 [slices*m + 1], slice-major
     lane_off: list             # 9 host ints
     chunk: int
     short_row: int
@@ -43,7 +44,7 @@ def build_task_plan(rowptr: torch.Tensor, col: torch.Tensor, ncols: int, slices:
     """Slice table -> task counts + prefix (one host round trip for the task count) -> task arrays, all
     through the C ABI.  None when the rows are not column-sorted (the slice table would be meaningless)."""
     import ctypes
-    assert slices >= 8 and slices % 8 == 0
+    assert 1 <= slices <= 4096
     m = rowptr.numel() - 1
     dev = col.device
     if m * slices + col.numel() // chunk + 1 >= 2 ** 31:        # task ids and seg_off are int32

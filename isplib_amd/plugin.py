@@ -22,6 +22,7 @@ Differences from the reference, each a defect there:
 """
 from __future__ import annotations
 
+import json
 import os
 import weakref
 from typing import Optional
@@ -87,34 +88,59 @@ def _storage_of(src, other: torch.Tensor) -> SparseStorage:
 def suggest_slices(m: int, n: int, nnz: int, k: int, minmax: bool = False) -> int:
     """Column-slice count for an M x N, nnz-entry SpMM over K fp32 features (0 = plain kernel).
 
-    Two measured constraints on MI355X (task-list schedule): a slice of the dense
-    operand should be about 8 MB (2x an XCD's 4 MiB L2: the hot rows stay resident) and a row must keep
-    ~20 edges per slice or per-task overhead and the partial rows eat the gain.  Reddit-shaped graph
-    (mean degree 492): K=32 -> 8, K=64 -> 8, K=128 and wider (128-column panels) -> 16, same for max/min;
-    ogbn-products-shaped (mean degree 50) -> 0; anything whose dense operand is under 16 MB -> 0."""
+    Measured on MI355X (scripts/exp_small.py; DESIGN.md section 5, task-list schedule): (i) a slice of the
+    dense operand should be about 7 MB (2x an XCD's 4 MiB L2: the hot rows stay resident); (ii) below that,
+    a few slices still pay because they cut rows into more, shorter tasks -- K/20 of them (6 at K=128, 2 at
+    K=32) -- as long as the graph has work for the whole chip; (iii) a row must keep ~20 edges per slice or
+    per-task overhead and the partial rows eat the gain.  Reddit-shaped graph (mean degree 492): K=32 -> 4,
+    K=64 -> 8, K=128 and wider (128-column panels) -> 16, same for max/min; a tenth of it at K=128 -> 6;
+    ogbn-products-shaped (mean degree 50) or under a million edges -> 0 (plain kernel, no preparation)."""
     del minmax
     if m <= 0 or n <= 0:
         return 0
     if k >= 192:          # the task entry sweeps wide K in 128-column panels: each pass is a K = 128 problem
         k = 128
-    by_cache = (n * k * 4) / float(8 << 20)
     avg_deg = nnz / m
-    if by_cache < 2.0 or avg_deg < 64:
+    if nnz < (1 << 20) or avg_deg < 64:
         return 0
-    s = int(min(by_cache, avg_deg / 20.0) / 8.0 + 0.5) * 8
-    return min(max(s, 8), 64)
+    by_cache = (n * k * 4) / float(7 << 20)
+    s = int(min(max(by_cache, k / 20.0), avg_deg / 20.0) + 0.5)
+    return min(max(s, 1), 64)
+
+
+# Measured choices that outlive the process: {graph signature: {"rows:k:minmax": slice count}}.  Filled by
+# iSpLibPlugin.autotune, written/merged by save_tuning/load_tuning; ISPLIB_TUNE_FILE names a file read at import.
+_tuning_db: dict = {}
+
+
+def graph_signature(storage: SparseStorage) -> str:
+    """Content key of a graph for the persisted tuning table: shape, nnz and the histogram of floor(log2(degree)).
+    Two graphs with the same key get the same schedule, which is all the key is for (one host sync, cached)."""
+    sig = getattr(storage, "_signature", None)
+    if sig is None:
+        deg = storage.rowcount()
+        hist = torch.bincount(torch.log2(deg.clamp(min=1).to(torch.float32)).to(torch.int64)).tolist() if deg.numel() else []
+        m, n = storage.sparse_sizes()
+        sig = storage._signature = f"{m}x{n}:{storage._col.numel()}:" + ",".join(str(c) for c in hist)
+    return sig
 
 
 def choose_slices(storage: SparseStorage, rows: int, k: int, minmax: bool = False) -> int:
     """Slice count for a graph held in `storage`: ISPLIB_SLICES=<n> (0 disables) > a count measured by
-    `iSpLibPlugin.autotune` for this graph and width > the `suggest_slices` rule."""
+    `iSpLibPlugin.autotune` for this graph and width (this process, or a loaded tuning file) > the
+    `suggest_slices` rule."""
     env = os.environ.get("ISPLIB_SLICES")
     if env is not None:
         n = int(env)
-        return n if n >= 8 and n % 8 == 0 else 0
+        return n if 1 <= n <= 4096 else 0
     tuned = storage._tuned.get((rows, k, minmax))
     if tuned is not None:
         return tuned
+    if _tuning_db:
+        tuned = _tuning_db.get(graph_signature(storage), {}).get(f"{rows}:{k}:{int(minmax)}")
+        if tuned is not None:
+            storage._tuned[(rows, k, minmax)] = int(tuned)
+            return int(tuned)
     return suggest_slices(storage._rowptr.numel() - 1, rows, storage._col.numel(), k, minmax)
 
 
@@ -245,9 +271,31 @@ class iSpLibPlugin:
                 continue
         if times:
             s._tuned[key] = min(times, key=times.get)
+            _tuning_db.setdefault(graph_signature(s), {})[f"{key[0]}:{k}:{int(minmax)}"] = s._tuned[key]
         else:
             s._tuned.pop(key, None)
         return times
+
+    @classmethod
+    def save_tuning(cls, path) -> None:
+        """Writes every choice `autotune` has measured (merged over what the file already holds) as JSON."""
+        merged = {}
+        if os.path.exists(path):
+            with open(path) as f:
+                merged = json.load(f)
+        for sig, table in _tuning_db.items():
+            merged.setdefault(sig, {}).update(table)
+        with open(path, "w") as f:
+            json.dump(merged, f, indent=1, sort_keys=True)
+
+    @classmethod
+    def load_tuning(cls, path) -> int:
+        """Merges a file written by `save_tuning`; returns the number of graphs it describes."""
+        with open(path) as f:
+            table = json.load(f)
+        for sig, entries in table.items():
+            _tuning_db.setdefault(sig, {}).update({k: int(v) for k, v in entries.items()})
+        return len(table)
 
     @classmethod
     def is_patched(cls) -> bool:
@@ -256,6 +304,7 @@ class iSpLibPlugin:
     @classmethod
     def clear_cache(cls) -> None:
         _foreign.clear()
+        _tuning_db.clear()
 
 
 def isplib_autotune(fn):
@@ -272,3 +321,7 @@ def isplib_autotune(fn):
     wrapper.__name__ = getattr(fn, "__name__", "wrapper")
     wrapper.__doc__ = getattr(fn, "__doc__", None)
     return wrapper
+
+
+if os.environ.get("ISPLIB_TUNE_FILE") and os.path.exists(os.environ["ISPLIB_TUNE_FILE"]):
+    iSpLibPlugin.load_tuning(os.environ["ISPLIB_TUNE_FILE"])

@@ -177,6 +177,20 @@ class SparseTensor:
     def from_csr(cls, rowptr, col, value=None, sparse_sizes=None, validate=True) -> "SparseTensor":
         return cls(rowptr=rowptr, col=col, value=value, sparse_sizes=sparse_sizes, validate=validate)
 
+    @classmethod
+    def from_mtx(cls, path, device=None) -> "SparseTensor":
+        """Graph from a MatrixMarket file, the input format of the reference's tuner (README.md:147-168)."""
+        from .mtx import read_mtx
+        rowptr, col, value, sizes = read_mtx(path)
+        if device is not None:
+            rowptr, col, value = rowptr.to(device), col.to(device), None if value is None else value.to(device)
+        return cls(rowptr=rowptr, col=col, value=value, sparse_sizes=sizes, validate=False)
+
+    def to_mtx(self, path, comment: str = "") -> None:
+        from .mtx import write_mtx
+        s = self.storage
+        write_mtx(path, s._rowptr, s._col, s._value, s._sparse_sizes, comment)
+
     def csr(self):
         s = self.storage
         return s._rowptr, s._col, s._value

@@ -25,7 +25,7 @@ def _assert_sum_close(got, ref, tol):
     assert np.all(err <= tol[fin]), f"max err/tol = {np.max(err / tol[fin])}"
 
 
-def _run_all(gpu, oracle, rowptr, col, val, x, unit=False, slices=(8, 16)):
+def _run_all(gpu, oracle, rowptr, col, val, x, unit=False, slices=(8, 16, 1, 5)):
     """Every reduction through both boundary entry points: fusedMM_csr_hip and, when the rows
     are column-sorted, fusedMM_csr_sliced_hip for each slice count."""
     from isplib_amd import cabi
@@ -179,7 +179,7 @@ def test_sliced_status_codes(gpu):
     assert cabi.fusedMM_csr_sliced_hip(cabi.MSG_SPMM_SUM, rowptr, col, None, table, 8, y, z, None, small,
                                        check=False) == cabi.NOT_ENOUGH_MEM
     ws = cabi.sliced_workspace("sum", 1, 4, 8, gpu)
-    assert cabi.fusedMM_csr_sliced_hip(cabi.MSG_SPMM_SUM, rowptr, col, None, table, 12, y, z, None, ws,
+    assert cabi.fusedMM_csr_sliced_hip(cabi.MSG_SPMM_SUM, rowptr, col, None, table, 0, y, z, None, ws,
                                        check=False) == cabi.FAIL
     assert cabi.fusedMM_csr_sliced_hip(cabi.MSG_SPMM_SUM, rowptr, col, None, table, 8, y, z, None, ws) == cabi.SUCCESS
     torch.cuda.synchronize()
@@ -273,7 +273,7 @@ def test_task_list_schedule(gpu, oracle_mod, k):
     x = cases.dense(900, k, 3, "integer" if k % 2 else "uniform")
     d_rowptr, d_col, d_val, d_x = (_t(a, gpu) for a in (rowptr, col, val, x))
     tol = cases.sum_tolerance(oracle_mod, rowptr, col, val, x)
-    for slices, chunk, short in ((8, 512, 256), (16, 64, 16), (8, 100, 0), (24, 512, 10 ** 9)):
+    for slices, chunk, short in ((8, 512, 256), (16, 64, 16), (8, 100, 0), (24, 512, 10 ** 9), (1, 128, 64), (3, 256, 0), (13, 512, 128)):
         plan = build_task_plan(d_rowptr, d_col, 900, slices, chunk, short)
         assert plan is not None and plan.lane_off[0] == 0 and plan.lane_off[8] == plan.n_tasks
         assert int(plan.task_len.sum()) == col.size and int(plan.task_len.max()) <= chunk

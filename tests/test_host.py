@@ -241,7 +241,7 @@ def test_task_entry_argument_validation_without_gpu():
         return L.fusedMM_csr_tasks_hip(msg, m, n, k, 0, None, one, one, one, n_tasks, one, one, one, one, slices, lane_off,
                                        one, k, one, k, None, ws, ws_bytes, None)
     assert call(msg=0x11103) == cabi.NO_OPT_IMPL
-    assert call(slices=12) == cabi.FAIL and "multiple of 8" in cabi.last_error()
+    assert call(slices=0) == cabi.FAIL and "[1, 4096]" in cabi.last_error()
     assert call(k=3) == cabi.FAIL and "k >= 4" in cabi.last_error()
     assert call(n=1 << 30, k=8) == cabi.FAIL and "3.5 GiB" in cabi.last_error()
     assert call() == cabi.NOT_ENOUGH_MEM
@@ -249,10 +249,81 @@ def test_task_entry_argument_validation_without_gpu():
     bad = (ctypes.c_int64 * 9)(0, 0, 0, 0, 0, 0, 0, 0, 5)
     assert call(ws=ctypes.c_void_p(256), ws_bytes=1 << 20, lane_off=bad) == cabi.FAIL and "lane_off" in cabi.last_error()
     info = cabi.TaskPlanInfo()
-    assert L.isplib_spmm_tasks_count_hip(4, one, one, one, 12, 1024, 128, one, one, 1 << 20, ctypes.byref(info), None) == cabi.FAIL
+    assert L.isplib_spmm_tasks_count_hip(4, one, one, one, 0, 1024, 128, one, one, 1 << 20, ctypes.byref(info), None) == cabi.FAIL
     assert L.isplib_spmm_tasks_count_hip(4, one, one, one, 8, 8, 128, one, one, 1 << 20, ctypes.byref(info), None) == cabi.FAIL
     assert L.isplib_spmm_tasks_workspace_bytes(cabi.MSG_SPMM_MAX, 10, 16) >= 2 * 10 * 16 * 4
-    assert L.isplib_spmm_slices_build_hip(4, 4, 0, one, one, None, 9, one, None, None) == cabi.FAIL
+    assert L.isplib_spmm_slices_build_hip(4, 4, 0, one, one, None, 4097, one, None, None) == cabi.FAIL
     assert L.fusedMM_csr_sliced_phase_hip(cabi.MSG_SPMM_SUM, 4, 4, 8, 0, None, one, one, one, one, 8, 8, 4, 1, one, 8, one, 8,
                                           None, ctypes.c_void_p(256), 1 << 20, None) == cabi.FAIL
     assert "slice range" in cabi.last_error()
+
+
+# ---- MatrixMarket I/O (the reference tuner's graph format, README.md:147-168) -------------------
+
+def test_mtx_round_trip_and_readme_case(tmp_path):
+    import scipy.io
+    import scipy.sparse as sp
+    from isplib_amd import mtx
+    from tests import cases
+    rowptr, col, val, *_ = cases.readme_case()
+    path = tmp_path / "readme.mtx"
+    mtx.write_mtx(path, torch.from_numpy(rowptr), torch.from_numpy(col), torch.from_numpy(val), (3, 3), "README.md:105-116")
+    rp, cl, vl, sizes = mtx.read_mtx(path)
+    assert sizes == (3, 3) and rp.tolist() == rowptr.tolist() and cl.tolist() == col.tolist()      # duplicate (0,0) kept
+    assert vl.tolist() == val.tolist()
+    # pattern files: unit weights
+    mtx.write_mtx(path, torch.from_numpy(rowptr), torch.from_numpy(col), None, (3, 3))
+    rp, cl, vl, _ = mtx.read_mtx(path)
+    assert vl is None and cl.tolist() == col.tolist()
+    # a file written by scipy (symmetric storage, comments) expands to both triangles, in (row, col) order
+    a = sp.random(40, 40, 0.1, random_state=3, format="coo")
+    a = (a + a.T).tocoo()
+    scipy.io.mmwrite(str(tmp_path / "sym.mtx"), a, comment="written by scipy", symmetry="symmetric")
+    rp, cl, vl, sizes = mtx.read_mtx(tmp_path / "sym.mtx")
+    want = a.tocsr()
+    want.sort_indices()
+    assert sizes == (40, 40) and rp.tolist() == want.indptr.tolist() and cl.tolist() == want.indices.tolist()
+    assert np.allclose(vl.numpy(), want.data, rtol=1e-6)
+
+
+def test_mtx_rejects_what_it_cannot_represent(tmp_path):
+    from isplib_amd import mtx
+    bad = tmp_path / "bad.mtx"
+    bad.write_text("%%MatrixMarket matrix array real general\n2 2\n1\n2\n3\n4\n")
+    with pytest.raises(ValueError, match="coordinate"):
+        mtx.read_mtx(bad)
+    bad.write_text("%%MatrixMarket matrix coordinate complex general\n2 2 1\n1 1 1 0\n")
+    with pytest.raises(ValueError, match="field"):
+        mtx.read_mtx(bad)
+    bad.write_text("%%MatrixMarket matrix coordinate real general\n2 2 2\n1 1 1.0\n")
+    with pytest.raises(ValueError, match="promises"):
+        mtx.read_mtx(bad)
+    bad.write_text("%%MatrixMarket matrix coordinate real general\n2 2 1\n3 1 1.0\n")
+    with pytest.raises(ValueError, match="outside"):
+        mtx.read_mtx(bad)
+    empty = tmp_path / "empty.mtx"
+    empty.write_text("%%MatrixMarket matrix coordinate pattern general\n% nothing\n3 4 0\n")
+    rp, cl, vl, sizes = mtx.read_mtx(empty)
+    assert sizes == (3, 4) and rp.tolist() == [0, 0, 0, 0] and cl.numel() == 0 and vl is None
+
+
+def test_tuning_table_persists_by_graph_signature(tmp_path):
+    from isplib_amd import plugin
+    from isplib_amd.sparse import SparseStorage
+    rowptr = torch.tensor([0, 2, 2, 5], dtype=torch.int64)
+    col = torch.tensor([0, 1, 0, 1, 2], dtype=torch.int64)
+    st = SparseStorage(rowptr, col, None, (3, 3))
+    sig = plugin.graph_signature(st)
+    assert sig == "3x3:5:1,2"                  # degrees 2, 0, 3 -> floor(log2(max(d,1))) = 1, 0, 1
+    plugin._tuning_db.clear()
+    plugin._tuning_db[sig] = {"3:128:0": 16}
+    path = tmp_path / "tune.json"
+    plugin.iSpLibPlugin.save_tuning(path)
+    plugin._tuning_db.clear()
+    assert plugin.choose_slices(st, 3, 128) == 0                      # the rule: tiny graph, plain kernel
+    assert plugin.iSpLibPlugin.load_tuning(path) == 1
+    assert plugin.choose_slices(st, 3, 128) == 16                     # the persisted measurement wins
+    same_shape = SparseStorage(rowptr.clone(), col.clone(), None, (3, 3))
+    assert plugin.choose_slices(same_shape, 3, 128) == 16             # keyed by content, not by object or pointer
+    assert plugin.choose_slices(same_shape, 3, 64) == 0
+    plugin._tuning_db.clear()
