@@ -58,8 +58,8 @@ class RowPartition:
         self.col = col[lo:hi].contiguous()
         self.val = None if val is None else val[lo:hi].contiguous()
         sizes = [self.x_cuts[p + 1] - self.x_cuts[p] for p in range(world)]
-        # shard pitch of the gather buffer; a multiple of 192 so that any slice count that is a multiple
-        # of `world` (8..64 slices) cuts every shard into whole column slices (spmm_overlapped)
+        # shard pitch of the gather buffer; a multiple of 192 so that a shard can be cut into q = 1, 2, 3, 4,
+        # 6, 8, 12, 16, ... whole column slices (spmm_overlapped runs world * q slices)
         self.max_rows = (max(max(sizes), 1) + 191) // 192 * 192
         self.x_rows = sizes[rank]
         xc = torch.tensor(self.x_cuts, dtype=torch.int64, device=col.device)
@@ -115,7 +115,10 @@ class RowPartition:
         s = suggest_slices(self.rows, self.ncols_padded, self.nnz, k, reduce in ("max", "min")) if slices is None else slices
         if s <= 0:
             return None
-        s = (s + self.world - 1) // self.world * self.world
+        q = (s + self.world - 1) // self.world           # slices per shard: a divisor of the 192-row pitch unit
+        while 192 % q:
+            q += 1
+        s = q * self.world
         table, ok = cabi.spmm_slices(self.rowptr, self.col_padded, self.ncols_padded, s)
         if not ok:
             return None
@@ -151,6 +154,63 @@ class RowPartition:
         return out
 
 
+    # ---- pipelined form: K is cut into panels, panel c+1 travels while panel c is aggregated -------
+
+    def task_plan(self, slices: int, chunk: int = 1024, short_row: int = 128):
+        """Task plan (isplib_amd.plan) of this rank's rows over the padded gather layout; None if unsorted."""
+        from .plan import build_task_plan
+        return build_task_plan(self.rowptr, self.col_padded, self.ncols_padded, slices, chunk, short_row)
+
+    def pipeline_state(self, k: int, panels: int, reduce: str = "sum", tplan=None):
+        """Operands of `spmm_pipelined` for width k: panel bounds (multiples of 4 columns), one send and one
+        gather buffer per panel, a task plan whose slice count suits the PANEL width (built here unless given;
+        None -> no plan possible) and the task workspace of the widest panel."""
+        from .plugin import suggest_slices
+        dev = self.col.device
+        w = ((k + panels - 1) // panels + 3) // 4 * 4
+        if tplan is None:
+            s = max(1, suggest_slices(self.rows, self.ncols_padded, self.nnz, w, reduce in ("max", "min")))
+            plans = self.__dict__.setdefault("_task_plans", {})
+            if s not in plans:
+                plans[s] = self.task_plan(s)
+            tplan = plans[s]
+            if tplan is None:
+                return None
+        bounds = [(c0, min(k, c0 + w)) for c0 in range(0, k, w)]
+        if bounds[-1][1] - bounds[-1][0] < 4 and len(bounds) > 1:       # the kernels need >= 4 columns
+            last = bounds.pop()
+            bounds[-1] = (bounds[-1][0], last[1])
+        send = [torch.zeros((self.max_rows, c1 - c0), dtype=torch.float32, device=dev) for c0, c1 in bounds]
+        recv = [torch.empty((self.ncols_padded, c1 - c0), dtype=torch.float32, device=dev) for c0, c1 in bounds]
+        return bounds, send, recv, tplan, tplan.workspace(reduce, max(c1 - c0 for c0, c1 in bounds))
+
+    def spmm_pipelined(self, x_shard: torch.Tensor, out: torch.Tensor, state, reduce: str = "sum",
+                       arg: Optional[torch.Tensor] = None):
+        """The all-gather of X cut into column panels: every panel is its own collective, issued up front, and
+        the task-list SpMM of panel c runs while panels c+1.. are still on the links.  Columns are independent
+        in an SpMM: the result is bitwise that of the task-list SpMM run panel by panel (max/min: also bitwise the
+        unpanelled call; sums can differ from it in the last bits because a wave's edge-slot count follows the
+        panel width).  A K = 128 aggregation costs the same as two K = 64 ones on this hardware (DESIGN.md
+        section 5), so the panels are free on the compute side and hide all but the first panel's transfer."""
+        from . import cabi
+        bounds, send, recv, tplan, work = state
+        msg = cabi.MESSAGE[reduce]
+        handles = []
+        for (c0, c1), s_buf, r_buf in zip(bounds, send, recv):
+            s_buf[: x_shard.size(0)].copy_(x_shard[:, c0:c1])
+            if self.world > 1:
+                handles.append(dist.all_gather_into_tensor(r_buf, s_buf, group=self.group, async_op=True))
+            else:
+                r_buf.copy_(s_buf)
+                handles.append(None)
+        for (c0, c1), r_buf, handle in zip(bounds, recv, handles):
+            if handle is not None:
+                handle.wait()
+            cabi.fusedMM_csr_tasks_hip(msg, self.rowptr, self.col_padded, self.val, tplan, r_buf, out[:, c0:c1],
+                                       None if arg is None else arg[:, c0:c1], work)
+        return out
+
+
 class _DistSpMM(torch.autograd.Function):
     """out[R_p] = A[R_p, :] @ allgather(X);  dX[R_p] = A^T[R_p, :] @ allgather(dY)  (csrc/fusedmm.cpp:285)."""
 
@@ -182,21 +242,45 @@ class DistGraph:
 
 
 def _spmm_auto(self, x_local: torch.Tensor) -> torch.Tensor:
-    """Sum-SpMM of this partition on unpadded local rows [x_rows, K]: pads into the shard pitch, picks the
-    overlapped sliced schedule when the slice rule asks for slices, else gather + plain kernel."""
+    """Sum-SpMM of this partition on unpadded local rows [x_rows, K]: pads into the shard pitch, then
+    ISPLIB_DIST_SCHEDULE = tasks (default: one all-gather, task-list SpMM) | overlap (local column slices
+    during the all-gather) | pipelined (two column panels, panel 2 travels while panel 1 is aggregated).
+    Whatever the schedule, a graph for which the slice rule says 0 runs gather + the plain kernel."""
+    import os
+    from . import cabi
+    from .plugin import suggest_slices
     k = x_local.size(1)
+    mode = os.environ.get("ISPLIB_DIST_SCHEDULE", "tasks")
+    if mode not in ("tasks", "overlap", "pipelined"):
+        raise ValueError(f"ISPLIB_DIST_SCHEDULE={mode!r}: expected tasks | overlap | pipelined")
     cache = self.__dict__.setdefault("_auto", {})
-    if k not in cache:
-        cache[k] = (self.plan(k, "sum"), self.gather_buffer(k, x_local.device),
-                    torch.zeros((self.max_rows, k), dtype=torch.float32, device=x_local.device))
-    plan, buf, shard = cache[k]
+    key = (k, mode)
+    if key not in cache:
+        s = suggest_slices(self.rows, self.ncols_padded, self.nnz, k)
+        ops = None
+        if s > 0 and mode == "overlap":
+            ops = self.plan(k, "sum", slices=s)
+        elif s > 0 and mode == "pipelined" and k >= 32:
+            ops = self.pipeline_state(k, 2, "sum")
+        elif s > 0:
+            plans = self.__dict__.setdefault("_task_plans", {})
+            if s not in plans:
+                plans[s] = self.task_plan(s)
+            ops = None if plans[s] is None else (plans[s], plans[s].workspace("sum", k))
+        cache[key] = (ops, self.gather_buffer(k, x_local.device),
+                      torch.zeros((self.max_rows, k), dtype=torch.float32, device=x_local.device))
+    ops, buf, shard = cache[key]
     shard[: self.x_rows].copy_(x_local)
     out = torch.empty((self.rows, k), dtype=torch.float32, device=x_local.device)
-    if plan is not None:
-        return self.spmm_overlapped(shard, buf, out, plan, "sum")
-    from . import cabi
+    if ops is not None and mode == "overlap":
+        return self.spmm_overlapped(shard, buf, out, ops, "sum")
+    if ops is not None and mode == "pipelined" and k >= 32:
+        return self.spmm_pipelined(shard, out, ops, "sum")
     self.all_gather(shard, buf)
-    cabi.fusedMM_csr_hip(cabi.MSG_SPMM_SUM, self.rowptr, self.col_padded, self.val, buf, out)
+    if ops is not None:
+        cabi.fusedMM_csr_tasks_hip(cabi.MSG_SPMM_SUM, self.rowptr, self.col_padded, self.val, ops[0], buf, out, None, ops[1])
+    else:
+        cabi.fusedMM_csr_hip(cabi.MSG_SPMM_SUM, self.rowptr, self.col_padded, self.val, buf, out)
     return out
 
 

@@ -30,8 +30,9 @@ rowptr, col = cases.random_csr(n, n, 90.0, seed=5, empty_rows=(0, 1500), hub=(7,
 val = cases.weights(col.size, 4)
 x, g = cases.dense(n, k, 3), cases.dense(n, k, 5)
 t = lambda a: torch.from_numpy(a).to(dev)
-for slices in ("0", "8"):                       # plain gather-then-SpMM, then the overlapped sliced schedule
-    os.environ["ISPLIB_SLICES"] = slices
+# plain gather-then-SpMM, then the three schedules of a sliced graph (ISPLIB_DIST_SCHEDULE)
+for slices, mode in (("0", "tasks"), ("8", "tasks"), ("8", "overlap"), ("6", "pipelined")):
+    os.environ["ISPLIB_DIST_SCHEDULE"] = mode
     import isplib_amd.plugin as plugin
     plugin.suggest_slices = (lambda *a, **kw: int(slices))
     graph = DistGraph(t(rowptr), t(col), t(val), n, rank, world)
@@ -42,10 +43,42 @@ for slices in ("0", "8"):                       # plain gather-then-SpMM, then t
     torch.cuda.synchronize()
     ref, _ = oracle.spmm_fw(rowptr, col, val, x, "sum")
     mag, _ = oracle.spmm_fw(rowptr, col, np.abs(val), np.abs(x), "sum")
-    assert np.all(np.abs(out.detach().cpu().numpy() - ref[r0:r1]) <= 1e-5 * mag[r0:r1] + 1e-30), slices
+    assert np.all(np.abs(out.detach().cpu().numpy() - ref[r0:r1]) <= 1e-5 * mag[r0:r1] + 1e-30), (slices, mode)
     dref = oracle.spmm_sum_bw(rowptr, col, val, n, g)
     dmag = oracle.spmm_sum_bw(rowptr, col, np.abs(val), n, np.abs(g))
-    assert np.all(np.abs(xs.grad.cpu().numpy() - dref[r0:r1]) <= 1e-5 * dmag[r0:r1] + 1e-30), slices
+    assert np.all(np.abs(xs.grad.cpu().numpy() - dref[r0:r1]) <= 1e-5 * dmag[r0:r1] + 1e-30), (slices, mode)
+# pipelined K-panel schedule: bitwise the task-list SpMM run panel by panel after one gather (max/min: also
+# bitwise the unpanelled call; sums differ from it in the last bits, the slots per wave depend on the width)
+from isplib_amd import cabi
+from isplib_amd.dist import RowPartition
+part = RowPartition(t(rowptr), t(col), t(val), n, rank, world)
+tplan = part.task_plan(6, chunk=128, short_row=32)
+for kk in (32, 41):
+    xk = cases.dense(n, kk, 9)
+    shard = part.shard(t(xk))
+    buf = part.gather_buffer(kk)
+    for red in ("sum", "max"):
+        part.all_gather(shard, buf)
+        want, want_arg = cabi.spmm_tasks(part.rowptr, part.col_padded, part.val, tplan, buf, red)
+        for panels in (2, 3):
+            state = part.pipeline_state(kk, panels, red, tplan)
+            out = torch.zeros((part.rows, kk), device=dev)
+            arg = torch.zeros((part.rows, kk), dtype=torch.int64, device=dev) if red == "max" else None
+            part.spmm_pipelined(shard, out, state, red, arg)
+            part.spmm_pipelined(shard, out, state, red, arg)      # buffers are reused across steps
+            torch.cuda.synchronize()
+            by_panel = torch.cat([cabi.spmm_tasks(part.rowptr, part.col_padded, part.val, tplan, buf[:, c0:c1].contiguous(), red)[0]
+                                  for c0, c1 in state[0]], 1)
+            assert torch.equal(out, by_panel), (kk, red, panels)
+            if red == "max":
+                assert torch.equal(out, want) and torch.equal(arg, want_arg), (kk, red, panels)
+            else:
+                mag, _ = oracle.spmm_fw(rowptr, col, np.abs(val), np.abs(xk), "sum")
+                lim = torch.from_numpy(mag[part.row0:part.row0 + part.rows]).to(dev) * 1e-5 + 1e-30
+                assert bool(((out - want).abs() <= lim).all()), (kk, red, panels)
+        ref, _ = oracle.spmm_fw(rowptr, col, val, xk, red)
+        if red == "max":
+            assert np.array_equal(want.cpu().numpy(), ref[part.row0:part.row0 + part.rows])
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
