@@ -43,6 +43,33 @@ template <> __device__ __forceinline__ float dot_chunk<4>(const float *p, const 
 }
 template <> __device__ __forceinline__ float dot_chunk<1>(const float *p, const float *q) { return p[0] * q[0]; }
 
+// U per-edge partial dot products per lane, each to be summed over the LPR lanes of its slot.  Instead of
+// log2(LPR) shuffles per value, the first log2(U) halving steps also halve the number of live values (a lane
+// keeps the values whose index bit matches its own lane bit and hands the others over), so U values cost
+// U-1 + log2(LPR) - log2(U) shuffles instead of U * log2(LPR).  Returns the finished sum of edge `mine`
+// (valid in every lane of the owning LPR/U-lane group).
+template <int U, int LPR>
+__device__ __forceinline__ float reduce_transposed(float (&d)[U], int lc, int &mine) {
+   static_assert(U == 1 || U == 2 || U == 4 || U == 8, "U must be a power of two <= 8");
+   static_assert(LPR >= U, "slot narrower than the values to transpose");
+   mine = 0;
+   int o = LPR / 2;
+#pragma unroll
+   for (int n = U; n > 1; n >>= 1, o >>= 1) {
+      const bool hi = (lc & o) != 0;
+      mine |= hi ? (n >> 1) : 0;
+#pragma unroll
+      for (int i = 0; i < n / 2; i++) {
+         const float send = hi ? d[i] : d[i + n / 2];
+         const float keep = hi ? d[i + n / 2] : d[i];
+         d[i] = keep + __shfl_xor(send, o);
+      }
+   }
+#pragma unroll
+   for (; o >= 1; o >>= 1) d[0] += __shfl_xor(d[0], o);
+   return d[0];
+}
+
 struct SddmmArgs {
    int64_t m, k;
    const int64_t *indx, *pntrb, *pntre;
@@ -81,21 +108,17 @@ __device__ __forceinline__ void sddmm_edges(const SddmmArgs &a, int64_t row, int
                for (int64_t c = (int64_t)lc * VEC; c < a.k; c += LPR * VEC) acc += dot_chunk<VEC>(yr + c, gr + c);
             part[u] = acc;
          }
-#pragma unroll
-         for (int u = 0; u < U; u++) {
-            float t = part[u];
-#pragma unroll
-            for (int off = LPR / 2; off >= 1; off >>= 1) t += __shfl_xor(t, off);
-            const int ei = s + u * G + g;
-            if (lc == 0 && ei < cnt) a.dval[base + ei] = t * scale;
-         }
+         int mine;
+         const float t = reduce_transposed<U, LPR>(part, lc, mine);
+         const int ei = s + mine * G + g;
+         if ((lc & (LPR / U - 1)) == 0 && ei < cnt) a.dval[base + ei] = t * scale;
       }
    }
 }
 
 template <int VEC, int LPR, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void sddmm_csr_kernel(const SddmmArgs a) {
-   const int wave = threadIdx.x >> 6;
+   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: task/row bookkeeping lives in SGPRs
    const int64_t row0 = (int64_t)blockIdx.x * WAVES;
    const int64_t row = row0 + wave;
    if (row < a.m) {
@@ -146,9 +169,9 @@ struct SddmmTaskArgs {
 };
 
 template <int LPR, int NCH, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void sddmm_task_kernel(const SddmmTaskArgs a) {
+__global__ __launch_bounds__(WAVES * 64, NCH == 1 ? 8 : 1) void sddmm_task_kernel(const SddmmTaskArgs a) {
    constexpr int G = 64 / LPR, U = 4;
-   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
    const int g = lane / LPR, lc = lane % LPR;
    const unsigned xcd = blockIdx.x & 7u, within = blockIdx.x >> 3;
    const int64_t t = a.lane_off[xcd] + (int64_t)within * WAVES + wave;
@@ -178,6 +201,7 @@ __global__ __launch_bounds__(WAVES * 64) void sddmm_task_kernel(const SddmmTaskA
       const unsigned off_l = p < e ? (unsigned)a.indx[p] * ldyb : SD_BUF_OOB;
       const int64_t left = e - base;
       const int cnt = left < 64 ? (int)left : 64;
+#pragma unroll 1
       for (int s = 0; s < cnt; s += G * U) {
          sd_v4i_t yv[U][NCH];
 #pragma unroll
@@ -189,18 +213,19 @@ __global__ __launch_bounds__(WAVES * 64) void sddmm_task_kernel(const SddmmTaskA
                yv[u][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)o, 0, 0);
             }
          }
+         float d[U];
 #pragma unroll
          for (int u = 0; u < U; u++) {
-            float d = 0.0f;
+            d[u] = 0.0f;
 #pragma unroll
             for (int j = 0; j < NCH; j++)
 #pragma unroll
-               for (int v = 0; v < 4; v++) d = fmaf(__int_as_float(yv[u][j][v]), gv[j][v], d);
-#pragma unroll
-            for (int o = LPR / 2; o >= 1; o >>= 1) d += __shfl_xor(d, o);
-            const int ei = s + u * G + g;
-            if (lc == 0 && ei < cnt) a.dval[base + ei] = d * scale;
+               for (int v = 0; v < 4; v++) d[u] = fmaf(__int_as_float(yv[u][j][v]), gv[j][v], d[u]);
          }
+         int mine;
+         const float sum = reduce_transposed<U, LPR>(d, lc, mine);
+         const int ei = s + mine * G + g;
+         if ((lc & (LPR / U - 1)) == 0 && ei < cnt) a.dval[base + ei] = sum * scale;
       }
    }
 }

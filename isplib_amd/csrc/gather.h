@@ -238,16 +238,21 @@ __device__ __forceinline__ void slot_reduce(float (&acc)[NCH][VEC], int (&bi)[NC
 // gathers issued back to back per slot (U) and the occupancy the register allocator is held to; both
 // measured on MI355X: the unit-weight sum kernel fits 8 waves/SIMD at U = 8 (62 VGPRs), the weighted
 // one needs U = 6 for 7, and max/min carry (value, id) pairs, so U = 4 keeps them at 8.
-template <int OP, int NCH, int ADDR> constexpr int unroll_of() {
+template <int OP, int NCH, int ADDR, bool TASK = false, int LPR = 64> constexpr int unroll_of() {
    if (NCH > 1) return (8 / NCH) > 2 ? 8 / NCH : 2;
+   if (TASK) {          // the task kernel keeps less state per wave: 8 gathers in flight fit 64 VGPRs almost everywhere
+      if (LPR == 8 && (OP != OP_ADD || ADDR == 2)) return 6;
+      if (LPR == 16 && OP != OP_ADD && ADDR == 2) return 6;
+      if (LPR >= 32 && OP != OP_ADD) return 4;      // measured: 8 is no faster unit-weight and 14 % slower weighted
+      return 8;
+   }
    if (ADDR != 0 && OP != OP_ADD) return 4;
    if (ADDR == 2) return 6;
    return 8;
 }
 template <int OP, int LPR, int NCH, int ADDR> constexpr int min_waves_of() {
    if (NCH != 1 || ADDR == 0) return 1;
-   if (OP != OP_ADD) return 8;
-   return (ADDR == 1 && LPR >= 16) ? 8 : 7;
+   return 8;
 }
 
 // tuning knobs (isplib_hip_tune), defined in spmm.hip

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(WAVES * 64, (min_waves_of<OP, LPR, NCH, ADDR>())) v
    __shared__ int sh_idx[OP == OP_ADD ? 1 : WAVES][OP == OP_ADD ? 1 : PANEL];
 
    const int lane = threadIdx.x & 63;
-   const int wave = threadIdx.x >> 6;
+   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: task/row bookkeeping lives in SGPRs
    const int g = lane / LPR, lc = lane % LPR;
    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
        const_cast<float *>(a.y), 0, ADDR ? (int)a.ybytes : 0, 0x00020000);   // kernarg-only: provably wave-uniform

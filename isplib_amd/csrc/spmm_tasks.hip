@@ -50,10 +50,10 @@ struct TaskArgs {
 template <int OP, int LPR, int NCH, int WAVES, int ADDR>
 __global__ __launch_bounds__(WAVES * 64, (min_waves_of<OP, LPR, NCH, ADDR>())) void spmm_task_kernel(const TaskArgs a) {
    constexpr int VEC = 4;
-   constexpr int U = unroll_of<OP, NCH, ADDR>();
+   constexpr int U = unroll_of<OP, NCH, ADDR, true, LPR>();
    constexpr int PANEL = LPR * VEC * NCH;
    const int lane = threadIdx.x & 63;
-   const int wave = threadIdx.x >> 6;
+   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: task/row bookkeeping lives in SGPRs
    const int g = lane / LPR, lc = lane % LPR;
    const unsigned xcd = blockIdx.x & 7u, within = blockIdx.x >> 3;
    const int64_t t0 = a.lane_off[xcd] + ((int64_t)within * WAVES + wave) * a.tpw;
