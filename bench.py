@@ -114,6 +114,16 @@ def main():
         n, target = synth.SHAPES[a.workload][0], synth.SHAPES[a.workload][1]
         n, target = max(64, int(n * a.scale)), int(target * a.scale) // 2 * 2
         rowptr, col = (synth.rmat_csr if a.generator == "rmat" else synth.uniform_csr)(n, target, device=dev)
+    if world > 1:
+        # every rank generated the graph from the same seed; rank 0's copy is made authoritative anyway, so that
+        # the partition (row cuts, shard pitch, collective sizes) can never differ between ranks
+        shape = torch.tensor([rowptr.numel(), col.numel()], dtype=torch.int64, device=dev)
+        dist.broadcast(shape, 0)
+        if rank != 0 and (int(shape[0]) != rowptr.numel() or int(shape[1]) != col.numel()):
+            rowptr = torch.empty(int(shape[0]), dtype=torch.int64, device=dev)
+            col = torch.empty(int(shape[1]), dtype=torch.int64, device=dev)
+        dist.broadcast(rowptr, 0)
+        dist.broadcast(col, 0)
     nnz = col.numel()
     x = synth.features(n, k, device=dev)
     val = synth.edge_weights(nnz, device=dev) if a.weighted else None
