@@ -132,9 +132,12 @@ int main() {
    HIP_OK(hipStreamSynchronize(st));
    if (!check_max("fusedMM_csr_tasks_hip")) return 1;
 
-   // 3. error behaviour: a FusedMM message outside the SpMM set is refused with the reference's status code
-   if (fusedMM_csr_hip(0x11103, m, n, k, 1.0f, nnz, m, n, d_val, d_col, d_rowptr, d_rowptr + 1, nullptr, k, d_x, k, 0.0f,
+   // 3. error behaviour: the reference's status codes -- a flag value csrc/fusedMM.h does not define, and a
+   //    user-defined stage (function pointers cannot cross to the device; see fusedMM_csr_udef_hip's menu)
+   if (fusedMM_csr_hip(0x11108, m, n, k, 1.0f, nnz, m, n, d_val, d_col, d_rowptr, d_rowptr + 1, nullptr, k, d_x, k, 0.0f,
                        d_out, k, nullptr, st) != ISPLIB_NO_OPT_IMPL) { printf("expected NO_OPT_IMPL\n"); return 1; }
+   if (fusedMM_csr_hip(0x1110F, m, n, k, 1.0f, nnz, m, n, d_val, d_col, d_rowptr, d_rowptr + 1, nullptr, k, d_x, k, 0.0f,
+                       d_out, k, nullptr, st) != ISPLIB_UNDEFINED_USER_FUNCTION) { printf("expected UNDEFINED_USER_FUNCTION\n"); return 1; }
    printf("c_abi_demo ok: m=%lld nnz=%lld k=%lld, %lld tasks; sum within 1e-5, max/arg bit-exact, both entry points\n",
           (long long)m, (long long)nnz, (long long)k, (long long)info.n_tasks);
    return 0;

@@ -57,7 +57,8 @@ extern "C" {
 #define ISPLIB_SUCCESS         0
 #define ISPLIB_FAIL            1    /* bad argument                            */
 #define ISPLIB_NOT_ENOUGH_MEM (-1)  /* workspace too small                      */
-#define ISPLIB_NO_OPT_IMPL     128  /* message outside the SpMM set             */
+#define ISPLIB_UNDEFINED_USER_FUNCTION 64 /* a *_UDEF stage without a built-in function (csrc/fusedMM.h:113) */
+#define ISPLIB_NO_OPT_IMPL     128  /* message outside the implemented set      */
 #define ISPLIB_HIP_ERROR       256  /* a HIP call failed; see isplib_hip_last_error */
 
 int         isplib_hip_abi_version(void);
@@ -82,6 +83,8 @@ const char *isplib_hip_last_error(void);   /* thread-local, "" if none */
  *     leading dimension as z) holds ABSOLUTE CSR positions; may be NULL.
  *   - x/ldx/alpha/rows/cols are accepted and ignored, as in the reference.
  * Requirements: n < 2^31, every row's degree < 2^31, ldy >= k, ldz >= k.
+ * Any other message word is handed to the generic pipeline below
+ * (fusedMM_csr_udef_hip with no user function).
  */
 int fusedMM_csr_hip(int32_t imessage, int64_t m, int64_t n, int64_t k,
                     float alpha, int64_t nnz, int64_t rows, int64_t cols,
@@ -89,10 +92,44 @@ int fusedMM_csr_hip(int32_t imessage, int64_t m, int64_t n, int64_t k,
                     const int64_t *indx /*[dev] nnz*/,
                     const int64_t *pntrb /*[dev] m*/,
                     const int64_t *pntre /*[dev] m*/,
-                    const float *x /*ignored*/, int64_t ldx,
+                    const float *x /*[dev] m x ldx; only read by non-SpMM messages*/, int64_t ldx,
                     const float *y /*[dev] n x ldy*/, int64_t ldy, float beta,
                     float *z /*[dev] m x ldz*/, int64_t ldz,
                     int64_t *z_arg /*[dev] m x ldz | NULL*/, void *stream);
+
+/*
+ * The generic five-stage FusedMM pipeline (csrc/fusedMM.h:18-74) for message words other than
+ * the four SpMM ones -- the SDDMM-fused patterns of the FusedMM paper (graph embedding with a
+ * sigmoid or t-distribution kernel, score-then-aggregate attention).  The reference never sends
+ * them (csrc/fusedmm.cpp:168-186) and the library that defines them is absent from its tree, so
+ * the semantics are restated here and in oracle/fusedmm_oracle.c; nothing pins them.
+ * For row i and stored entry e = (i, j), a = val[e] (1 if val is NULL), per column c:
+ *   VOP  T[c] = COPY_LHS x[i,c] | COPY_RHS y[j,c] | ADD x+y | SUBL x-y | SUBR y-x | MAX | MIN
+ *   ROP  s    = NOOP 1 | DOT sum x[i,c]*T[c] | ADD_LHS sum x | ADD_RHS sum T | NORML sum x^2 | NORMR sum T^2
+ *   SOP  s'   = NOOP s | COPY a | UDEF f(s): C function pointers cannot cross to the device, so the
+ *               user function is chosen from a built-in menu (`sop_udef`, `sop_param`)
+ *   VSC  T'[c]= NOOP T[c] | MUL s'*T[c] | ADD s'+T[c] | MEAN (MUL, the row divided by max(deg,1))
+ *   AOP  z[i,c] ADD += | MAX | MIN (z_arg as in fusedMM_csr_hip) T'[c]
+ * VOP/ROP/VSC/AOP_UDEF and SOP_UDEF without a menu entry return ISPLIB_UNDEFINED_USER_FUNCTION,
+ * flag values the header does not define ISPLIB_NO_OPT_IMPL.  k <= 1024; same write-only z,
+ * beta == 0 and tie rules as fusedMM_csr_hip.  One wave per row, no atomics.
+ */
+enum isplib_sop_udef {
+   ISPLIB_SOP_NONE = 0,
+   ISPLIB_SOP_SIGMOID = 1,            /* 1 / (1 + exp(-s))                                  */
+   ISPLIB_SOP_ONE_MINUS_SIGMOID = 2,  /* 1 - sigmoid(s): the gradient scale of sigmoid embedding */
+   ISPLIB_SOP_TDIST = 3,              /* 1 / (1 + s): t-distribution kernel on s = |y_j - x_i|^2 */
+   ISPLIB_SOP_SCALE = 4,              /* sop_param * s                                       */
+   ISPLIB_SOP_EXP = 5,                /* exp(s)                                              */
+   ISPLIB_SOP_LEAKY_EXP = 6           /* exp(s > 0 ? s : sop_param * s): un-normalised GAT score */
+};
+int fusedMM_csr_udef_hip(int32_t imessage, int64_t m, int64_t n, int64_t k, float alpha, int64_t nnz,
+                         int64_t rows, int64_t cols, const float *val /*[dev] nnz | NULL*/,
+                         const int64_t *indx, const int64_t *pntrb, const int64_t *pntre,
+                         const float *x /*[dev] m x ldx | NULL if unused*/, int64_t ldx,
+                         const float *y /*[dev] n x ldy*/, int64_t ldy, float beta,
+                         float *z /*[dev] m x ldz*/, int64_t ldz, int64_t *z_arg /*[dev] | NULL*/,
+                         int sop_udef /*enum isplib_sop_udef*/, float sop_param, void *stream);
 
 /*
  * Column-sliced SpMM: same result as fusedMM_csr_hip, faster when y does not fit an

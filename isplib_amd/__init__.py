@@ -12,9 +12,9 @@ from . import _lib
 _lib.load_ops()
 
 from . import cabi  # noqa: E402
-from .plugin import gcn_norm_matmul, iSpLibPlugin, isplib_autotune, matmul, spmm_autotuned  # noqa: E402
+from .plugin import fusedmm, gcn_norm_matmul, iSpLibPlugin, isplib_autotune, matmul, spmm_autotuned  # noqa: E402
 from .sparse import SparseStorage, SparseTensor  # noqa: E402
 
 __version__ = "0.1.0"
-__all__ = ["iSpLibPlugin", "isplib_autotune", "matmul", "spmm_autotuned", "gcn_norm_matmul", "SparseTensor", "SparseStorage",
+__all__ = ["iSpLibPlugin", "isplib_autotune", "matmul", "spmm_autotuned", "gcn_norm_matmul", "fusedmm", "SparseTensor", "SparseStorage",
            "cabi"]

@@ -23,6 +23,22 @@ MSG_SPMM_MIN = 0x2 | 0x00 | 0x100 | 0x1000 | 0x30000
 MESSAGE = {"sum": MSG_SPMM_SUM, "add": MSG_SPMM_SUM, "mean": MSG_SPMM_MEAN, "max": MSG_SPMM_MAX, "min": MSG_SPMM_MIN}
 
 SUCCESS, FAIL, NOT_ENOUGH_MEM, NO_OPT_IMPL, HIP_ERROR = 0, 1, -1, 128, 256
+UNDEFINED_USER_FUNCTION = 64
+
+# FusedMM stage flags (csrc/fusedMM.h:18-74) and the built-in SOP_UDEF menu (enum isplib_sop_udef)
+VOP = {"copy_lhs": 0x1, "copy_rhs": 0x2, "add": 0x3, "subl": 0x4, "subr": 0x5, "max": 0x6, "min": 0x7, "udef": 0xF}
+ROP = {"noop": 0x00, "dot": 0x10, "add_lhs": 0x20, "add_rhs": 0x30, "norml": 0x40, "normr": 0x50, "udef": 0xF0}
+SOP = {"noop": 0x000, "copy": 0x100, "udef": 0xF00}
+VSC = {"noop": 0x0000, "mul": 0x1000, "add": 0x2000, "mean": 0x3000, "udef": 0xF000}
+AOP = {"add": 0x10000, "max": 0x20000, "min": 0x30000, "udef": 0xF0000}
+SOP_UDEF = {"none": 0, "sigmoid": 1, "one_minus_sigmoid": 2, "tdist": 3, "scale": 4, "exp": 5, "leaky_exp": 6}
+# the FusedMM paper's named patterns as message words (+ the menu entry their SOP_UDEF stands for)
+PATTERNS = {
+    "spmm": (MSG_SPMM_SUM, "none"),
+    "sigmoid_embedding": (VOP["copy_rhs"] | ROP["dot"] | SOP["udef"] | VSC["mul"] | AOP["add"], "sigmoid"),
+    "tdist_embedding": (VOP["subr"] | ROP["normr"] | SOP["udef"] | VSC["mul"] | AOP["add"], "tdist"),
+    "attention_sum": (VOP["copy_rhs"] | ROP["dot"] | SOP["udef"] | VSC["mul"] | AOP["add"], "leaky_exp"),
+}
 
 EXPORTS = (
     "isplib_hip_abi_version", "isplib_hip_last_error", "fusedMM_csr_hip", "performDummySpMM_hip",
@@ -32,7 +48,7 @@ EXPORTS = (
     "fusedMM_csr_sliced_hip", "fusedMM_csr_sliced_phase_hip", "isplib_hip_tune",
     "isplib_spmm_tasks_workspace_bytes", "fusedMM_csr_tasks_hip",
     "isplib_spmm_tasks_plan_workspace_bytes", "isplib_spmm_tasks_count_hip", "isplib_spmm_tasks_fill_hip",
-    "isplib_sddmm_csr_tasks_hip", "fusedMM_csr_tasks_epilogue_hip",
+    "isplib_sddmm_csr_tasks_hip", "fusedMM_csr_tasks_epilogue_hip", "fusedMM_csr_udef_hip",
 )
 
 _i64, _f32, _vp, _i32 = ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_int32
@@ -58,6 +74,9 @@ def lib() -> ctypes.CDLL:
         L.fusedMM_csr_hip.restype = ctypes.c_int
         L.fusedMM_csr_hip.argtypes = [_i32, _i64, _i64, _i64, _f32, _i64, _i64, _i64, _vp, _vp, _vp, _vp,
                                       _vp, _i64, _vp, _i64, _f32, _vp, _i64, _vp, _vp]
+        L.fusedMM_csr_udef_hip.restype = ctypes.c_int
+        L.fusedMM_csr_udef_hip.argtypes = [_i32, _i64, _i64, _i64, _f32, _i64, _i64, _i64, _vp, _vp, _vp, _vp,
+                                           _vp, _i64, _vp, _i64, _f32, _vp, _i64, _vp, ctypes.c_int, _f32, _vp]
         L.performDummySpMM_hip.restype = None
         L.performDummySpMM_hip.argtypes = [_i64, _vp]
         L.isplib_spmm_minmax_bw_hip.restype = ctypes.c_int
@@ -156,6 +175,31 @@ def fusedMM_csr_hip(imessage: int, rowptr: torch.Tensor, col: torch.Tensor, val:
     if check:
         _check(st, "fusedMM_csr_hip")
     return st
+
+
+def fusedmm(imessage: int, rowptr, col, val, x, y, sop_udef="none", sop_param: float = 0.0, check: bool = True):
+    """The generic FusedMM pipeline (fusedMM_csr_udef_hip): z[i,:] = AOP_j VSC(SOP(ROP(VOP(x_i, y_j))), .) over the
+    stored entries of row i.  `imessage` is a word built from VOP/ROP/SOP/VSC/AOP (or PATTERNS[name][0]);
+    `sop_udef` names the built-in function a SOP_UDEF stage stands for.  Returns (status, z, z_arg | None)."""
+    rowptr = _dev(rowptr, "rowptr", torch.int64)
+    col = _dev(col, "col", torch.int64)
+    if val is not None:
+        val = _dev(val, "val", torch.float32)
+    y = _dev(y, "y", torch.float32)
+    if x is not None:
+        x = _dev(x, "x", torch.float32)
+    m, n, k = rowptr.numel() - 1, y.size(0), y.size(1)
+    z = torch.empty((m, k), dtype=torch.float32, device=y.device)
+    arg = torch.empty((m, k), dtype=torch.int64, device=y.device) if ((imessage >> 16) & 0xF) in (2, 3) else None
+    rp = rowptr.data_ptr()
+    kind = SOP_UDEF[sop_udef] if isinstance(sop_udef, str) else int(sop_udef)
+    with torch.cuda.device(y.device):
+        st = lib().fusedMM_csr_udef_hip(int(imessage), m, n, k, 1.0, col.numel(), m, n, _ptr(val), _ptr(col),
+                                        ctypes.c_void_p(rp), ctypes.c_void_p(rp + 8), _ptr(x), k, _ptr(y), k, 0.0,
+                                        _ptr(z), k, _ptr(arg), kind, float(sop_param), _stream(y.device))
+    if check:
+        _check(st, "fusedMM_csr_udef_hip")
+    return st, z, arg
 
 
 def spmm(rowptr, col, val, y, reduce: str = "sum"):

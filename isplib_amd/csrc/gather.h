@@ -255,6 +255,40 @@ template <int OP, int LPR, int NCH, int ADDR> constexpr int min_waves_of() {
    return 8;
 }
 
+// U per-edge partial dot products per lane, each to be summed over the LPR lanes of its slot.  Instead of
+// log2(LPR) shuffles per value, the first log2(U) halving steps also halve the number of live values (a lane
+// keeps the values whose index bit matches its own lane bit and hands the others over), so U values cost
+// U-1 + log2(LPR) - log2(U) shuffles instead of U * log2(LPR).  Returns the finished sum of edge `mine`
+// (valid in every lane of the owning LPR/U-lane group).
+template <int U, int LPR>
+__device__ __forceinline__ float reduce_transposed(float (&d)[U], int lc, int &mine) {
+   static_assert(U == 1 || U == 2 || U == 4 || U == 8, "U must be a power of two <= 8");
+   static_assert(LPR >= U, "slot narrower than the values to transpose");
+   mine = 0;
+   int o = LPR / 2;
+#pragma unroll
+   for (int n = U; n > 1; n >>= 1, o >>= 1) {
+      const bool hi = (lc & o) != 0;
+      mine |= hi ? (n >> 1) : 0;
+#pragma unroll
+      for (int i = 0; i < n / 2; i++) {
+         const float send = hi ? d[i] : d[i + n / 2];
+         const float keep = hi ? d[i + n / 2] : d[i];
+         d[i] = keep + __shfl_xor(send, o);
+      }
+   }
+#pragma unroll
+   for (; o >= 1; o >>= 1) d[0] += __shfl_xor(d[0], o);
+   return d[0];
+}
+
+// lane (within its LPR-lane slot) that ends up owning value u of reduce_transposed
+template <int U, int LPR> __device__ __forceinline__ constexpr int transposed_owner(int u) {
+   int lane = 0, o = LPR / 2;
+   for (int n = U; n > 1; n >>= 1, o >>= 1) lane |= (u & (n >> 1)) ? o : 0;
+   return lane;
+}
+
 // tuning knobs (isplib_hip_tune), defined in spmm.hip
 extern int g_force_lpr, g_addr_mode, g_tasks_per_wave, g_panel_cols;
 

@@ -459,7 +459,12 @@ extern "C" int fusedMM_csr_hip(int32_t imessage, int64_t m, int64_t n, int64_t k
                                const int64_t *pntrb, const int64_t *pntre, const float *x, int64_t ldx,
                                const float *y, int64_t ldy, float beta, float *z, int64_t ldz, int64_t *z_arg,
                                void *stream) {
-   (void)alpha; (void)rows; (void)cols; (void)x; (void)ldx;
+   const int32_t head = imessage & 0xFFF, vsc = imessage & 0xF000;
+   const bool spmm_word = head == (ISPLIB_VOP_COPY_RHS | ISPLIB_ROP_NOOP | ISPLIB_SOP_COPY) &&
+                          (vsc == ISPLIB_VSC_MUL || vsc == ISPLIB_VSC_MEAN) && (imessage >> 20) == 0;
+   if (!spmm_word)      // SDDMM-fused words: the generic pipeline (no user function: *_UDEF stages are refused there)
+      return fusedMM_csr_udef_hip(imessage, m, n, k, alpha, nnz, rows, cols, val, indx, pntrb, pntre, x, ldx, y, ldy, beta,
+                                  z, ldz, z_arg, ISPLIB_SOP_NONE, 0.0f, stream);
    return spmm_entry(imessage, m, n, k, nnz, val, indx, pntrb, pntre, y, ldy, beta, z, ldz, z_arg, nullptr, 1, 0, 0, 0,
                      nullptr, 0, stream);
 }

@@ -184,6 +184,22 @@ def spmm_autotuned(src, other: torch.Tensor, reduce: str = "sum") -> torch.Tenso
 matmul = spmm_autotuned
 
 
+def fusedmm(src, x: Optional[torch.Tensor], y: torch.Tensor, pattern="sigmoid_embedding", sop_param: float = 0.0,
+            sop_udef: Optional[str] = None) -> torch.Tensor:
+    """The generic FusedMM pipeline over the stored entries of `src` (include/isplib_hip.h, fusedMM_csr_udef_hip):
+    ``z[i] = AOP_j VSC(SOP(ROP(VOP(x[i], y[j]))))``.  `pattern` is a name from ``cabi.PATTERNS`` (sigmoid_embedding,
+    tdist_embedding, attention_sum, spmm) or a raw message word built from ``cabi.VOP/ROP/SOP/VSC/AOP``; for a raw
+    word with SOP_UDEF, `sop_udef` names the built-in function.  Forward only (the reference has no such op:
+    these words are defined by csrc/fusedMM.h:18-74 but never sent by iSpLib)."""
+    from . import cabi
+    if isinstance(pattern, str):
+        word, fn = cabi.PATTERNS[pattern]
+    else:
+        word, fn = int(pattern), (sop_udef or "none")
+    st = _storage_of(src, y)
+    return cabi.fusedmm(word, st._rowptr, st._col, st._value, x, y, sop_udef=sop_udef or fn, sop_param=sop_param)[1]
+
+
 def gcn_norm_matmul(src, other: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
     """relu(D^-1/2 (A + I) D^-1/2 @ other + bias) for an UNWEIGHTED square graph, without materialising the
     normalised edge weights: the SpMM runs on the unit-weight fast path, the self loop, the left D^-1/2, bias

@@ -71,6 +71,9 @@ def lib() -> ctypes.CDLL:
         L.oracle_sddmm_csr.restype = ctypes.c_int
         L.oracle_sddmm_csr.argtypes = [i64, i64, vp, vp, vp, vp, i64, vp, i64, ctypes.c_int, vp]
         L.oracle_num_threads.restype = ctypes.c_int
+        L.oracle_fusedMM_csr_udef.restype = ctypes.c_int
+        L.oracle_fusedMM_csr_udef.argtypes = [ctypes.c_int32, i64, i64, i64, vp, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp,
+                                              ctypes.c_int, f32]
         _lib = L
     return _lib
 
@@ -101,6 +104,19 @@ def fusedMM_csr(imsg, m, n, k, val, indx, rowptr, y, z, z_arg=None) -> int:
     return lib().fusedMM_csr(int(imsg), m, n, k, 1.0, val.size, m, n,
                              _p(val), _p(indx), ctypes.c_void_p(pb), ctypes.c_void_p(pb + 8),
                              _p(dummy), k, _p(y), k, 0.0, _p(z), k, _p(z_arg))
+
+
+def fusedmm_general(imsg, rowptr, col, value, x, y, sop_udef=0, sop_param=0.0):
+    """The generic five-stage pipeline (fusedmm_oracle.c, oracle_fusedMM_csr_udef) -> (status, z, z_arg | None).
+    z is written, not accumulated into; z_arg only for AOP_MAX / AOP_MIN."""
+    m, k = rowptr.size - 1, y.shape[1]
+    z = np.empty((m, k), np.float32)
+    arg = np.empty((m, k), np.int64) if ((imsg >> 16) & 0xF) in (2, 3) else None
+    pb = rowptr.ctypes.data
+    st = lib().oracle_fusedMM_csr_udef(int(imsg), m, k, col.size, _p(value), _p(col), ctypes.c_void_p(pb),
+                                       ctypes.c_void_p(pb + 8), _p(x), k, _p(y), k, _p(z), k, _p(arg),
+                                       int(sop_udef), float(sop_param))
+    return st, z, arg
 
 
 def spmm_fw(rowptr, col, value, mat, reduce="sum"):

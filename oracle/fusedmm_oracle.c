@@ -121,6 +121,110 @@ static void row_min(const VALUETYPE *val, const INDEXTYPE *indx,
    }
 }
 
+/*
+ * The generic five-stage pipeline for every other message word (csrc/fusedMM.h:18-74).  The reference never
+ * sends these (csrc/fusedmm.cpp:168-186) and holds no body or test for them: "parity unpinned" in the full
+ * sense.  Restated from the FusedMM paper's general kernel; the HIP path (fusedMM_csr_udef_hip) follows this
+ * text, and tests/ check both against closed-form NumPy expressions of the named patterns.
+ *   VOP T = f(x_i, y_j);  ROP s = reduce (NOOP: 1; DOT: <x_i, T>; ADD_RHS/NORMR: over T; ADD_LHS/NORML: over x_i);
+ *   SOP s' = s | a_ij | f(s);  VSC T' = T | s'*T | s'+T;  AOP z_i (+=|max|min) T'.
+ * sop_udef / sop_param: the built-in menu of include/isplib_hip.h (enum isplib_sop_udef).
+ */
+#include <math.h>
+#include <float.h>
+#include <stdlib.h>
+
+static VALUETYPE sop_menu(int kind, VALUETYPE s, VALUETYPE p)
+{
+   switch (kind) {
+      case 1: return 1.0f / (1.0f + expf(-s));
+      case 2: return 1.0f - 1.0f / (1.0f + expf(-s));
+      case 3: return 1.0f / (1.0f + s);
+      case 4: return p * s;
+      case 5: return expf(s);
+      case 6: return expf(s > 0.0f ? s : p * s);
+      default: return s;
+   }
+}
+
+int oracle_fusedMM_csr_udef(const int32_t imessage, const INDEXTYPE m, const INDEXTYPE k, const INDEXTYPE nnz,
+                            const VALUETYPE *val, const INDEXTYPE *indx, const INDEXTYPE *pntrb,
+                            const INDEXTYPE *pntre, const VALUETYPE *x, const INDEXTYPE ldx, const VALUETYPE *y,
+                            const INDEXTYPE ldy, VALUETYPE *z, const INDEXTYPE ldz, INDEXTYPE *z_arg,
+                            const int sop_udef, const VALUETYPE sop_param)
+{
+   const int vop = imessage & 0xF, rop = (imessage >> 4) & 0xF, sop = (imessage >> 8) & 0xF,
+             vsc = (imessage >> 12) & 0xF, aop = (imessage >> 16) & 0xF;
+   if ((imessage >> 20) != 0) return ORC_NO_OPT_IMPL;
+   if (vop == 0xF || rop == 0xF || vsc == 0xF || aop == 0xF) return 64;
+   if (vop < 1 || vop > 7 || rop > 5 || vsc > 3 || aop < 1 || aop > 3) return ORC_NO_OPT_IMPL;
+   if (sop != 0 && sop != 1 && sop != 0xF) return ORC_NO_OPT_IMPL;
+   if (sop == 0xF && (sop_udef < 1 || sop_udef > 6)) return 64;
+   if (vsc == 3 && aop != 1) return ORC_NO_OPT_IMPL;
+   if (m < 0 || k < 0) return ORC_FAIL;
+#pragma omp parallel
+   {
+      VALUETYPE *t = (VALUETYPE *)malloc(sizeof(VALUETYPE) * (size_t)(k > 0 ? k : 1));
+#pragma omp for schedule(dynamic, ORC_ROW_CHUNK)
+      for (INDEXTYPE i = 0; i < m; i++) {
+         const INDEXTYPE b = pntrb[i], e = pntre[i];
+         const VALUETYPE *xi = x ? x + i * ldx : (const VALUETYPE *)0;
+         VALUETYPE *zi = z + i * ldz;
+         INDEXTYPE *ai = z_arg ? z_arg + i * ldz : (INDEXTYPE *)0;
+         for (INDEXTYPE c = 0; c < k; c++) {
+            zi[c] = aop == 1 ? 0.0f : (aop == 2 ? -FLT_MAX : FLT_MAX);
+            if (ai) ai[c] = nnz;
+         }
+         for (INDEXTYPE j = b; j < e; j++) {
+            const VALUETYPE *yj = y + indx[j] * ldy;
+            VALUETYPE s = 1.0f;
+            VALUETYPE red = 0.0f;
+            for (INDEXTYPE c = 0; c < k; c++) {
+               const VALUETYPE xx = xi ? xi[c] : 0.0f, yy = yj[c];
+               VALUETYPE tv;
+               switch (vop) {
+                  case 1: tv = xx; break;
+                  case 3: tv = xx + yy; break;
+                  case 4: tv = xx - yy; break;
+                  case 5: tv = yy - xx; break;
+                  case 6: tv = xx > yy ? xx : yy; break;
+                  case 7: tv = xx < yy ? xx : yy; break;
+                  default: tv = yy; break;
+               }
+               t[c] = tv;
+               switch (rop) {
+                  case 1: red += xx * tv; break;
+                  case 2: red += xx; break;
+                  case 3: red += tv; break;
+                  case 4: red += xx * xx; break;
+                  case 5: red += tv * tv; break;
+                  default: break;
+               }
+            }
+            if (rop != 0) s = red;
+            if (sop == 1) s = val ? val[j] : 1.0f;
+            else if (sop == 0xF) s = sop_menu(sop_udef, s, sop_param);
+            for (INDEXTYPE c = 0; c < k; c++) {
+               VALUETYPE tv = t[c];
+               if (vsc == 1 || vsc == 3) tv = s * tv;
+               else if (vsc == 2) tv = s + tv;
+               if (aop == 1) zi[c] += tv;
+               else if (aop == 2) { if (tv > zi[c]) { zi[c] = tv; if (ai) ai[c] = j; } }
+               else { if (tv < zi[c]) { zi[c] = tv; if (ai) ai[c] = j; } }
+            }
+         }
+         if (vsc == 3) {
+            const VALUETYPE d = (VALUETYPE)((e - b) > 1 ? (e - b) : 1);
+            for (INDEXTYPE c = 0; c < k; c++) zi[c] = zi[c] / d;
+         }
+         if (aop != 1 && e <= b)
+            for (INDEXTYPE c = 0; c < k; c++) zi[c] = 0.0f;
+      }
+      free(t);
+   }
+   return ORC_SUCCESS;
+}
+
 /* Same 20-argument C ABI as csrc/fusedMM.h:77-99. Host pointers. */
 int fusedMM_csr(const int32_t imessage, const INDEXTYPE m, const INDEXTYPE n,
                 const INDEXTYPE k, const VALUETYPE alpha, const INDEXTYPE nnz,

@@ -134,7 +134,9 @@ def test_status_codes(gpu):
     col = torch.tensor([0], device=gpu)
     y = torch.ones((1, 4), device=gpu)
     z = torch.empty((1, 4), device=gpu)
-    assert cabi.fusedMM_csr_hip(0x11103, rowptr, col, None, y, z, check=False) == cabi.NO_OPT_IMPL   # VOP_ADD
+    assert cabi.fusedMM_csr_hip(0x11108, rowptr, col, None, y, z, check=False) == cabi.NO_OPT_IMPL   # VOP 8: undefined
+    assert cabi.fusedMM_csr_hip(0x1110F, rowptr, col, None, y, z, check=False) == cabi.UNDEFINED_USER_FUNCTION   # VOP_UDEF
+    assert cabi.fusedMM_csr_hip(0x11103, rowptr, col, None, y, z, check=False) == cabi.FAIL          # VOP_ADD reads x: NULL here
     assert cabi.fusedMM_csr_hip(0x23102, rowptr, col, None, y, z, check=False) == cabi.NO_OPT_IMPL   # MEAN with MAX
     assert cabi.fusedMM_csr_hip(cabi.MSG_SPMM_SUM, rowptr, col, None, y, z, beta=1.0, check=False) == cabi.FAIL
     assert "beta" in cabi.last_error()

@@ -53,8 +53,10 @@ def test_cabi_argument_validation_without_gpu():
     """Status codes that are decided before any HIP call."""
     from isplib_amd import cabi
     L = cabi.lib()
-    st = L.fusedMM_csr_hip(0x11103, 1, 1, 1, 1.0, 0, 1, 1, None, None, None, None, None, 1, None, 1, 0.0, None, 1, None, None)
-    assert st == cabi.NO_OPT_IMPL and "SpMM" in cabi.last_error()
+    st = L.fusedMM_csr_hip(0x11108, 1, 1, 1, 1.0, 0, 1, 1, None, None, None, None, None, 1, None, 1, 0.0, None, 1, None, None)
+    assert st == cabi.NO_OPT_IMPL and "VOP" in cabi.last_error()          # a flag value the header does not define
+    st = L.fusedMM_csr_hip(0x11F02, 1, 1, 1, 1.0, 0, 1, 1, None, None, None, None, None, 1, None, 1, 0.0, None, 1, None, None)
+    assert st == cabi.UNDEFINED_USER_FUNCTION                             # SOP_UDEF through the entry without a menu
     st = L.fusedMM_csr_hip(cabi.MSG_SPMM_SUM, 1, 1, 1, 1.0, 0, 1, 1, None, None, None, None, None, 1, None, 1, 0.5, None, 1, None, None)
     assert st == cabi.FAIL and "beta" in cabi.last_error()
     st = L.fusedMM_csr_hip(cabi.MSG_SPMM_SUM, 0, 0, 4, 1.0, 0, 0, 0, None, None, None, None, None, 4, None, 4, 0.0, None, 4, None, None)

@@ -185,3 +185,76 @@ def test_dx_of_sum_and_mean_against_dense_fp64(oracle_mod):
         assert np.allclose(z[f"{n}/sum/dx"], a.T @ g.astype(np.float64), rtol=1e-5, atol=1e-5)
         deg = np.maximum(np.diff(rowptr), 1)[:, None]
         assert np.allclose(z[f"{n}/mean/dx"], (a / deg).T @ g.astype(np.float64), rtol=1e-5, atol=1e-5)
+
+
+# ---- generic FusedMM pipeline (words the reference never sends; unpinned by it) ----------------------------
+
+def _word(vop, rop, sop, vsc, aop):
+    return vop | (rop << 4) | (sop << 8) | (vsc << 12) | (aop << 16)
+
+
+def test_generic_pipeline_named_patterns_against_closed_forms(oracle_mod):
+    rowptr, col = cases.random_csr(50, 40, 6.0, seed=21, empty_rows=(3, 49), duplicates=True)
+    k = 12
+    x, y = cases.dense(50, k, 7) * 0.5, cases.dense(40, k, 8) * 0.5
+    row = np.repeat(np.arange(50), np.diff(rowptr))
+    xe, ye = x[row].astype(np.float64), y[col].astype(np.float64)
+    # sigmoid embedding: z_i = sum_j sigmoid(<x_i, y_j>) y_j
+    st, z, _ = oracle_mod.fusedmm_general(_word(2, 1, 0xF, 1, 1), rowptr, col, None, x, y, sop_udef=1)
+    want = np.zeros((50, k))
+    np.add.at(want, row, (1 / (1 + np.exp(-(xe * ye).sum(1))))[:, None] * ye)
+    assert st == 0 and np.allclose(z, want, rtol=1e-5, atol=1e-6)
+    # t-distribution embedding: z_i = sum_j (y_j - x_i) / (1 + |y_j - x_i|^2)
+    st, z, _ = oracle_mod.fusedmm_general(_word(5, 5, 0xF, 1, 1), rowptr, col, None, x, y, sop_udef=3)
+    d = ye - xe
+    want = np.zeros((50, k))
+    np.add.at(want, row, d / (1 + (d * d).sum(1))[:, None])
+    assert st == 0 and np.allclose(z, want, rtol=1e-5, atol=1e-6)
+    # the SpMM word through the generic path = the launcher's SpMM
+    val = cases.weights(col.size, 4)
+    st, z, _ = oracle_mod.fusedmm_general(0x11102, rowptr, col, val, None, y)
+    ref, _ = oracle_mod.spmm_fw(rowptr, col, val, y, "sum")
+    assert st == 0 and np.array_equal(z, ref)
+    st, z, arg = oracle_mod.fusedmm_general(0x21102, rowptr, col, val, None, y)
+    ref, ref_arg = oracle_mod.spmm_fw(rowptr, col, val, y, "max")
+    assert st == 0 and np.array_equal(z, ref) and np.array_equal(arg, ref_arg)
+
+
+def test_generic_pipeline_every_stage_against_numpy_statement(oracle_mod):
+    from tests import fusedmm_ref
+    rowptr, col = cases.random_csr(30, 25, 5.0, seed=4, empty_rows=(0, 17), duplicates=True)
+    val = cases.weights(col.size, 4, "signed_int")
+    for k in (5, 16):
+        x, y = cases.dense(30, k, 3, "integer"), cases.dense(25, k, 5, "integer")      # exact arithmetic: ties are real
+        for vop in range(1, 8):
+            for rop in range(0, 6):
+                for sop, kind, prm in ((0, 0, 0.0), (1, 0, 0.0), (0xF, 4, 0.25), (0xF, 1, 0.0), (0xF, 3, 0.0)):
+                    if kind == 3 and rop not in (4, 5):
+                        continue                                  # 1/(1+s) is only meaningful for s >= 0
+                    for vsc in range(0, 4):
+                        for aop in (1, 2, 3):
+                            if vsc == 3 and aop != 1:
+                                continue
+                            w = _word(vop, rop, sop, vsc, aop)
+                            st, z, arg = oracle_mod.fusedmm_general(w, rowptr, col, val, x, y, kind, prm)
+                            want, want_arg = fusedmm_ref.fusedmm(w, rowptr, col, val, x, y, kind, prm)
+                            assert st == 0, hex(w)
+                            exact = kind in (0, 4)
+                            if exact and aop != 1:
+                                assert np.array_equal(z, want.astype(np.float32)) and np.array_equal(arg, want_arg), hex(w)
+                            else:
+                                lim = 1e-5 * np.abs(want).max() + 1e-6
+                                assert np.all(np.abs(z - want) <= lim), hex(w)
+
+
+def test_generic_pipeline_status_codes(oracle_mod):
+    rowptr, col, val, x, *_ = cases.readme_case()
+    call = lambda w, kind=0: oracle_mod.fusedmm_general(w, rowptr, col, val, x, x, kind)[0]  # noqa: E731
+    assert call(_word(0xF, 0, 1, 1, 1)) == 64          # VOP_UDEF: no user functions on this path
+    assert call(_word(2, 1, 0xF, 1, 1)) == 64          # SOP_UDEF without a menu entry
+    assert call(_word(2, 1, 0xF, 1, 1), 1) == 0
+    assert call(_word(8, 0, 1, 1, 1)) == 128           # a VOP value the header does not define
+    assert call(_word(2, 0, 2, 1, 1)) == 128           # SOP 0x200 undefined
+    assert call(_word(2, 0, 1, 3, 2)) == 128           # MEAN with MAX
+    assert call(_word(0, 0, 1, 1, 1)) == 128           # VOP_NOOP: nothing to aggregate
+    assert call(_word(2, 0, 1, 1, 0)) == 128           # AOP_NOOP
