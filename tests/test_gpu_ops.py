@@ -350,6 +350,38 @@ def test_autotune_keeps_the_fastest_slice_count(gpu, oracle_mod):
     assert np.all(np.abs(out.cpu().numpy() - ref) <= cases.sum_tolerance(oracle_mod, rowptr, col, val, x))
 
 
+def test_mtx_graph_tuning_file_and_generic_pipeline_through_the_package(gpu, oracle_mod, tmp_path):
+    """The tuner's workflow end to end: .mtx adjacency -> SparseTensor -> autotune -> saved table -> a fresh graph
+    object with the same content picks the persisted choice up; plus isplib_amd.fusedmm on the same graph."""
+    import isplib_amd
+    from isplib_amd import plugin
+    rowptr, col = cases.random_csr(500, 500, 80.0, seed=23, empty_rows=(9,))
+    val = cases.weights(col.size, 4)
+    src = isplib_amd.SparseTensor.from_csr(_t(rowptr, gpu), _t(col, gpu), _t(val, gpu), (500, 500))
+    src.to_mtx(tmp_path / "g.mtx", "tests")
+    adj = isplib_amd.SparseTensor.from_mtx(tmp_path / "g.mtx", device=gpu)
+    assert adj.sparse_sizes() == (500, 500) and torch.equal(adj.csr()[1], src.csr()[1])
+    assert torch.allclose(adj.csr()[2], src.csr()[2], rtol=1e-6)           # %.9g round trip of fp32
+    plugin._tuning_db.clear()
+    times = isplib_amd.iSpLibPlugin.autotune(adj, 32, "sum", candidates=(0, 3, 8))
+    best = min(times, key=times.get)
+    isplib_amd.iSpLibPlugin.save_tuning(tmp_path / "tune.json")
+    plugin._tuning_db.clear()
+    fresh = isplib_amd.SparseTensor.from_mtx(tmp_path / "g.mtx", device=gpu)
+    assert isplib_amd.iSpLibPlugin.load_tuning(tmp_path / "tune.json") == 1
+    assert plugin.choose_slices(fresh.storage, 500, 32) == best
+    x = cases.dense(500, 32, 3)
+    out = isplib_amd.matmul(fresh, _t(x, gpu))
+    v = fresh.csr()[2].cpu().numpy()
+    ref, _ = oracle_mod.spmm_fw(rowptr, col, v, x, "sum")
+    assert np.all(np.abs(out.cpu().numpy() - ref) <= cases.sum_tolerance(oracle_mod, rowptr, col, v, x))
+    plugin._tuning_db.clear()
+    y = cases.dense(500, 32, 5) * np.float32(0.2)
+    z = isplib_amd.fusedmm(fresh, _t(x, gpu) * 0.2, _t(y, gpu), "sigmoid_embedding")
+    _, zref, _ = oracle_mod.fusedmm_general(0x11F12, rowptr, col, None, (x * np.float32(0.2)).astype(np.float32), y, 1)
+    assert np.all(np.abs(z.cpu().numpy() - zref) <= 1e-4 * np.abs(zref).max())
+
+
 def _gcn_reference(oracle_mod, rowptr, col, x, bias, relu):
     """relu(D^-1/2 (A + I) D^-1/2 x + b) composed from the oracle's unit-weight sum (fp32 steps like the kernel)."""
     deg = np.diff(rowptr).astype(np.float32) + 1
