@@ -123,11 +123,13 @@ int main() {
    const size_t ws = isplib_spmm_tasks_workspace_bytes(ISPLIB_MSG_SPMM_MAX, info.n_tasks, k);
    void *d_ws = nullptr; HIP_OK(hipMalloc(&d_ws, ws));
    HIP_OK(hipMemsetAsync(d_out, 0xff, (size_t)m * k * sizeof(float), st));
-   ISP_OK(fusedMM_csr_tasks_hip(ISPLIB_MSG_SPMM_SUM, m, n, k, nnz, d_val, d_col, d_rowptr, d_rowptr + 1, info.n_tasks, d_trow,
+   int32_t *d_col32 = nullptr; HIP_OK(hipMalloc(&d_col32, (size_t)nnz * sizeof(int32_t)));      // once per graph: 4-byte ids
+   ISP_OK(isplib_pack_indices_hip(nnz, d_col, d_col32, st));
+   ISP_OK(fusedMM_csr_tasks_hip(ISPLIB_MSG_SPMM_SUM, m, n, k, nnz, d_val, d_col, d_col32, d_rowptr, d_rowptr + 1, info.n_tasks, d_trow,
                                 d_tb, d_tlen, d_seg, S, info.lane_off, d_x, k, d_out, k, nullptr, d_ws, ws, st));
    HIP_OK(hipStreamSynchronize(st));
    if (!check_sum("fusedMM_csr_tasks_hip")) return 1;
-   ISP_OK(fusedMM_csr_tasks_hip(ISPLIB_MSG_SPMM_MAX, m, n, k, nnz, d_val, d_col, d_rowptr, d_rowptr + 1, info.n_tasks, d_trow,
+   ISP_OK(fusedMM_csr_tasks_hip(ISPLIB_MSG_SPMM_MAX, m, n, k, nnz, d_val, d_col, /*indx32*/ nullptr, d_rowptr, d_rowptr + 1, info.n_tasks, d_trow,
                                 d_tb, d_tlen, d_seg, S, info.lane_off, d_x, k, d_out, k, d_arg, d_ws, ws, st));
    HIP_OK(hipStreamSynchronize(st));
    if (!check_max("fusedMM_csr_tasks_hip")) return 1;

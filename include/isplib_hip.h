@@ -222,8 +222,13 @@ int    isplib_spmm_tasks_fill_hip(int64_t m, const int64_t *pntrb, const int64_t
                                   const int32_t *seg_off, int32_t *task_row, int64_t *task_b,
                                   int32_t *task_len, void *stream);
 size_t isplib_spmm_tasks_workspace_bytes(int32_t imessage, int64_t n_tasks, int64_t k);
+/* indx32 (optional, may be NULL): the column ids of indx packed to 32 bits, once per graph, by
+ * isplib_pack_indices_hip.  The task kernels then stream 4 instead of 8 bytes per stored entry -- the index
+ * stream is the one operand that always comes from HBM (Reddit: 917 MB per pass; -12 % time at k=32, -4 % at
+ * k=128).  indx stays the reference's int64 array and is what NULL falls back to. */
+int    isplib_pack_indices_hip(int64_t nnz, const int64_t *indx, int32_t *indx32, void *stream);
 int    fusedMM_csr_tasks_hip(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t nnz,
-                             const float *val, const int64_t *indx,
+                             const float *val, const int64_t *indx, const int32_t *indx32,
                              const int64_t *pntrb, const int64_t *pntre,
                              int64_t n_tasks, const int32_t *task_row,
                              const int64_t *task_b, const int32_t *task_len,
@@ -247,7 +252,7 @@ typedef struct isplib_epilogue {
    int          relu;        /* nonzero: max(., 0) */
 } isplib_epilogue;
 int    fusedMM_csr_tasks_epilogue_hip(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t nnz,
-                                      const float *val, const int64_t *indx,
+                                      const float *val, const int64_t *indx, const int32_t *indx32,
                                       const int64_t *pntrb, const int64_t *pntre,
                                       int64_t n_tasks, const int32_t *task_row,
                                       const int64_t *task_b, const int32_t *task_len,
@@ -289,6 +294,7 @@ int isplib_sddmm_csr_hip(int64_t m, int64_t k, const int64_t *indx,
 /* The same over the task plan of the SpMM (one wave per task, XCD-lane grouping -> the L2 affinity of
  * the task-list SpMM; dval is per edge, so no workspace and no combine).  4 <= k <= 1024. */
 int isplib_sddmm_csr_tasks_hip(int64_t m, int64_t n, int64_t k, const int64_t *indx,
+                               const int32_t *indx32 /*optional, as in fusedMM_csr_tasks_hip*/,
                                const int64_t *pntrb, const int64_t *pntre,
                                int64_t n_tasks, const int32_t *task_row,
                                const int64_t *task_b, const int32_t *task_len,

@@ -48,7 +48,7 @@ EXPORTS = (
     "fusedMM_csr_sliced_hip", "fusedMM_csr_sliced_phase_hip", "isplib_hip_tune",
     "isplib_spmm_tasks_workspace_bytes", "fusedMM_csr_tasks_hip",
     "isplib_spmm_tasks_plan_workspace_bytes", "isplib_spmm_tasks_count_hip", "isplib_spmm_tasks_fill_hip",
-    "isplib_sddmm_csr_tasks_hip", "fusedMM_csr_tasks_epilogue_hip", "fusedMM_csr_udef_hip",
+    "isplib_sddmm_csr_tasks_hip", "fusedMM_csr_tasks_epilogue_hip", "fusedMM_csr_udef_hip", "isplib_pack_indices_hip",
 )
 
 _i64, _f32, _vp, _i32 = ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_int32
@@ -106,7 +106,9 @@ def lib() -> ctypes.CDLL:
         L.isplib_spmm_tasks_workspace_bytes.restype = ctypes.c_size_t
         L.isplib_spmm_tasks_workspace_bytes.argtypes = [_i32, _i64, _i64]
         L.fusedMM_csr_tasks_hip.restype = ctypes.c_int
-        L.fusedMM_csr_tasks_hip.argtypes = [_i32, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp,
+        L.isplib_pack_indices_hip.restype = ctypes.c_int
+        L.isplib_pack_indices_hip.argtypes = [_i64, _vp, _vp, _vp]
+        L.fusedMM_csr_tasks_hip.argtypes = [_i32, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp,
                                             ctypes.c_int, _vp, _vp, _i64, _vp, _i64, _vp, _vp, ctypes.c_size_t, _vp]
         L.isplib_spmm_tasks_plan_workspace_bytes.restype = ctypes.c_size_t
         L.isplib_spmm_tasks_plan_workspace_bytes.argtypes = [_i64, ctypes.c_int]
@@ -116,10 +118,10 @@ def lib() -> ctypes.CDLL:
         L.isplib_spmm_tasks_fill_hip.restype = ctypes.c_int
         L.isplib_spmm_tasks_fill_hip.argtypes = [_i64, _vp, _vp, _vp, ctypes.POINTER(TaskPlanInfo), _vp, _vp, _vp, _vp, _vp]
         L.isplib_sddmm_csr_tasks_hip.restype = ctypes.c_int
-        L.isplib_sddmm_csr_tasks_hip.argtypes = [_i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp,
+        L.isplib_sddmm_csr_tasks_hip.argtypes = [_i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp,
                                                  _i64, ctypes.c_int, _vp, _vp]
         L.fusedMM_csr_tasks_epilogue_hip.restype = ctypes.c_int
-        L.fusedMM_csr_tasks_epilogue_hip.argtypes = [_i32, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp,
+        L.fusedMM_csr_tasks_epilogue_hip.argtypes = [_i32, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp,
                                                      ctypes.c_int, _vp, _vp, _i64, _vp, _i64, _vp, ctypes.c_size_t,
                                                      ctypes.POINTER(Epilogue), _vp]
         L.isplib_hip_tune.restype = ctypes.c_int
@@ -356,6 +358,21 @@ def fusedMM_csr_sliced_phase_hip(imessage: int, rowptr, col, val, sliceptr, slic
     return st
 
 
+def pack_indices(col: torch.Tensor) -> torch.Tensor:
+    """int32 copy of the column ids (isplib_pack_indices_hip): what the task kernels stream instead of the int64 array."""
+    col = _dev(col, "col", torch.int64)
+    out = torch.empty(col.numel(), dtype=torch.int32, device=col.device)
+    with torch.cuda.device(col.device):
+        _check(lib().isplib_pack_indices_hip(col.numel(), _ptr(col), _ptr(out), _stream(col.device)), "isplib_pack_indices_hip")
+    return out
+
+
+def _plan_col32(plan, col):
+    """The plan's packed column ids if it has them and they belong to this `col` (same length), else NULL."""
+    c32 = getattr(plan, "col32", None)
+    return _ptr(c32) if c32 is not None and c32.numel() == col.numel() and c32.device == col.device else None
+
+
 def fusedMM_csr_tasks_hip(imessage: int, rowptr, col, val, plan, y, z, z_arg, workspace, check: bool = True) -> int:
     """Raw boundary call of the task-list SpMM; ``plan`` is an isplib_amd.plan.TaskPlan."""
     assert y.is_cuda and y.dtype == torch.float32 and y.dim() == 2 and y.stride(1) == 1
@@ -363,7 +380,7 @@ def fusedMM_csr_tasks_hip(imessage: int, rowptr, col, val, plan, y, z, z_arg, wo
     rp = rowptr.data_ptr()
     lane = (ctypes.c_int64 * 9)(*plan.lane_off)
     with torch.cuda.device(y.device):
-        st = lib().fusedMM_csr_tasks_hip(int(imessage), m, n, k, col.numel(), _ptr(val), _ptr(col), ctypes.c_void_p(rp),
+        st = lib().fusedMM_csr_tasks_hip(int(imessage), m, n, k, col.numel(), _ptr(val), _ptr(col), _plan_col32(plan, col), ctypes.c_void_p(rp),
                                          ctypes.c_void_p(rp + 8), plan.n_tasks, _ptr(plan.task_row), _ptr(plan.task_b),
                                          _ptr(plan.task_len), _ptr(plan.seg_off), plan.slices, lane, _ptr(y),
                                          y.stride(0) if n > 1 else max(k, y.stride(0)), _ptr(z),
@@ -401,7 +418,7 @@ def sddmm_tasks(rowptr, col, plan, y, g, mean: bool = False):
     rp = rowptr.data_ptr()
     lane = (ctypes.c_int64 * 9)(*plan.lane_off)
     with torch.cuda.device(y.device):
-        st = lib().isplib_sddmm_csr_tasks_hip(m, n, k, _ptr(col), ctypes.c_void_p(rp), ctypes.c_void_p(rp + 8), plan.n_tasks,
+        st = lib().isplib_sddmm_csr_tasks_hip(m, n, k, _ptr(col), _plan_col32(plan, col), ctypes.c_void_p(rp), ctypes.c_void_p(rp + 8), plan.n_tasks,
                                               _ptr(plan.task_row), _ptr(plan.task_b), _ptr(plan.task_len), lane, _ptr(y), k,
                                               _ptr(g), k, int(bool(mean)), _ptr(dval), _stream(y.device))
     _check(st, "isplib_sddmm_csr_tasks_hip")
@@ -421,7 +438,7 @@ def spmm_tasks_epilogue(rowptr, col, val, plan, y, reduce="sum", row_scale=None,
     rp = rowptr.data_ptr()
     lane = (ctypes.c_int64 * 9)(*plan.lane_off)
     with torch.cuda.device(y.device):
-        st = lib().fusedMM_csr_tasks_epilogue_hip(MESSAGE[reduce], m, n, k, col.numel(), _ptr(val), _ptr(col), ctypes.c_void_p(rp),
+        st = lib().fusedMM_csr_tasks_epilogue_hip(MESSAGE[reduce], m, n, k, col.numel(), _ptr(val), _ptr(col), _plan_col32(plan, col), ctypes.c_void_p(rp),
                                                   ctypes.c_void_p(rp + 8), plan.n_tasks, _ptr(plan.task_row), _ptr(plan.task_b),
                                                   _ptr(plan.task_len), _ptr(plan.seg_off), plan.slices, lane, _ptr(y), k, _ptr(out),
                                                   k, _ptr(work), work.numel(), ctypes.byref(ep), _stream(y.device))

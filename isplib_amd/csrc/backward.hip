@@ -129,6 +129,7 @@ typedef __attribute__((__vector_size__(4 * sizeof(int)))) int sd_v4i_t;
 struct SddmmTaskArgs {
    int64_t k;
    const int64_t *indx, *pntrb, *pntre;
+   const int32_t *indx32;
    const float *y;
    int64_t ldy;
    unsigned ybytes;
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(WAVES * 64, NCH == 1 ? 8 : 1) void sddmm_task_kerne
    const unsigned ldyb = (unsigned)a.ldy * 4u;
    for (int64_t base = b; base < e; base += 64) {
       const int64_t p = base + lane;
-      const unsigned off_l = p < e ? (unsigned)a.indx[p] * ldyb : SD_BUF_OOB;
+      const unsigned off_l = p < e ? (a.indx32 ? (unsigned)a.indx32[p] : (unsigned)a.indx[p]) * ldyb : SD_BUF_OOB;
       const int64_t left = e - base;
       const int cnt = left < 64 ? (int)left : 64;
 #pragma unroll 1
@@ -276,8 +277,8 @@ extern "C" int isplib_sddmm_csr_hip(int64_t m, int64_t k, const int64_t *indx, c
    return launch_sddmm<1, 64>(a, st);
 }
 
-extern "C" int isplib_sddmm_csr_tasks_hip(int64_t m, int64_t n, int64_t k, const int64_t *indx, const int64_t *pntrb,
-                                          const int64_t *pntre, int64_t n_tasks, const int32_t *task_row,
+extern "C" int isplib_sddmm_csr_tasks_hip(int64_t m, int64_t n, int64_t k, const int64_t *indx, const int32_t *indx32,
+                                          const int64_t *pntrb, const int64_t *pntre, int64_t n_tasks, const int32_t *task_row,
                                           const int64_t *task_b, const int32_t *task_len,
                                           const int64_t *lane_off_host, const float *y, int64_t ldy, const float *g,
                                           int64_t ldg, int mean, float *dval, void *stream) {
@@ -291,7 +292,7 @@ extern "C" int isplib_sddmm_csr_tasks_hip(int64_t m, int64_t n, int64_t k, const
       return fail(ISPLIB_FAIL, "isplib_sddmm_csr_tasks_hip: null operand");
    if (ldy < k || ldg < k) return fail(ISPLIB_FAIL, "isplib_sddmm_csr_tasks_hip: leading dimension smaller than k");
    SddmmTaskArgs a;
-   a.k = k; a.indx = indx; a.pntrb = pntrb; a.pntre = pntre; a.y = y; a.ldy = ldy; a.ybytes = (unsigned)yb;
+   a.k = k; a.indx = indx; a.indx32 = indx32; a.pntrb = pntrb; a.pntre = pntre; a.y = y; a.ldy = ldy; a.ybytes = (unsigned)yb;
    a.g = g; a.ldg = ldg; a.mean = mean ? 1 : 0; a.dval = dval;
    a.task_row = task_row; a.task_b = task_b; a.task_len = task_len;
    for (int x = 0; x < 9; x++) a.lane_off[x] = lane_off_host[x];

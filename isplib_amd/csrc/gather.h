@@ -198,7 +198,7 @@ __device__ __forceinline__ void wave_edges_buf(const Args &a, const __amdgpu_buf
       unsigned off_l = BUF_OOB;
       float v_l = 0.0f;
       if (p < re) {
-         off_l = (unsigned)a.indx[p] * ldyb;
+         off_l = (a.indx32 ? (unsigned)a.indx32[p] : (unsigned)a.indx[p]) * ldyb;
          if (HAS_VAL) v_l = a.val[p];
       }
       const int64_t left = re - base;

@@ -389,3 +389,21 @@ extern "C" int isplib_spmm_tasks_fill_hip(int64_t m, const int64_t *pntrb, const
                       task_len);
    return check_launch("plan_fill_kernel");
 }
+
+// ---- 32-bit copy of the column ids for the task kernels (include/isplib_hip.h) -------------------
+namespace isplib {
+__global__ __launch_bounds__(256) void pack_indices_kernel(int64_t nnz, const int64_t *__restrict__ indx,
+                                                           int32_t *__restrict__ indx32) {
+   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += stride) indx32[i] = (int32_t)indx[i];
+}
+}  // namespace isplib
+
+extern "C" int isplib_pack_indices_hip(int64_t nnz, const int64_t *indx, int32_t *indx32, void *stream) {
+   clear_error();
+   if (nnz < 0) return fail(ISPLIB_FAIL, "isplib_pack_indices_hip: negative nnz");
+   if (nnz == 0) return ISPLIB_SUCCESS;
+   if (!indx || !indx32) return fail(ISPLIB_FAIL, "isplib_pack_indices_hip: null operand");
+   hipLaunchKernelGGL(pack_indices_kernel, dim3(grid_for(nnz)), dim3(256), 0, (hipStream_t)stream, nnz, indx, indx32);
+   return check_launch("pack_indices_kernel");
+}

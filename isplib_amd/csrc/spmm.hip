@@ -33,6 +33,7 @@ struct SpmmArgs {
    int64_t m, k, nnz;
    const float *val;       // may be null (unit weights)
    const int64_t *indx;
+   const int32_t *indx32;  // packed copy of indx (task entries only; null here)
    const int64_t *pntrb;
    const int64_t *pntre;
    const float *y;
@@ -424,7 +425,7 @@ static int spmm_entry(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t
 
    SpmmArgs a;
    a.m = m; a.k = k; a.nnz = nnz;
-   a.val = val; a.indx = indx; a.pntrb = pntrb; a.pntre = pntre;
+   a.val = val; a.indx = indx; a.indx32 = nullptr; a.pntrb = pntrb; a.pntre = pntre;
    a.y = y; a.ldy = ldy; a.z = z; a.ldz = ldz; a.z_arg = z_arg;
    a.mean = (vsc == ISPLIB_VSC_MEAN) ? 1 : 0;
    a.long_row = 2048;

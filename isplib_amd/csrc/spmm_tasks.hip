@@ -26,6 +26,7 @@ struct TaskArgs {
    int64_t m, k, nnz;
    const float *val;
    const int64_t *indx, *pntrb, *pntre;
+   const int32_t *indx32;    // the column ids packed to 32 bits, or null
    const float *y;
    int64_t ldy;
    unsigned ybytes;
@@ -220,7 +221,7 @@ extern "C" size_t isplib_spmm_tasks_workspace_bytes(int32_t imessage, int64_t n_
 }
 
 static int tasks_entry(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t nnz, const float *val,
-                       const int64_t *indx, const int64_t *pntrb, const int64_t *pntre, int64_t n_tasks,
+                       const int64_t *indx, const int32_t *indx32, const int64_t *pntrb, const int64_t *pntre, int64_t n_tasks,
                        const int32_t *task_row, const int64_t *task_b, const int32_t *task_len, const int32_t *seg_off,
                        int slices, const int64_t *lane_off_host, const float *y, int64_t ldy, float *z, int64_t ldz,
                        int64_t *z_arg, void *workspace, size_t workspace_bytes, const isplib_epilogue *ep,
@@ -246,7 +247,7 @@ static int tasks_entry(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_
    if (!workspace || workspace_bytes < need) return fail(ISPLIB_NOT_ENOUGH_MEM, "fusedMM_csr_tasks_hip: workspace too small");
    if (((uintptr_t)workspace & 255) != 0) return fail(ISPLIB_FAIL, "fusedMM_csr_tasks_hip: workspace must be 256-byte aligned");
    TaskArgs a;
-   a.m = m; a.k = k; a.nnz = nnz; a.val = val; a.indx = indx; a.pntrb = pntrb; a.pntre = pntre;
+   a.m = m; a.k = k; a.nnz = nnz; a.val = val; a.indx = indx; a.indx32 = indx32; a.pntrb = pntrb; a.pntre = pntre;
    a.y = y; a.ldy = ldy; a.ybytes = (unsigned)yb; a.z = z; a.ldz = ldz; a.z_arg = z_arg;
    a.mean = (vsc == ISPLIB_VSC_MEAN) ? 1 : 0; a.slices = slices;
    a.task_row = task_row; a.task_b = task_b; a.task_len = task_len; a.seg_off = seg_off;
@@ -295,23 +296,23 @@ static int tasks_entry(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_
 }
 
 extern "C" int fusedMM_csr_tasks_hip(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t nnz, const float *val,
-                                     const int64_t *indx, const int64_t *pntrb, const int64_t *pntre,
-                                     int64_t n_tasks, const int32_t *task_row, const int64_t *task_b,
+                                     const int64_t *indx, const int32_t *indx32, const int64_t *pntrb,
+                                     const int64_t *pntre, int64_t n_tasks, const int32_t *task_row, const int64_t *task_b,
                                      const int32_t *task_len, const int32_t *seg_off, int slices,
                                      const int64_t *lane_off_host, const float *y, int64_t ldy, float *z,
                                      int64_t ldz, int64_t *z_arg, void *workspace, size_t workspace_bytes,
                                      void *stream) {
-   return tasks_entry(imessage, m, n, k, nnz, val, indx, pntrb, pntre, n_tasks, task_row, task_b, task_len, seg_off, slices,
-                      lane_off_host, y, ldy, z, ldz, z_arg, workspace, workspace_bytes, nullptr, stream);
+   return tasks_entry(imessage, m, n, k, nnz, val, indx, indx32, pntrb, pntre, n_tasks, task_row, task_b, task_len, seg_off,
+                      slices, lane_off_host, y, ldy, z, ldz, z_arg, workspace, workspace_bytes, nullptr, stream);
 }
 
 extern "C" int fusedMM_csr_tasks_epilogue_hip(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t nnz,
-                                              const float *val, const int64_t *indx, const int64_t *pntrb,
-                                              const int64_t *pntre, int64_t n_tasks, const int32_t *task_row,
+                                              const float *val, const int64_t *indx, const int32_t *indx32,
+                                              const int64_t *pntrb, const int64_t *pntre, int64_t n_tasks, const int32_t *task_row,
                                               const int64_t *task_b, const int32_t *task_len, const int32_t *seg_off,
                                               int slices, const int64_t *lane_off_host, const float *y, int64_t ldy,
                                               float *z, int64_t ldz, void *workspace, size_t workspace_bytes,
                                               const isplib_epilogue *epilogue, void *stream) {
-   return tasks_entry(imessage, m, n, k, nnz, val, indx, pntrb, pntre, n_tasks, task_row, task_b, task_len, seg_off, slices,
-                      lane_off_host, y, ldy, z, ldz, nullptr, workspace, workspace_bytes, epilogue, stream);
+   return tasks_entry(imessage, m, n, k, nnz, val, indx, indx32, pntrb, pntre, n_tasks, task_row, task_b, task_len, seg_off,
+                      slices, lane_off_host, y, ldy, z, ldz, nullptr, workspace, workspace_bytes, epilogue, stream);
 }

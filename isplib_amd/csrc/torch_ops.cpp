@@ -65,6 +65,14 @@ void *current_stream(const Tensor &t) { return (void *)c10::hip::getCurrentHIPSt
 //   {sliceptr}                                           column-sliced kernel
 //   {task_row, task_b, task_len, seg_off, lane_off_cpu}  task-list kernel
 using Plan = std::vector<Tensor>;
+// task plan = {task_row, task_b, task_len, seg_off, lane_off (host)} + optionally the 32-bit copy of col
+static inline bool is_task_plan(const Plan &p) { return p.size() == 5 || p.size() == 6; }
+static inline const int32_t *plan_col32(const Plan &p, const Tensor &col) {
+   if (p.size() != 6) return nullptr;
+   TORCH_CHECK(p[5].scalar_type() == at::kInt && p[5].numel() == col.numel() && p[5].device() == col.device(),
+               "isplib: the plan's packed column ids do not match col");
+   return p[5].data_ptr<int32_t>();
+}
 std::tuple<Tensor, Tensor> spmm_fw(const Tensor &rowptr_, const Tensor &col_, const optional<Tensor> &value_,
                                    const Tensor &mat_, int reduction, const Plan &plan = Plan()) {
    check_index(rowptr_, "rowptr");
@@ -91,7 +99,7 @@ std::tuple<Tensor, Tensor> spmm_fw(const Tensor &rowptr_, const Tensor &col_, co
    if (reduction == R_MAX || reduction == R_MIN) arg = at::empty({M, K}, rowptr.options());
    const int64_t *rp = rowptr.data_ptr<int64_t>();
    const bool tasks_fit = K >= 4 && (double)N * (double)K * 4.0 <= 3.5 * 1073741824.0;
-   if (plan.size() == 5 && tasks_fit && M > 0 && K > 0) {
+   if (is_task_plan(plan) && tasks_fit && M > 0 && K > 0) {
       const Tensor &task_row = plan[0], &task_b = plan[1], &task_len = plan[2], &seg_off = plan[3], &lane = plan[4];
       TORCH_CHECK(task_row.is_cuda() && task_row.scalar_type() == at::kInt && task_len.scalar_type() == at::kInt &&
                       seg_off.scalar_type() == at::kInt && task_b.scalar_type() == at::kLong,
@@ -103,7 +111,7 @@ std::tuple<Tensor, Tensor> spmm_fw(const Tensor &rowptr_, const Tensor &col_, co
       const size_t ws = isplib_spmm_tasks_workspace_bytes(msg, n_tasks, K);
       Tensor work = at::empty({(int64_t)ws}, mat.options().dtype(at::kByte));
       const int st = fusedMM_csr_tasks_hip(msg, M, N, K, nnz, value.defined() ? value.data_ptr<float>() : nullptr,
-                                           col.data_ptr<int64_t>(), rp, rp + 1, n_tasks, task_row.data_ptr<int32_t>(),
+                                           col.data_ptr<int64_t>(), plan_col32(plan, col), rp, rp + 1, n_tasks, task_row.data_ptr<int32_t>(),
                                            task_b.data_ptr<int64_t>(), task_len.data_ptr<int32_t>(),
                                            seg_off.data_ptr<int32_t>(), nsl, lane.data_ptr<int64_t>(),
                                            mat.data_ptr<float>(), K, out.data_ptr<float>(), K,
@@ -165,8 +173,8 @@ Tensor sddmm(const Tensor &rowptr, const Tensor &col, const Tensor &mat, const T
    const int64_t M = rowptr.numel() - 1, N = y.size(0), K = y.size(1);
    Tensor dval = at::empty({col.numel()}, y.options());
    const int64_t *rp = rowptr.data_ptr<int64_t>();
-   if (plan.size() == 5 && K >= 4 && K <= 1024 && (double)N * (double)K * 4.0 <= 3.5 * 1073741824.0) {
-      const int st = isplib_sddmm_csr_tasks_hip(M, N, K, col.data_ptr<int64_t>(), rp, rp + 1, plan[0].numel(),
+   if (is_task_plan(plan) && K >= 4 && K <= 1024 && (double)N * (double)K * 4.0 <= 3.5 * 1073741824.0) {
+      const int st = isplib_sddmm_csr_tasks_hip(M, N, K, col.data_ptr<int64_t>(), plan_col32(plan, col), rp, rp + 1, plan[0].numel(),
                                                 plan[0].data_ptr<int32_t>(), plan[1].data_ptr<int64_t>(),
                                                 plan[2].data_ptr<int32_t>(), plan[4].data_ptr<int64_t>(),
                                                 y.data_ptr<float>(), K, g.data_ptr<float>(), K, mean ? 1 : 0,
@@ -186,7 +194,7 @@ Tensor epilogue_spmm(const Tensor &rowptr, const Tensor &col, const Plan &plan, 
                      const Tensor &row_scale, const Tensor &bias, bool relu) {
    const Tensor y = y_.contiguous();
    const int64_t M = rowptr.numel() - 1, N = y.size(0), K = y.size(1), nnz = col.numel();
-   const bool tasks_fit = plan.size() == 5 && K >= 4 && M > 0 && (double)N * (double)K * 4.0 <= 3.5 * 1073741824.0;
+   const bool tasks_fit = is_task_plan(plan) && K >= 4 && M > 0 && (double)N * (double)K * 4.0 <= 3.5 * 1073741824.0;
    if (!tasks_fit) {
       Tensor out = std::get<0>(spmm_fw(rowptr, col, c10::nullopt, y, R_SUM, plan));
       if (self_.defined()) out = out + self_;
@@ -215,7 +223,7 @@ Tensor epilogue_spmm(const Tensor &rowptr, const Tensor &col, const Plan &plan, 
    ep.relu = relu ? 1 : 0;
    const int64_t *rp = rp_c.data_ptr<int64_t>();
    const int st = fusedMM_csr_tasks_epilogue_hip(
-       ISPLIB_MSG_SPMM_SUM, M, N, K, nnz, nullptr, col_c.data_ptr<int64_t>(), rp, rp + 1, n_tasks,
+       ISPLIB_MSG_SPMM_SUM, M, N, K, nnz, nullptr, col_c.data_ptr<int64_t>(), plan_col32(plan, col_c), rp, rp + 1, n_tasks,
        plan[0].data_ptr<int32_t>(), plan[1].data_ptr<int64_t>(), plan[2].data_ptr<int32_t>(), plan[3].data_ptr<int32_t>(), nsl,
        plan[4].data_ptr<int64_t>(), y.data_ptr<float>(), K, out.data_ptr<float>(), K, work.data_ptr(), ws, &ep,
        current_stream(y));

@@ -158,8 +158,11 @@ class RowPartition:
 
     def task_plan(self, slices: int, chunk: int = 1024, short_row: int = 128):
         """Task plan (isplib_amd.plan) of this rank's rows over the padded gather layout; None if unsorted."""
+        from . import cabi
         from .plan import build_task_plan
-        return build_task_plan(self.rowptr, self.col_padded, self.ncols_padded, slices, chunk, short_row)
+        if getattr(self, "_col32", None) is None:
+            self._col32 = cabi.pack_indices(self.col_padded)
+        return build_task_plan(self.rowptr, self.col_padded, self.ncols_padded, slices, chunk, short_row, col32=self._col32)
 
     def pipeline_state(self, k: int, panels: int, reduce: str = "sum", tplan=None):
         """Operands of `spmm_pipelined` for width k: panel bounds (multiples of 4 columns), one send and one

@@ -33,6 +33,8 @@ class TaskPlan:
     lane_off: list             # 9 host ints
     chunk: int
     short_row: int
+    col32: Optional[torch.Tensor] = None   # int32 [nnz]: the column ids packed once per graph; the task kernels
+    #                                        stream these 4 bytes per edge instead of the 8 of the int64 array
 
     def workspace(self, reduce: str, k: int) -> torch.Tensor:
         nbytes = cabi.lib().isplib_spmm_tasks_workspace_bytes(cabi.MESSAGE[reduce], self.n_tasks, k)
@@ -40,9 +42,10 @@ class TaskPlan:
 
 
 def build_task_plan(rowptr: torch.Tensor, col: torch.Tensor, ncols: int, slices: int, chunk: int = 1024,
-                    short_row: int = 128) -> Optional[TaskPlan]:
+                    short_row: int = 128, col32: Optional[torch.Tensor] = None) -> Optional[TaskPlan]:
     """Slice table -> task counts + prefix (one host round trip for the task count) -> task arrays, all
-    through the C ABI.  None when the rows are not column-sorted (the slice table would be meaningless)."""
+    through the C ABI.  None when the rows are not column-sorted (the slice table would be meaningless).
+    `col32`: a packed copy of `col` shared between the plans of one graph (made here when not given)."""
     import ctypes
     assert 1 <= slices <= 4096
     m = rowptr.numel() - 1
@@ -73,5 +76,7 @@ def build_task_plan(rowptr: torch.Tensor, col: torch.Tensor, ncols: int, slices:
                                           ctypes.c_void_p(seg_off.data_ptr()), ctypes.c_void_p(task_row.data_ptr()),
                                           ctypes.c_void_p(task_b.data_ptr()), ctypes.c_void_p(task_len.data_ptr()), stream)
         cabi._check(st, "isplib_spmm_tasks_fill_hip")
+    if col32 is None:
+        col32 = cabi.pack_indices(col)
     return TaskPlan(slices, n_tasks, task_row[:n_tasks], task_b[:n_tasks], task_len[:n_tasks], seg_off,
-                    [int(v) for v in info.lane_off], chunk, short_row)
+                    [int(v) for v in info.lane_off], chunk, short_row, col32)

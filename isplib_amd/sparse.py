@@ -94,7 +94,8 @@ class SparseStorage:
 
     def plan(self, n_slices: int):
         """Schedule operands of A for the `_planned` operators: [] (plain kernel) or the task plan
-        [task_row, task_b, task_len, seg_off, lane_off_cpu]; built once per graph and slice count."""
+        [task_row, task_b, task_len, seg_off, lane_off_cpu, col32]; built once per graph and slice count
+        (col32, the packed column ids, once per graph)."""
         return self._plan_for(self._plans, n_slices, self._rowptr, self._col, self._sparse_sizes[1])
 
     def plan_t(self, n_slices: int):
@@ -109,12 +110,13 @@ class SparseStorage:
             return []
         if n_slices not in cache:
             from .plan import build_task_plan
+            shared = next((v[5] for v in cache.values() if len(v) == 6), None)     # one packed copy per graph
             try:
-                p = build_task_plan(rowptr, col, ncols, n_slices)
+                p = build_task_plan(rowptr, col, ncols, n_slices, col32=shared)
             except RuntimeError:          # e.g. a graph too large for int32 task ids: plain kernel
                 p = None
             cache[n_slices] = [] if p is None else [p.task_row, p.task_b, p.task_len, p.seg_off,
-                                                    torch.tensor(p.lane_off, dtype=torch.int64)]
+                                                    torch.tensor(p.lane_off, dtype=torch.int64), p.col32]
         return cache[n_slices]
 
     def gcn_dinv(self) -> torch.Tensor:

@@ -240,7 +240,7 @@ def test_task_entry_argument_validation_without_gpu():
     one = ctypes.c_void_p(8)      # never dereferenced: validation fails first
 
     def call(msg=cabi.MSG_SPMM_SUM, m=4, n=4, k=8, n_tasks=0, slices=8, ws=None, ws_bytes=0, lane_off=lane):
-        return L.fusedMM_csr_tasks_hip(msg, m, n, k, 0, None, one, one, one, n_tasks, one, one, one, one, slices, lane_off,
+        return L.fusedMM_csr_tasks_hip(msg, m, n, k, 0, None, one, None, one, one, n_tasks, one, one, one, one, slices, lane_off,
                                        one, k, one, k, None, ws, ws_bytes, None)
     assert call(msg=0x11103) == cabi.NO_OPT_IMPL
     assert call(slices=0) == cabi.FAIL and "[1, 4096]" in cabi.last_error()
