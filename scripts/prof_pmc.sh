@@ -1,7 +1,10 @@
 #!/bin/bash
 # usage: prof_pmc.sh <outdir> <cmd...>   -- separate --pmc passes (TCC slots: FETCH_SIZE 3, WRITE_SIZE 2)
-out=$1; shift
-mkdir -p $out
+out=$(realpath -m "$1"); shift
+mkdir -p "$out"
+args=()
+for a in "$@"; do if [ -f "$a" ]; then args+=("$(realpath "$a")"); else args+=("$a"); fi; done   # we cd away below
+set -- "${args[@]}"
 cd /tmp; export TMPDIR=/tmp
 i=0
 for ctrs in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_INST_CYCLES_VMEM_RD SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL" "GRBM_GUI_ACTIVE GRBM_TA_BUSY"; do
