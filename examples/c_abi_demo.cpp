@@ -134,6 +134,19 @@ int main() {
    HIP_OK(hipStreamSynchronize(st));
    if (!check_max("fusedMM_csr_tasks_hip")) return 1;
 
+   // 2b. the same through an isplib_graph handle: the library owns the plan, the packed ids and the workspace
+   isplib_graph *graph = nullptr;
+   ISP_OK(isplib_graph_create(m, n, nnz, d_rowptr, d_col, d_val, &graph));
+   ISP_OK(isplib_graph_set_slices(graph, S));                       // -1 would apply isplib_suggest_slices
+   HIP_OK(hipMemsetAsync(d_out, 0xff, (size_t)m * k * sizeof(float), st));
+   ISP_OK(isplib_graph_spmm(graph, ISPLIB_MSG_SPMM_SUM, k, d_x, k, d_out, k, nullptr, st));
+   HIP_OK(hipStreamSynchronize(st));
+   if (!check_sum("isplib_graph_spmm")) return 1;
+   ISP_OK(isplib_graph_spmm(graph, ISPLIB_MSG_SPMM_MAX, k, d_x, k, d_out, k, d_arg, st));
+   HIP_OK(hipStreamSynchronize(st));
+   if (!check_max("isplib_graph_spmm")) return 1;
+   isplib_graph_destroy(graph);
+
    // 3. error behaviour: the reference's status codes -- a flag value csrc/fusedMM.h does not define, and a
    //    user-defined stage (function pointers cannot cross to the device; see fusedMM_csr_udef_hip's menu)
    if (fusedMM_csr_hip(0x11108, m, n, k, 1.0f, nnz, m, n, d_val, d_col, d_rowptr, d_rowptr + 1, nullptr, k, d_x, k, 0.0f,

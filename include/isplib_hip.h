@@ -322,6 +322,33 @@ int    isplib_csr2csc_hip(int64_t m, int64_t n, int64_t nnz,
                           int64_t *csr2csc, int64_t *row_t, float *val_t,
                           void *workspace, size_t workspace_bytes, void *stream);
 
+/*
+ * isplib_graph: a handle that owns what a graph needs for the fast path -- the per-graph operands the
+ * stateless entries above leave to the caller (slice tables, task plans per slice count, the packed column
+ * ids, the CSC operands of the backward, one grow-only workspace), built lazily on the device.  It is what
+ * the reference's C++ layer (csrc/fusedmm.cpp:113-203) would hold per graph in place of the pointer-keyed
+ * dicts of isplib/__init__.py:35-40.
+ *   isplib_graph_create   borrows rowptr[m+1] / col[nnz] / val[nnz]|NULL (device; must outlive the handle)
+ *   isplib_graph_spmm     z = A (x) y for one of the four SpMM words; schedule by isplib_suggest_slices
+ *                         (or isplib_graph_set_slices: -1 rule, 0 plain kernel, 1..4096 task list)
+ *   isplib_graph_spmm_backward   dx = A^T dy (mean != 0: with weights val/max(deg,1), the mean forward's
+ *                         backward, csrc/fusedmm.cpp:375); the CSC operands are built on first use
+ *   isplib_suggest_slices the measured rule (0 = plain row-per-wave kernel)
+ * The first call that needs a new plan (or the transpose) allocates device memory and synchronises the
+ * stream once; every later call is asynchronous and allocation-free.  Not thread-safe; the calls of one
+ * handle must be ordered on one stream at a time (they share the workspace).
+ */
+typedef struct isplib_graph isplib_graph;
+int  isplib_suggest_slices(int64_t m, int64_t n, int64_t nnz, int64_t k);
+int  isplib_graph_create(int64_t m, int64_t n, int64_t nnz, const int64_t *rowptr, const int64_t *col,
+                         const float *val, isplib_graph **out);
+int  isplib_graph_set_slices(isplib_graph *g, int slices);
+int  isplib_graph_spmm(isplib_graph *g, int32_t imessage, int64_t k, const float *y, int64_t ldy,
+                       float *z, int64_t ldz, int64_t *z_arg, void *stream);
+int  isplib_graph_spmm_backward(isplib_graph *g, int mean, int64_t k, const float *dy, int64_t lddy,
+                                float *dx, int64_t lddx, void *stream);
+void isplib_graph_destroy(isplib_graph *g);
+
 #ifdef __cplusplus
 }
 #endif

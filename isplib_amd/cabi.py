@@ -49,6 +49,8 @@ EXPORTS = (
     "isplib_spmm_tasks_workspace_bytes", "fusedMM_csr_tasks_hip",
     "isplib_spmm_tasks_plan_workspace_bytes", "isplib_spmm_tasks_count_hip", "isplib_spmm_tasks_fill_hip",
     "isplib_sddmm_csr_tasks_hip", "fusedMM_csr_tasks_epilogue_hip", "fusedMM_csr_udef_hip", "isplib_pack_indices_hip",
+    "isplib_suggest_slices", "isplib_graph_create", "isplib_graph_set_slices", "isplib_graph_spmm", "isplib_graph_spmm_backward",
+    "isplib_graph_destroy",
 )
 
 _i64, _f32, _vp, _i32 = ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_int32
@@ -124,6 +126,18 @@ def lib() -> ctypes.CDLL:
         L.fusedMM_csr_tasks_epilogue_hip.argtypes = [_i32, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp,
                                                      ctypes.c_int, _vp, _vp, _i64, _vp, _i64, _vp, ctypes.c_size_t,
                                                      ctypes.POINTER(Epilogue), _vp]
+        L.isplib_suggest_slices.restype = ctypes.c_int
+        L.isplib_suggest_slices.argtypes = [_i64, _i64, _i64, _i64]
+        L.isplib_graph_create.restype = ctypes.c_int
+        L.isplib_graph_create.argtypes = [_i64, _i64, _i64, _vp, _vp, _vp, ctypes.POINTER(_vp)]
+        L.isplib_graph_set_slices.restype = ctypes.c_int
+        L.isplib_graph_set_slices.argtypes = [_vp, ctypes.c_int]
+        L.isplib_graph_spmm.restype = ctypes.c_int
+        L.isplib_graph_spmm.argtypes = [_vp, _i32, _i64, _vp, _i64, _vp, _i64, _vp, _vp]
+        L.isplib_graph_spmm_backward.restype = ctypes.c_int
+        L.isplib_graph_spmm_backward.argtypes = [_vp, ctypes.c_int, _i64, _vp, _i64, _vp, _i64, _vp]
+        L.isplib_graph_destroy.restype = None
+        L.isplib_graph_destroy.argtypes = [_vp]
         L.isplib_hip_tune.restype = ctypes.c_int
         L.isplib_hip_tune.argtypes = [ctypes.c_int, ctypes.c_int]
         _sigs_set = True
@@ -444,3 +458,51 @@ def spmm_tasks_epilogue(rowptr, col, val, plan, y, reduce="sum", row_scale=None,
                                                   k, _ptr(work), work.numel(), ctypes.byref(ep), _stream(y.device))
     _check(st, "fusedMM_csr_tasks_epilogue_hip")
     return out
+
+
+class GraphHandle:
+    """ctypes view of `isplib_graph` (include/isplib_hip.h): the torch-free host's per-graph object.  torch only
+    supplies the device buffers here; plans, packed ids, CSC operands and workspace live inside the library."""
+
+    def __init__(self, rowptr, col, val, ncols: int):
+        self.rowptr = _dev(rowptr, "rowptr", torch.int64)       # borrowed by the handle: keep them alive
+        self.col = _dev(col, "col", torch.int64)
+        self.val = None if val is None else _dev(val, "val", torch.float32)
+        self.m, self.n = self.rowptr.numel() - 1, int(ncols)
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.col.device):
+            _check(lib().isplib_graph_create(self.m, self.n, self.col.numel(), _ptr(self.rowptr), _ptr(self.col),
+                                             _ptr(self.val), ctypes.byref(self._h)), "isplib_graph_create")
+
+    def set_slices(self, slices: int) -> None:
+        _check(lib().isplib_graph_set_slices(self._h, int(slices)), "isplib_graph_set_slices")
+
+    def spmm(self, y: torch.Tensor, reduce: str = "sum"):
+        y = _dev(y, "y", torch.float32)
+        k = y.size(1)
+        out = torch.empty((self.m, k), dtype=torch.float32, device=y.device)
+        arg = torch.empty((self.m, k), dtype=torch.int64, device=y.device) if reduce in ("max", "min") else None
+        with torch.cuda.device(y.device):
+            _check(lib().isplib_graph_spmm(self._h, MESSAGE[reduce], k, _ptr(y), k, _ptr(out), k, _ptr(arg), _stream(y.device)),
+                   "isplib_graph_spmm")
+        return out, arg
+
+    def spmm_backward(self, dy: torch.Tensor, mean: bool = False) -> torch.Tensor:
+        dy = _dev(dy, "dy", torch.float32)
+        k = dy.size(1)
+        dx = torch.empty((self.n, k), dtype=torch.float32, device=dy.device)
+        with torch.cuda.device(dy.device):
+            _check(lib().isplib_graph_spmm_backward(self._h, int(bool(mean)), k, _ptr(dy), k, _ptr(dx), k, _stream(dy.device)),
+                   "isplib_graph_spmm_backward")
+        return dx
+
+    def close(self) -> None:
+        if self._h:
+            lib().isplib_graph_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass

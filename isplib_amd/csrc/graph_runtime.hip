@@ -1,0 +1,257 @@
+// graph_runtime.hip -- isplib_graph: a handle that owns everything a graph needs for the fast path.
+//
+// The stateless entries (fusedMM_csr_hip, fusedMM_csr_tasks_hip, ...) leave allocation and caching to the
+// caller; isplib_amd/plan.py + sparse.py do that for torch hosts.  This file is the same thing for hosts
+// without torch (the reference's C++ layer, csrc/fusedmm.cpp:113-203, would keep one handle per graph where
+// isplib/__init__.py:35-40 keeps its pointer-keyed dicts): per-graph operands built lazily on the device,
+// cached per slice count, one grow-only workspace, the schedule picked by the same measured rule.
+//   forward   out = A (x) y            isplib_graph_spmm
+//   backward  dX  = A^T dY             isplib_graph_spmm_backward   (sum, or mean with val/deg weights,
+//                                                                    csrc/fusedmm.cpp:285,375)
+// First use of a (side, slice count) allocates and synchronises the stream once; after that every call is
+// asynchronous and allocation-free.  A handle is not thread-safe and its calls must be ordered on one
+// stream at a time (the workspace is shared).
+#include <map>
+#include <new>
+
+#include "common.h"
+
+using namespace isplib;
+
+namespace {
+
+struct Plan {
+   bool usable = false;          // false: rows not column-sorted (or too large for 32-bit task ids) -> plain kernel
+   int64_t n_tasks = 0;
+   int32_t *task_row = nullptr, *task_len = nullptr, *seg_off = nullptr;
+   int64_t *task_b = nullptr;
+   int64_t lane_off[9] = {0};
+};
+
+struct Side {                    // A, or A^T, as CSR
+   int64_t m = 0, n = 0, nnz = 0;
+   const int64_t *rowptr = nullptr, *col = nullptr;
+   const float *val = nullptr;
+   int32_t *col32 = nullptr;
+   std::map<int, Plan> plans;
+};
+
+void free_side(Side &s, bool owns_arrays) {
+   for (auto &kv : s.plans) {
+      (void)hipFree(kv.second.task_row); (void)hipFree(kv.second.task_len);
+      (void)hipFree(kv.second.seg_off); (void)hipFree(kv.second.task_b);
+   }
+   s.plans.clear();
+   (void)hipFree(s.col32);
+   s.col32 = nullptr;
+   if (owns_arrays) {
+      (void)hipFree(const_cast<int64_t *>(s.rowptr)); (void)hipFree(const_cast<int64_t *>(s.col));
+      (void)hipFree(const_cast<float *>(s.val));
+   }
+}
+
+}  // namespace
+
+struct isplib_graph {
+   Side fwd, bwd;                // bwd = A^T, built on first backward call
+   bool has_bwd = false;
+   float *mean_val_t = nullptr;  // val[csr2csc] / max(deg(row),1): the mean backward's weights
+   void *work = nullptr;
+   size_t work_bytes = 0;
+   int forced_slices = -1;       // -1: isplib_suggest_slices
+};
+
+#define TRY_ALLOC(ptr, bytes)                                                                              \
+   do {                                                                                                    \
+      if (hipMalloc((void **)&(ptr), (bytes) ? (bytes) : 256) != hipSuccess) {                             \
+         (void)hipGetLastError();                                                                          \
+         return fail(ISPLIB_NOT_ENOUGH_MEM, "isplib_graph: device allocation failed");                     \
+      }                                                                                                    \
+   } while (0)
+
+extern "C" int isplib_suggest_slices(int64_t m, int64_t n, int64_t nnz, int64_t k) {
+   // Measured on MI355X: about 7 MB of the dense operand per slice (2x an XCD's L2),
+   // never fewer than k/20 slices on a graph with work for the whole chip, at least ~20 edges per row and
+   // slice; wide k is swept in 128-column panels, so it counts as 128.  0 = plain row-per-wave kernel.
+   if (m <= 0 || n <= 0 || k <= 0) return 0;
+   if (k >= 192) k = 128;
+   const double avg_deg = (double)nnz / (double)m;
+   if (nnz < (1 << 20) || avg_deg < 64.0) return 0;
+   const double by_cache = (double)n * (double)k * 4.0 / (double)(7 << 20);
+   double s = by_cache > (double)k / 20.0 ? by_cache : (double)k / 20.0;
+   if (avg_deg / 20.0 < s) s = avg_deg / 20.0;
+   int r = (int)(s + 0.5);
+   return r < 1 ? 1 : (r > 64 ? 64 : r);
+}
+
+extern "C" int isplib_graph_create(int64_t m, int64_t n, int64_t nnz, const int64_t *rowptr, const int64_t *col,
+                                   const float *val, isplib_graph **out) {
+   clear_error();
+   if (!out) return fail(ISPLIB_FAIL, "isplib_graph_create: out is NULL");
+   *out = nullptr;
+   if (m < 0 || n < 0 || nnz < 0 || n > 0x7fffffffLL) return fail(ISPLIB_FAIL, "isplib_graph_create: bad dimension (n must be < 2^31)");
+   if (!rowptr || (nnz > 0 && !col)) return fail(ISPLIB_FAIL, "isplib_graph_create: null operand");
+   isplib_graph *g = new (std::nothrow) isplib_graph();
+   if (!g) return fail(ISPLIB_NOT_ENOUGH_MEM, "isplib_graph_create: host allocation failed");
+   g->fwd.m = m; g->fwd.n = n; g->fwd.nnz = nnz; g->fwd.rowptr = rowptr; g->fwd.col = col; g->fwd.val = val;
+   *out = g;
+   return ISPLIB_SUCCESS;
+}
+
+extern "C" void isplib_graph_destroy(isplib_graph *g) {
+   if (!g) return;
+   (void)hipDeviceSynchronize();           // nothing of ours may still be in flight
+   free_side(g->fwd, false);
+   free_side(g->bwd, true);
+   (void)hipFree(g->mean_val_t);
+   (void)hipFree(g->work);
+   delete g;
+}
+
+extern "C" int isplib_graph_set_slices(isplib_graph *g, int slices) {
+   clear_error();
+   if (!g) return fail(ISPLIB_FAIL, "isplib_graph_set_slices: null handle");
+   if (slices < -1 || slices > ISPLIB_MAX_SLICES) return fail(ISPLIB_FAIL, "isplib_graph_set_slices: -1 (rule), 0 (plain) or 1..4096");
+   g->forced_slices = slices;
+   return ISPLIB_SUCCESS;
+}
+
+static int ensure_work(isplib_graph *g, size_t bytes, hipStream_t st) {
+   if (g->work_bytes >= bytes) return ISPLIB_SUCCESS;
+   if (g->work) {
+      ISPLIB_HIP_TRY(hipStreamSynchronize(st));          // an earlier call may still be reading the old one
+      (void)hipFree(g->work);
+      g->work = nullptr; g->work_bytes = 0;
+   }
+   TRY_ALLOC(g->work, bytes);
+   g->work_bytes = bytes;
+   return ISPLIB_SUCCESS;
+}
+
+// slice table -> task counts -> task arrays, all on the device; one stream synchronisation (inside count)
+static int build_plan(isplib_graph *g, Side &s, int slices, hipStream_t st, Plan &p) {
+   const int64_t m = s.m;
+   if ((double)m * slices + (double)s.nnz / 1024.0 + 1.0 >= 2147483647.0) return ISPLIB_SUCCESS;   // int32 task ids
+   int64_t *table = nullptr;
+   int32_t *flag = nullptr;
+   void *tmp = nullptr;
+   TRY_ALLOC(table, isplib_spmm_slices_bytes(m, slices));
+   int rc = ISPLIB_SUCCESS;
+   int32_t unsorted = 0;
+   isplib_task_plan_info info;
+   const size_t tmp_bytes = isplib_spmm_tasks_plan_workspace_bytes(m, slices);
+   do {
+      if (hipMalloc((void **)&flag, 256) != hipSuccess || hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 256) != hipSuccess ||
+          hipMalloc((void **)&p.seg_off, ((size_t)m * slices + 1) * sizeof(int32_t)) != hipSuccess) {
+         (void)hipGetLastError();
+         rc = fail(ISPLIB_NOT_ENOUGH_MEM, "isplib_graph: device allocation failed");
+         break;
+      }
+      rc = isplib_spmm_slices_build_hip(m, s.n, s.nnz, s.rowptr, s.rowptr + 1, s.col, slices, table, flag, st);
+      if (rc) break;
+      if (hipMemcpyAsync(&unsorted, flag, sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+          hipStreamSynchronize(st) != hipSuccess) { rc = hip_fail(hipGetLastError(), "isplib_graph: reading the sortedness flag"); break; }
+      if (unsorted) break;                  // plan stays unusable: the plain kernel serves this graph
+      rc = isplib_spmm_tasks_count_hip(m, s.rowptr, s.rowptr + 1, table, slices, 1024, 128, p.seg_off, tmp, tmp_bytes, &info, st);
+      if (rc) break;
+      p.n_tasks = info.n_tasks;
+      for (int x = 0; x < 9; x++) p.lane_off[x] = info.lane_off[x];
+      const size_t nt = (size_t)(p.n_tasks > 0 ? p.n_tasks : 1);
+      if (hipMalloc((void **)&p.task_row, nt * sizeof(int32_t)) != hipSuccess || hipMalloc((void **)&p.task_len, nt * sizeof(int32_t)) != hipSuccess ||
+          hipMalloc((void **)&p.task_b, nt * sizeof(int64_t)) != hipSuccess) {
+         (void)hipGetLastError();
+         rc = fail(ISPLIB_NOT_ENOUGH_MEM, "isplib_graph: device allocation failed");
+         break;
+      }
+      rc = isplib_spmm_tasks_fill_hip(m, s.rowptr, s.rowptr + 1, table, &info, p.seg_off, p.task_row, p.task_b, p.task_len, st);
+      if (rc) break;
+      if (!s.col32 && s.nnz > 0) {
+         if (hipMalloc((void **)&s.col32, (size_t)s.nnz * sizeof(int32_t)) != hipSuccess) { (void)hipGetLastError(); s.col32 = nullptr; }
+         else if ((rc = isplib_pack_indices_hip(s.nnz, s.col, s.col32, st)) != 0) break;
+      }
+      if (hipStreamSynchronize(st) != hipSuccess) { rc = hip_fail(hipGetLastError(), "isplib_graph: plan build"); break; }
+      p.usable = true;
+   } while (0);
+   (void)hipFree(table); (void)hipFree(flag); (void)hipFree(tmp);
+   (void)g;
+   return rc;
+}
+
+static int run_side(isplib_graph *g, Side &s, const float *val, int32_t imessage, int64_t k, const float *y, int64_t ldy,
+                    float *z, int64_t ldz, int64_t *z_arg, hipStream_t st) {
+   int slices = g->forced_slices >= 0 ? g->forced_slices : isplib_suggest_slices(s.m, s.n, s.nnz, k);
+   if (k < 4 || (double)s.n * (double)ldy * 4.0 > 3.5 * 1073741824.0) slices = 0;      // outside the task entry's domain
+   if (slices > 0) {
+      auto it = s.plans.find(slices);
+      if (it == s.plans.end()) {
+         Plan p;
+         const int rc = build_plan(g, s, slices, st, p);
+         if (rc) {
+            (void)hipFree(p.task_row); (void)hipFree(p.task_len); (void)hipFree(p.seg_off); (void)hipFree(p.task_b);
+            return rc;
+         }
+         it = s.plans.emplace(slices, p).first;
+      }
+      const Plan &p = it->second;
+      if (p.usable) {
+         const size_t need = isplib_spmm_tasks_workspace_bytes(imessage, p.n_tasks, k < 192 ? k : 128);
+         const int rc = ensure_work(g, need, st);
+         if (rc) return rc;
+         return fusedMM_csr_tasks_hip(imessage, s.m, s.n, k, s.nnz, val, s.col, s.col32, s.rowptr, s.rowptr + 1, p.n_tasks,
+                                      p.task_row, p.task_b, p.task_len, p.seg_off, slices, p.lane_off, y, ldy, z, ldz, z_arg,
+                                      g->work, g->work_bytes, st);
+      }
+   }
+   return fusedMM_csr_hip(imessage, s.m, s.n, k, 1.0f, s.nnz, s.m, s.n, val, s.col, s.rowptr, s.rowptr + 1, nullptr, k, y, ldy,
+                          0.0f, z, ldz, z_arg, st);
+}
+
+extern "C" int isplib_graph_spmm(isplib_graph *g, int32_t imessage, int64_t k, const float *y, int64_t ldy, float *z,
+                                 int64_t ldz, int64_t *z_arg, void *stream) {
+   clear_error();
+   if (!g) return fail(ISPLIB_FAIL, "isplib_graph_spmm: null handle");
+   return run_side(g, g->fwd, g->fwd.val, imessage, k, y, ldy, z, ldz, z_arg, (hipStream_t)stream);
+}
+
+static int ensure_transpose(isplib_graph *g, hipStream_t st) {
+   if (g->has_bwd) return ISPLIB_SUCCESS;
+   const Side &a = g->fwd;
+   Side t;
+   t.m = a.n; t.n = a.m; t.nnz = a.nnz;
+   int64_t *colptr = nullptr, *row_t = nullptr;
+   float *val_t = nullptr;
+   void *ws = nullptr;
+   const size_t ws_bytes = isplib_csr2csc_workspace_bytes(a.m, a.n, a.nnz);
+   int rc = ISPLIB_SUCCESS;
+   const size_t e = (size_t)(a.nnz > 0 ? a.nnz : 1);
+   if (hipMalloc((void **)&colptr, ((size_t)a.n + 1) * sizeof(int64_t)) != hipSuccess || hipMalloc((void **)&row_t, e * sizeof(int64_t)) != hipSuccess ||
+       (a.val && hipMalloc((void **)&val_t, e * sizeof(float)) != hipSuccess) || hipMalloc((void **)&g->mean_val_t, e * sizeof(float)) != hipSuccess ||
+       hipMalloc(&ws, ws_bytes ? ws_bytes : 256) != hipSuccess) {
+      (void)hipGetLastError();
+      rc = fail(ISPLIB_NOT_ENOUGH_MEM, "isplib_graph: device allocation failed (transpose)");
+   }
+   // two passes of the same stable sort: the plain weights (sum backward), then val / max(deg,1) (mean backward)
+   if (!rc && a.val) rc = isplib_csr2csc_hip(a.m, a.n, a.nnz, a.rowptr, a.col, a.val, 0, colptr, nullptr, row_t, val_t, ws, ws_bytes, st);
+   if (!rc) rc = isplib_csr2csc_hip(a.m, a.n, a.nnz, a.rowptr, a.col, a.val, 1, colptr, nullptr, row_t, g->mean_val_t, ws, ws_bytes, st);
+   if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = hip_fail(hipGetLastError(), "isplib_graph: transpose");
+   (void)hipFree(ws);
+   if (rc) {
+      (void)hipFree(colptr); (void)hipFree(row_t); (void)hipFree(val_t); (void)hipFree(g->mean_val_t);
+      g->mean_val_t = nullptr;
+      return rc;
+   }
+   t.rowptr = colptr; t.col = row_t; t.val = val_t;
+   g->bwd = t;
+   g->has_bwd = true;
+   return ISPLIB_SUCCESS;
+}
+
+extern "C" int isplib_graph_spmm_backward(isplib_graph *g, int mean, int64_t k, const float *dy, int64_t lddy, float *dx,
+                                          int64_t lddx, void *stream) {
+   clear_error();
+   if (!g) return fail(ISPLIB_FAIL, "isplib_graph_spmm_backward: null handle");
+   hipStream_t st = (hipStream_t)stream;
+   const int rc = ensure_transpose(g, st);
+   if (rc) return rc;
+   return run_side(g, g->bwd, mean ? g->mean_val_t : g->bwd.val, ISPLIB_MSG_SPMM_SUM, k, dy, lddy, dx, lddx, nullptr, st);
+}

@@ -96,16 +96,8 @@ def suggest_slices(m: int, n: int, nnz: int, k: int, minmax: bool = False) -> in
     K=64 -> 8, K=128 and wider (128-column panels) -> 16, same for max/min; a tenth of it at K=128 -> 6;
     ogbn-products-shaped (mean degree 50) or under a million edges -> 0 (plain kernel, no preparation)."""
     del minmax
-    if m <= 0 or n <= 0:
-        return 0
-    if k >= 192:          # the task entry sweeps wide K in 128-column panels: each pass is a K = 128 problem
-        k = 128
-    avg_deg = nnz / m
-    if nnz < (1 << 20) or avg_deg < 64:
-        return 0
-    by_cache = (n * k * 4) / float(7 << 20)
-    s = int(min(max(by_cache, k / 20.0), avg_deg / 20.0) + 0.5)
-    return min(max(s, 1), 64)
+    from . import cabi
+    return int(cabi.lib().isplib_suggest_slices(int(m), int(n), int(nnz), int(k)))     # one rule, in the C ABI
 
 
 # Measured choices that outlive the process: {graph signature: {"rows:k:minmax": slice count}}.  Filled by

@@ -433,3 +433,39 @@ def test_task_epilogue_entry_point(gpu, oracle_mod):
         _close(got, ref, rtol=1e-5, atol=2e-5)
     with pytest.raises(RuntimeError, match="sum / mean only"):
         cabi.spmm_tasks_epilogue(_t(rowptr, gpu), _t(col, gpu), None, plan, _t(x, gpu), "max", relu=True)
+
+
+def test_graph_handle_runs_the_fast_path_for_torch_free_hosts(gpu, oracle_mod):
+    """isplib_graph (include/isplib_hip.h): the library-owned per-graph state -- plans, packed ids, CSC operands,
+    workspace -- behind create / spmm / spmm_backward / destroy, against the oracle for every reduction and for the
+    sum and mean backward; plain kernel, rule and forced slice counts give the same answers."""
+    from isplib_amd import cabi
+    rowptr, col = cases.random_csr(300, 260, 40.0, seed=12, empty_rows=(0, 299), hub=(17, 3000), duplicates=True)
+    val = cases.weights(col.size, 4)
+    x, g = cases.dense(260, 48, 3), cases.dense(300, 48, 5)
+    for weights in (val, None):
+        h = cabi.GraphHandle(_t(rowptr, gpu), _t(col, gpu), None if weights is None else _t(weights, gpu), 260)
+        hv = weights if weights is not None else np.ones(col.size, np.float32)
+        tol = cases.sum_tolerance(oracle_mod, rowptr, col, hv, x)
+        for slices in (-1, 0, 1, 7):
+            h.set_slices(slices)
+            for red in cases.REDUCES:
+                ref, ref_arg = oracle_mod.spmm_fw(rowptr, col, hv, x, red)
+                out, arg = h.spmm(_t(x, gpu), red)
+                if red in ("max", "min"):
+                    assert np.array_equal(out.cpu().numpy().view(np.uint32), ref.view(np.uint32)), (red, slices)
+                    assert np.array_equal(arg.cpu().numpy(), ref_arg), (red, slices)
+                else:
+                    deg = np.maximum(np.diff(rowptr), 1)[:, None] if red == "mean" else 1
+                    assert np.all(np.abs(out.cpu().numpy() - ref) <= tol / deg + 1e-12), (red, slices)
+            dx = h.spmm_backward(_t(g, gpu)).cpu().numpy()
+            dref = oracle_mod.spmm_sum_bw(rowptr, col, hv, 260, g)
+            dmag = oracle_mod.spmm_sum_bw(rowptr, col, np.abs(hv), 260, np.abs(g))
+            assert np.all(np.abs(dx - dref) <= 1e-5 * dmag + 1e-30), slices
+            dxm = h.spmm_backward(_t(g, gpu), mean=True).cpu().numpy()
+            mref = oracle_mod.spmm_mean_bw(rowptr, col, hv, 260, g)
+            assert np.all(np.abs(dxm - mref) <= 1e-5 * dmag + 1e-30), slices
+        h.close()
+        h.close()                                                   # idempotent
+    with pytest.raises(RuntimeError):
+        cabi.GraphHandle(_t(rowptr, gpu), _t(col, gpu), None, 2 ** 31 + 5)

@@ -329,3 +329,21 @@ def test_tuning_table_persists_by_graph_signature(tmp_path):
     assert plugin.choose_slices(same_shape, 3, 128) == 16             # keyed by content, not by object or pointer
     assert plugin.choose_slices(same_shape, 3, 64) == 0
     plugin._tuning_db.clear()
+
+
+def test_slice_rule_lives_in_the_c_abi_and_handle_entries_validate():
+    import ctypes
+    from isplib_amd import cabi, plugin
+    L = cabi.lib()
+    n, nnz = 232965, 114615892                                     # the Reddit shape: K=32 -> 4, 64 -> 8, >=128 -> 16
+    assert [L.isplib_suggest_slices(n, n, nnz, k) for k in (32, 64, 128, 256, 608)] == [4, 8, 16, 16, 16]
+    assert L.isplib_suggest_slices(2449029, 2449029, 123718280, 256) == 0      # products: mean degree 50 -> plain
+    assert L.isplib_suggest_slices(2708, 2708, 10556, 16) == 0                  # Cora: launch-bound, no preparation
+    assert plugin.suggest_slices(n, n, nnz, 128, True) == 16                    # the Python name is the same rule
+    assert L.isplib_graph_spmm(None, cabi.MSG_SPMM_SUM, 8, None, 8, None, 8, None, None) == cabi.FAIL
+    assert "null handle" in cabi.last_error()
+    assert L.isplib_graph_set_slices(None, 4) == cabi.FAIL
+    out = ctypes.c_void_p()
+    assert L.isplib_graph_create(4, 1 << 31, 0, ctypes.c_void_p(8), None, None, ctypes.byref(out)) == cabi.FAIL
+    assert L.isplib_graph_create(-1, 4, 0, ctypes.c_void_p(8), None, None, ctypes.byref(out)) == cabi.FAIL
+    L.isplib_graph_destroy(None)                                   # a no-op, like free(NULL)
