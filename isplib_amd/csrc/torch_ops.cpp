@@ -26,7 +26,9 @@
 #include <torch/library.h>
 
 #include <initializer_list>
+#include <mutex>
 #include <tuple>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/isplib_hip.h"
@@ -67,12 +69,85 @@ void *current_stream(const Tensor &t) { return (void *)c10::hip::getCurrentHIPSt
 using Plan = std::vector<Tensor>;
 // task plan = {task_row, task_b, task_len, seg_off, lane_off (host)} + optionally the 32-bit copy of col
 static inline bool is_task_plan(const Plan &p) { return p.size() == 5 || p.size() == 6; }
+// what the reference-schema operators pass: "no plan was given, choose for me" (one undefined tensor), as opposed
+// to the empty plan of the *_planned operators, which means "the plain kernel, please"
+static inline Plan auto_plan() { return Plan{Tensor()}; }
+static inline bool is_auto_plan(const Plan &p) { return p.size() == 1 && !p[0].defined(); }
 static inline const int32_t *plan_col32(const Plan &p, const Tensor &col) {
    if (p.size() != 6) return nullptr;
    TORCH_CHECK(p[5].scalar_type() == at::kInt && p[5].numel() == col.numel() && p[5].device() == col.device(),
                "isplib: the plan's packed column ids do not match col");
    return p[5].data_ptr<int32_t>();
 }
+// ---- per-graph handles for callers that pass no plan (the reference-schema operators) --------------------------
+// iSpLib's Python keeps its per-graph operands in dicts keyed by raw data pointers (isplib/__init__.py:35-40,50) and
+// calls the operators with just (rowptr, col, value, mat).  To give that caller the task-list schedule, the
+// operator library keeps one isplib_graph per (rowptr, col, value) triple it has seen -- keyed by the same
+// pointers, but every hit is checked against weak references to the very tensors (and their version counters),
+// so a freed-and-reused address can never serve a stale plan.  Small graphs (rule says 0 slices) never get here.
+struct GraphCacheEntry {
+   c10::weak_intrusive_ptr<c10::TensorImpl> rowptr, col, value;
+   uint32_t v_rowptr = 0, v_col = 0, v_value = 0;
+   bool has_value = false;
+   isplib_graph *handle = nullptr;
+   GraphCacheEntry(const Tensor &r, const Tensor &c, const Tensor &v)
+       : rowptr(r.getIntrusivePtr()), col(c.getIntrusivePtr()), value(v.defined() ? v.getIntrusivePtr() : c.getIntrusivePtr()),
+         v_rowptr(r._version()), v_col(c._version()), v_value(v.defined() ? v._version() : 0), has_value(v.defined()) {}
+   bool alive() const { return !rowptr.expired() && !col.expired() && !value.expired(); }
+   bool matches(const Tensor &r, const Tensor &c, const Tensor &v) const {
+      return rowptr.lock() == r.getIntrusivePtr() && col.lock() == c.getIntrusivePtr() && has_value == v.defined() &&
+             (!v.defined() || value.lock() == v.getIntrusivePtr()) && v_rowptr == r._version() && v_col == c._version() &&
+             (!v.defined() || v_value == v._version());
+   }
+};
+struct GraphKey {
+   const void *rowptr, *col, *value;
+   int64_t n;
+   bool operator==(const GraphKey &o) const { return rowptr == o.rowptr && col == o.col && value == o.value && n == o.n; }
+};
+struct GraphKeyHash {
+   size_t operator()(const GraphKey &k) const {
+      return std::hash<const void *>()(k.rowptr) ^ (std::hash<const void *>()(k.col) << 1) ^ (std::hash<const void *>()(k.value) << 2) ^
+             std::hash<int64_t>()(k.n);
+   }
+};
+std::mutex g_graph_mutex;
+std::unordered_map<GraphKey, GraphCacheEntry, GraphKeyHash> g_graphs;
+
+// runs the SpMM through a cached handle; false = not applicable (caller falls through to the plain kernel)
+bool spmm_through_handle(int32_t msg, const Tensor &rowptr, const Tensor &col, const Tensor &value, const Tensor &mat,
+                         Tensor &out, Tensor &arg) {
+   const int64_t M = rowptr.numel() - 1, N = mat.size(0), K = mat.size(1), nnz = col.numel();
+   if (isplib_suggest_slices(M, N, nnz, K) <= 0) return false;
+   std::lock_guard<std::mutex> lock(g_graph_mutex);        // also serialises the handle's shared workspace
+   const GraphKey key{rowptr.data_ptr(), col.data_ptr(), value.defined() ? value.data_ptr() : nullptr, N};
+   auto it = g_graphs.find(key);
+   if (it != g_graphs.end() && !it->second.matches(rowptr, col, value)) {
+      isplib_graph_destroy(it->second.handle);
+      g_graphs.erase(it);
+      it = g_graphs.end();
+   }
+   if (it == g_graphs.end()) {
+      for (auto dead = g_graphs.begin(); dead != g_graphs.end();) {      // graphs whose tensors are gone
+         if (!dead->second.alive()) {
+            isplib_graph_destroy(dead->second.handle);
+            dead = g_graphs.erase(dead);
+         } else {
+            ++dead;
+         }
+      }
+      GraphCacheEntry e(rowptr, col, value);
+      check_status(isplib_graph_create(M, N, nnz, rowptr.data_ptr<int64_t>(), col.data_ptr<int64_t>(),
+                                       value.defined() ? value.data_ptr<float>() : nullptr, &e.handle),
+                   "isplib_graph_create");
+      it = g_graphs.emplace(key, std::move(e)).first;
+   }
+   check_status(isplib_graph_spmm(it->second.handle, msg, K, mat.data_ptr<float>(), K, out.data_ptr<float>(), K,
+                                  arg.defined() ? arg.data_ptr<int64_t>() : nullptr, current_stream(mat)),
+                "isplib_graph_spmm");
+   return true;
+}
+
 std::tuple<Tensor, Tensor> spmm_fw(const Tensor &rowptr_, const Tensor &col_, const optional<Tensor> &value_,
                                    const Tensor &mat_, int reduction, const Plan &plan = Plan()) {
    check_index(rowptr_, "rowptr");
@@ -120,7 +195,7 @@ std::tuple<Tensor, Tensor> spmm_fw(const Tensor &rowptr_, const Tensor &col_, co
       check_status(st, "fusedMM_csr_tasks_hip");
       return std::make_tuple(out, arg);
    }
-   if (plan.size() == 1 && M > 0 && K > 0) {
+   if (plan.size() == 1 && plan[0].defined() && M > 0 && K > 0) {
       check_index(plan[0], "slices");
       const Tensor table = plan[0].contiguous();
       TORCH_CHECK(table.numel() % M == 0 && table.numel() / M >= 9, "isplib: slice table does not match rowptr");
@@ -135,6 +210,10 @@ std::tuple<Tensor, Tensor> spmm_fw(const Tensor &rowptr_, const Tensor &col_, co
       check_status(st, "fusedMM_csr_sliced_hip");
       return std::make_tuple(out, arg);
    }
+   // no plan given (the reference's own call pattern): large graphs go through a cached per-graph handle
+   if (is_auto_plan(plan) && M > 0 && K > 0 && rowptr.is_same(rowptr_) && col.is_same(col_) &&
+       (!value.defined() || value.is_same(*value_)) && spmm_through_handle(msg, rowptr, col, value, mat, out, arg))
+      return std::make_tuple(out, arg);
    const int st = fusedMM_csr_hip(msg, M, N, K, 1.0f, nnz, M, N, value.defined() ? value.data_ptr<float>() : nullptr,
                                   col.data_ptr<int64_t>(), rp, rp + 1, nullptr, K, mat.data_ptr<float>(), K, 0.0f,
                                   out.data_ptr<float>(), K, arg.defined() ? arg.data_ptr<int64_t>() : nullptr,
@@ -433,7 +512,7 @@ Tensor fusedmm_spmm_add(optional<Tensor> opt_row, Tensor rowptr, Tensor col, opt
                         optional<Tensor> opt_colptr, optional<Tensor> opt_csr2csc, Tensor mat,
                         optional<Tensor> value_index_select, optional<Tensor> row_index_select) {
    return SpmmSum::apply(opt_row, rowptr, col, opt_value, opt_colptr, opt_csr2csc, mat, value_index_select,
-                         row_index_select, Plan(), Plan())[0];
+                         row_index_select, auto_plan(), auto_plan())[0];
 }
 
 // same operators fed with the per-graph schedule operands of A (forward) and A^T (backward)
@@ -459,11 +538,11 @@ Tensor fusedmm_spmm_mean(optional<Tensor> opt_row, Tensor rowptr, Tensor col, op
                          optional<Tensor> opt_rowcount, optional<Tensor> opt_colptr, optional<Tensor> opt_csr2csc,
                          Tensor mat, optional<Tensor> new_row, optional<Tensor> new_rowcount) {
    return SpmmMean::apply(opt_row, rowptr, col, opt_value, opt_rowcount, opt_colptr, opt_csr2csc, mat, new_row,
-                          new_rowcount, Plan(), Plan())[0];
+                          new_rowcount, auto_plan(), auto_plan())[0];
 }
 
 std::tuple<Tensor, Tensor> fusedmm_spmm_max(Tensor rowptr, Tensor col, optional<Tensor> opt_value, Tensor mat) {
-   auto r = SpmmMinMax<R_MAX>::apply(rowptr, col, opt_value, mat, Plan());
+   auto r = SpmmMinMax<R_MAX>::apply(rowptr, col, opt_value, mat, auto_plan());
    return std::make_tuple(r[0], r[1]);
 }
 
@@ -480,8 +559,19 @@ std::tuple<Tensor, Tensor> fusedmm_spmm_min_planned(Tensor rowptr, Tensor col, o
 }
 
 std::tuple<Tensor, Tensor> fusedmm_spmm_min(Tensor rowptr, Tensor col, optional<Tensor> opt_value, Tensor mat) {
-   auto r = SpmmMinMax<R_MIN>::apply(rowptr, col, opt_value, mat, Plan());
+   auto r = SpmmMinMax<R_MIN>::apply(rowptr, col, opt_value, mat, auto_plan());
    return std::make_tuple(r[0], r[1]);
+}
+
+// introspection / housekeeping of the per-graph handle cache of the reference-schema operators
+int64_t graph_cache_size() {
+   std::lock_guard<std::mutex> lock(g_graph_mutex);
+   return (int64_t)g_graphs.size();
+}
+void graph_cache_clear() {
+   std::lock_guard<std::mutex> lock(g_graph_mutex);
+   for (auto &kv : g_graphs) isplib_graph_destroy(kv.second.handle);
+   g_graphs.clear();
 }
 
 void performDummySpMM(int64_t flag) { performDummySpMM_hip(flag, (void *)c10::hip::getCurrentHIPStream().stream()); }
@@ -501,6 +591,8 @@ TORCH_LIBRARY(isplib, m) {
    m.def("fusedmm_spmm_min(Tensor rowptr, Tensor col, Tensor? value, Tensor mat) -> (Tensor, Tensor)",
          &fusedmm_spmm_min);
    m.def("performDummySpMM(int flag) -> ()", &performDummySpMM);
+   m.def("graph_cache_size() -> int", &graph_cache_size);
+   m.def("graph_cache_clear() -> ()", &graph_cache_clear);
    // additions (not in the reference): the same operators fed with per-graph schedule operands
    // (plan = [] | [sliceptr] | [task_row, task_b, task_len, seg_off, lane_off_cpu]; plan_t: the same for A^T)
    m.def("fusedmm_spmm_planned(Tensor rowptr, Tensor col, Tensor? value, Tensor? colptr, Tensor mat, Tensor? value_t, "

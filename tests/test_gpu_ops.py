@@ -469,3 +469,50 @@ def test_graph_handle_runs_the_fast_path_for_torch_free_hosts(gpu, oracle_mod):
         h.close()                                                   # idempotent
     with pytest.raises(RuntimeError):
         cabi.GraphHandle(_t(rowptr, gpu), _t(col, gpu), None, 2 ** 31 + 5)
+
+
+def test_reference_schema_ops_get_the_task_schedule_through_cached_handles(gpu, oracle_mod):
+    """INTEGRATION.md option B: iSpLib's own Python calls torch.ops.isplib.fusedmm_spmm* with just the CSR arrays and
+    its cached CSC operands.  On a graph large enough for the slice rule, the operator library serves it from a
+    per-graph isplib_graph handle (forward on A, backward on the cached A^T operands), validated by tensor identity."""
+    import isplib_amd  # noqa: F401
+    ops = torch.ops.isplib
+    ops.graph_cache_clear()
+    n, k = 4000, 64
+    rowptr, col = cases.random_csr(n, n, 300.0, seed=31, empty_rows=(5,))
+    assert col.size >= (1 << 20)
+    val = cases.weights(col.size, 4)
+    x, g = cases.dense(n, k, 3), cases.dense(n, k, 5)
+    d_rowptr, d_col, d_val = _t(rowptr, gpu), _t(col, gpu), _t(val, gpu)
+    from isplib_amd import cabi
+    colptr, perm, row_t, val_t = cabi.csr2csc(d_rowptr, d_col, d_val, n)      # what isplib/__init__.py:76-80 caches
+    row = cabi.csr_row_ids(d_rowptr, col.size)
+    tol = cases.sum_tolerance(oracle_mod, rowptr, col, val, x)
+    ref, _ = oracle_mod.spmm_fw(rowptr, col, val, x, "sum")
+    dref = oracle_mod.spmm_sum_bw(rowptr, col, val, n, g)
+    dmag = oracle_mod.spmm_sum_bw(rowptr, col, np.abs(val), n, np.abs(g))
+    for it in range(2):
+        xs = _t(x, gpu).requires_grad_(True)
+        out = ops.fusedmm_spmm(row, d_rowptr, d_col, d_val, colptr, perm, xs, val_t, row_t)
+        out.backward(_t(g, gpu))
+        assert np.all(np.abs(out.detach().cpu().numpy() - ref) <= tol)
+        assert np.all(np.abs(xs.grad.cpu().numpy() - dref) <= 1e-5 * dmag + 1e-30)
+        assert ops.graph_cache_size() == 2, "one handle for A, one for the cached A^T operands; reused on the second pass"
+    mx, arg = ops.fusedmm_spmm_max(d_rowptr, d_col, d_val, _t(x, gpu))
+    rmx, rarg = oracle_mod.spmm_fw(rowptr, col, val, x, "max")
+    assert np.array_equal(mx.cpu().numpy(), rmx) and np.array_equal(arg.cpu().numpy(), rarg)
+    assert ops.graph_cache_size() == 2                                   # same (rowptr, col, value) triple: same handle
+    # an in-place edit of the graph invalidates its handle (version counter), and the answer follows the edit
+    d_val.mul_(2.0)
+    out2 = ops.fusedmm_spmm_max(d_rowptr, d_col, d_val, _t(x, gpu))[0]
+    rmx2, _ = oracle_mod.spmm_fw(rowptr, col, (val * 2).astype(np.float32), x, "max")
+    assert np.array_equal(out2.cpu().numpy(), rmx2)
+    # graphs whose tensors are gone are dropped the next time a new graph arrives
+    del d_rowptr, d_col, d_val, colptr, perm, row_t, val_t, row, out, xs
+    r2, c2 = cases.random_csr(n, n, 300.0, seed=32)
+    out3 = ops.fusedmm_spmm_max(_t(r2, gpu), _t(c2, gpu), None, _t(x, gpu))[0]
+    rmx3, _ = oracle_mod.spmm_fw(r2, c2, np.ones(c2.size, np.float32), x, "max")
+    assert np.array_equal(out3.cpu().numpy(), rmx3)
+    assert ops.graph_cache_size() <= 1
+    ops.graph_cache_clear()
+    assert ops.graph_cache_size() == 0
