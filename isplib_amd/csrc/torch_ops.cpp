@@ -142,9 +142,10 @@ bool spmm_through_handle(int32_t msg, const Tensor &rowptr, const Tensor &col, c
                    "isplib_graph_create");
       it = g_graphs.emplace(key, std::move(e)).first;
    }
-   check_status(isplib_graph_spmm(it->second.handle, msg, K, mat.data_ptr<float>(), K, out.data_ptr<float>(), K,
-                                  arg.defined() ? arg.data_ptr<int64_t>() : nullptr, current_stream(mat)),
-                "isplib_graph_spmm");
+   const int st = isplib_graph_spmm(it->second.handle, msg, K, mat.data_ptr<float>(), K, out.data_ptr<float>(), K,
+                                    arg.defined() ? arg.data_ptr<int64_t>() : nullptr, current_stream(mat));
+   if (st == ISPLIB_NOT_ENOUGH_MEM) return false;      // no room for the plan beside torch's pool: the plain kernel needs none
+   check_status(st, "isplib_graph_spmm");
    return true;
 }
 
