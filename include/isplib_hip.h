@@ -328,7 +328,9 @@ int    isplib_csr2csc_hip(int64_t m, int64_t n, int64_t nnz,
  * ids, the CSC operands of the backward, one grow-only workspace), built lazily on the device.  It is what
  * the reference's C++ layer (csrc/fusedmm.cpp:113-203) would hold per graph in place of the pointer-keyed
  * dicts of isplib/__init__.py:35-40.
- *   isplib_graph_create   borrows rowptr[m+1] / col[nnz] / val[nnz]|NULL (device; must outlive the handle)
+ *   isplib_graph_create   borrows rowptr[m+1] / col[nnz] / val[nnz]|NULL (device; must outlive the handle and
+ *                         must not change: val is examined once, and a vector of exact 1.0f -- what
+ *                         isplib/__init__.py:51-57 materialises for an unweighted graph -- is treated as NULL)
  *   isplib_graph_spmm     z = A (x) y for one of the four SpMM words; schedule by isplib_suggest_slices
  *                         (or isplib_graph_set_slices: -1 rule, 0 plain kernel, 1..4096 task list)
  *   isplib_graph_spmm_backward   dx = A^T dy (mean != 0: with weights val/max(deg,1), the mean forward's
