@@ -24,6 +24,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# this pool's driver only supports dmabuf IPC: without it RCCL's peer mappings fail (hipIpcGetMemHandle)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 
