@@ -25,6 +25,10 @@
 #include <torch/csrc/autograd/custom_function.h>
 #include <torch/library.h>
 
+#include <hip/hip_runtime_api.h>
+
+#include <cstdio>
+#include <cstdlib>
 #include <initializer_list>
 #include <mutex>
 #include <tuple>
@@ -60,6 +64,30 @@ void check_float(const Tensor &t, const char *name) {
 }
 
 void *current_stream(const Tensor &t) { return (void *)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+
+// ISPLIB_DEBUG=1: per-operator device time on stderr under the reference's own labels (the commented-out timers
+// of csrc/fusedmm.cpp:52-53,252-253,288-289,...: FUSEDMM_SPMM_<RED>_{FW,BW}).  Synchronises per op: debugging only.
+struct OpTimer {
+   const char *name;
+   bool on;
+   hipStream_t st = nullptr;
+   hipEvent_t a = nullptr, b = nullptr;
+   OpTimer(const char *n, const Tensor &t) : name(n) {
+      static const bool enabled = [] { const char *e = std::getenv("ISPLIB_DEBUG"); return e && *e && *e != '0'; }();
+      on = enabled && t.defined() && t.is_cuda();
+      if (!on) return;
+      st = (hipStream_t)current_stream(t);
+      on = hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess && hipEventRecord(a, st) == hipSuccess;
+   }
+   ~OpTimer() {
+      if (on && hipEventRecord(b, st) == hipSuccess && hipEventSynchronize(b) == hipSuccess) {
+         float ms = 0.0f;
+         if (hipEventElapsedTime(&ms, a, b) == hipSuccess) std::fprintf(stderr, "%s: %.3f ms\n", name, ms);
+      }
+      if (a) (void)hipEventDestroy(a);
+      if (b) (void)hipEventDestroy(b);
+   }
+};
 
 // fusedmm_spmm_fw, csrc/fusedmm.cpp:113-203
 // `plan`: per-graph schedule operands (isplib_amd/plan.py, include/isplib_hip.h):
@@ -330,6 +358,7 @@ class SpmmSum : public torch::autograd::Function<SpmmSum> {
                                 optional<Variable> opt_csr2csc, Variable mat, optional<Variable> value_index_select,
                                 optional<Variable> row_index_select, Plan plan, Plan plan_t) {
       const bool has_value = opt_value.has_value() && opt_value->defined();
+      OpTimer timer("FUSEDMM_SPMM_SUM_FW", mat);
       auto out = std::get<0>(spmm_fw(rowptr, col, opt_value, mat, R_SUM, plan));   // :244
       ctx->saved_data["plan_t"] = plan_t;
       ctx->saved_data["plan"] = plan;
@@ -343,6 +372,7 @@ class SpmmSum : public torch::autograd::Function<SpmmSum> {
    }
 
    static variable_list backward(AutogradContext *ctx, variable_list grad_outs) {
+      OpTimer timer("FUSEDMM_SPMM_SUM_BW", grad_outs[0]);
       const bool has_value = ctx->saved_data["has_value"].toBool();
       auto grad_out = grad_outs[0];
       auto saved = ctx->get_saved_variables();
@@ -378,6 +408,7 @@ class SpmmMean : public torch::autograd::Function<SpmmMean> {
                                 optional<Variable> opt_colptr, optional<Variable> opt_csr2csc, Variable mat,
                                 optional<Variable> new_row, optional<Variable> new_rowcount, Plan plan, Plan plan_t) {
       const bool has_value = opt_value.has_value() && opt_value->defined();
+      OpTimer timer("FUSEDMM_SPMM_MEAN_FW", mat);
       auto out = std::get<0>(spmm_fw(rowptr, col, opt_value, mat, R_MEAN, plan));   // :331
       ctx->saved_data["plan_t"] = plan_t;
       ctx->saved_data["plan"] = plan;
@@ -392,6 +423,7 @@ class SpmmMean : public torch::autograd::Function<SpmmMean> {
    }
 
    static variable_list backward(AutogradContext *ctx, variable_list grad_outs) {
+      OpTimer timer("FUSEDMM_SPMM_MEAN_BW", grad_outs[0]);
       const bool has_value = ctx->saved_data["has_value"].toBool();
       auto grad_out = grad_outs[0];
       auto saved = ctx->get_saved_variables();
@@ -428,6 +460,7 @@ class SpmmMinMax : public torch::autograd::Function<SpmmMinMax<RED>> {
    static variable_list forward(AutogradContext *ctx, Variable rowptr, Variable col, optional<Variable> opt_value,
                                 Variable mat, Plan plan) {
       const bool has_value = opt_value.has_value() && opt_value->defined();
+      OpTimer timer(RED == R_MAX ? "FUSEDMM_SPMM_MAX_FW" : "FUSEDMM_SPMM_MIN_FW", mat);
       auto result = spmm_fw(rowptr, col, opt_value, mat, RED, plan);   // :397 / :465
       auto out = std::get<0>(result);
       auto arg_out = std::get<1>(result);
@@ -438,6 +471,7 @@ class SpmmMinMax : public torch::autograd::Function<SpmmMinMax<RED>> {
    }
 
    static variable_list backward(AutogradContext *ctx, variable_list grad_outs) {
+      OpTimer timer(RED == R_MAX ? "FUSEDMM_SPMM_MAX_BW" : "FUSEDMM_SPMM_MIN_BW", grad_outs[0]);
       const bool has_value = ctx->saved_data["has_value"].toBool();
       auto saved = ctx->get_saved_variables();
       auto col = saved[0], value = saved[1], mat = saved[2], arg_out = saved[3];
