@@ -341,7 +341,7 @@ int    isplib_csr2csc_hip(int64_t m, int64_t n, int64_t nnz,
  * handle must be ordered on one stream at a time (they share the workspace).
  */
 typedef struct isplib_graph isplib_graph;
-int  isplib_suggest_slices(int64_t m, int64_t n, int64_t nnz, int64_t k);
+int  isplib_suggest_slices(int64_t m, int64_t n, int64_t nnz, int64_t k, int minmax /*nonzero for max / min*/);
 int  isplib_graph_create(int64_t m, int64_t n, int64_t nnz, const int64_t *rowptr, const int64_t *col,
                          const float *val, isplib_graph **out);
 int  isplib_graph_set_slices(isplib_graph *g, int slices);

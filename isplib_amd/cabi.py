@@ -127,7 +127,7 @@ def lib() -> ctypes.CDLL:
                                                      ctypes.c_int, _vp, _vp, _i64, _vp, _i64, _vp, ctypes.c_size_t,
                                                      ctypes.POINTER(Epilogue), _vp]
         L.isplib_suggest_slices.restype = ctypes.c_int
-        L.isplib_suggest_slices.argtypes = [_i64, _i64, _i64, _i64]
+        L.isplib_suggest_slices.argtypes = [_i64, _i64, _i64, _i64, ctypes.c_int]
         L.isplib_graph_create.restype = ctypes.c_int
         L.isplib_graph_create.argtypes = [_i64, _i64, _i64, _vp, _vp, _vp, ctypes.POINTER(_vp)]
         L.isplib_graph_set_slices.restype = ctypes.c_int

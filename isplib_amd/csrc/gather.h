@@ -290,6 +290,6 @@ template <int U, int LPR> __device__ __forceinline__ constexpr int transposed_ow
 }
 
 // tuning knobs (isplib_hip_tune), defined in spmm.hip
-extern int g_force_lpr, g_addr_mode, g_tasks_per_wave, g_panel_cols;
+extern int g_force_lpr, g_addr_mode, g_tasks_per_wave, g_panel_cols, g_panel_cols_minmax;
 
 }  // namespace isplib

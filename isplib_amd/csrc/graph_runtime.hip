@@ -78,12 +78,14 @@ struct isplib_graph {
       }                                                                                                    \
    } while (0)
 
-extern "C" int isplib_suggest_slices(int64_t m, int64_t n, int64_t nnz, int64_t k) {
+extern "C" int isplib_suggest_slices(int64_t m, int64_t n, int64_t nnz, int64_t k, int minmax) {
    // Measured on MI355X: about 7 MB of the dense operand per slice (2x an XCD's L2),
    // never fewer than k/20 slices on a graph with work for the whole chip, at least ~20 edges per row and
-   // slice; wide k is swept in 128-column panels, so it counts as 128.  0 = plain row-per-wave kernel.
+   // slice; wide k is swept in panels of 128 columns (sum / mean) or 64 (max / min), so it counts as the
+   // panel width.  0 = plain row-per-wave kernel.
    if (m <= 0 || n <= 0 || k <= 0) return 0;
-   if (k >= 192) k = 128;
+   if (minmax && k >= 96) k = 64;
+   else if (k >= 192) k = 128;
    const double avg_deg = (double)nnz / (double)m;
    if (nnz < (1 << 20) || avg_deg < 64.0) return 0;
    const double by_cache = (double)n * (double)k * 4.0 / (double)(7 << 20);
@@ -207,7 +209,8 @@ static int weights_are_unit(Side &s, hipStream_t st) {
 static int run_side(isplib_graph *g, Side &s, const float *val, int32_t imessage, int64_t k, const float *y, int64_t ldy,
                     float *z, int64_t ldz, int64_t *z_arg, hipStream_t st) {
    if (val && val == s.val && weights_are_unit(s, st) == 1) val = nullptr;
-   int slices = g->forced_slices >= 0 ? g->forced_slices : isplib_suggest_slices(s.m, s.n, s.nnz, k);
+   const int minmax = (imessage & 0xF0000) != ISPLIB_AOP_ADD;
+   int slices = g->forced_slices >= 0 ? g->forced_slices : isplib_suggest_slices(s.m, s.n, s.nnz, k, minmax);
    if (k < 4 || (double)s.n * (double)ldy * 4.0 > 3.5 * 1073741824.0) slices = 0;      // outside the task entry's domain
    if (slices > 0) {
       auto it = s.plans.find(slices);

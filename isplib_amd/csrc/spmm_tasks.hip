@@ -271,7 +271,9 @@ static int tasks_entry(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_
    // (task kernel + combine) per panel on the same stream: a panel of y is n*panel*4 bytes, which stays
    // inside the 256 MiB Infinity Cache when the whole y does not, and every pass runs at the efficiency of
    // the well-filled K = panel case.  Panels only change which columns a launch touches, never a result.
-   const int64_t pw = (g_panel_cols >= 4 && k >= g_panel_cols + g_panel_cols / 2) ? (int64_t)(g_panel_cols / 4 * 4) : k;
+   // max/min carry (value, id) pairs: their passes run best at 64 columns (two K=64 passes 4.17 ms, one K=128 pass 4.75 ms).
+   const int panel = aop == ISPLIB_AOP_ADD ? g_panel_cols : g_panel_cols_minmax;
+   const int64_t pw = (panel >= 4 && k >= panel + panel / 2) ? (int64_t)(panel / 4 * 4) : k;
    for (int64_t c0 = 0; c0 < k; c0 += pw) {
       TaskArgs p = a;
       p.k = (k - c0) < pw ? (k - c0) : pw;

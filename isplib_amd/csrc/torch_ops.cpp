@@ -146,7 +146,7 @@ std::unordered_map<GraphKey, GraphCacheEntry, GraphKeyHash> g_graphs;
 bool spmm_through_handle(int32_t msg, const Tensor &rowptr, const Tensor &col, const Tensor &value, const Tensor &mat,
                          Tensor &out, Tensor &arg) {
    const int64_t M = rowptr.numel() - 1, N = mat.size(0), K = mat.size(1), nnz = col.numel();
-   if (isplib_suggest_slices(M, N, nnz, K) <= 0) return false;
+   if (isplib_suggest_slices(M, N, nnz, K, (msg & 0xF0000) != ISPLIB_AOP_ADD) <= 0) return false;
    std::lock_guard<std::mutex> lock(g_graph_mutex);        // also serialises the handle's shared workspace
    const GraphKey key{rowptr.data_ptr(), col.data_ptr(), value.defined() ? value.data_ptr() : nullptr, N};
    auto it = g_graphs.find(key);

@@ -93,11 +93,11 @@ def suggest_slices(m: int, n: int, nnz: int, k: int, minmax: bool = False) -> in
     a few slices still pay because they cut rows into more, shorter tasks -- K/20 of them (6 at K=128, 2 at
     K=32) -- as long as the graph has work for the whole chip; (iii) a row must keep ~20 edges per slice or
     per-task overhead and the partial rows eat the gain.  Reddit-shaped graph (mean degree 492): K=32 -> 4,
-    K=64 -> 8, K=128 and wider (128-column panels) -> 16, same for max/min; a tenth of it at K=128 -> 6;
+    K=64 -> 8, K=128 and wider (128-column panels) -> 16; max/min run in 64-column panels, so K >= 96 -> 8;
+    a tenth of the graph at K=128 -> 6;
     ogbn-products-shaped (mean degree 50) or under a million edges -> 0 (plain kernel, no preparation)."""
-    del minmax
     from . import cabi
-    return int(cabi.lib().isplib_suggest_slices(int(m), int(n), int(nnz), int(k)))     # one rule, in the C ABI
+    return int(cabi.lib().isplib_suggest_slices(int(m), int(n), int(nnz), int(k), int(bool(minmax))))   # one rule, in the C ABI
 
 
 # Measured choices that outlive the process: {graph signature: {"rows:k:minmax": slice count}}.  Filled by
