@@ -81,11 +81,12 @@ struct isplib_graph {
 extern "C" int isplib_suggest_slices(int64_t m, int64_t n, int64_t nnz, int64_t k, int minmax) {
    // Measured on MI355X: about 7 MB of the dense operand per slice (2x an XCD's L2),
    // never fewer than k/20 slices on a graph with work for the whole chip, at least ~20 edges per row and
-   // slice; wide k is swept in panels of 128 columns (sum / mean) or 64 (max / min), so it counts as the
-   // panel width.  0 = plain row-per-wave kernel.
+   // slice; wide k is swept in column panels (64 wide when rows are whole cache lines, else 128) and counts
+   // as the panel width.  0 = plain row-per-wave kernel.
    if (m <= 0 || n <= 0 || k <= 0) return 0;
-   if (minmax && k >= 96) k = 64;
-   else if (k >= 192) k = 128;
+   (void)minmax;             // both families run in the same panels (isplib_hip_tune keys 4 / 5)
+   if (k % 32 == 0) { if (k >= 96) k = 64; }          // rows of whole cache lines: 64-column panels
+   else if (k >= 192) k = 128;                        // ragged rows: 128-column panels
    const double avg_deg = (double)nnz / (double)m;
    if (nnz < (1 << 20) || avg_deg < 64.0) return 0;
    const double by_cache = (double)n * (double)k * 4.0 / (double)(7 << 20);

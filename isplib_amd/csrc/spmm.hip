@@ -373,7 +373,7 @@ int g_force_lpr = 0;   // tuning knob (isplib_hip_tune): lanes per row slot, 0 =
 int g_addr_mode = 1;   // tuning knob: 0 = always 64-bit addressing, 1 = buffer descriptors when they fit
 int g_tasks_per_wave = 1;   // tuning knob: consecutive tasks handled by one wave of the task kernel
 int g_panel_cols_minmax = 64;   // the same for max / min (isplib_hip_tune(5, w))
-int g_panel_cols = 128;     // column-panel width of the task schedule for wide K (isplib_hip_tune(4, w); 0 = one pass)
+int g_panel_cols = 64;      // column-panel width of the task schedule for wide K (isplib_hip_tune(4, w); 0 = one pass)
 
 template <int OP, int VEC>
 static int launch_vec(const SpmmArgs &a, hipStream_t st) {

@@ -271,8 +271,12 @@ static int tasks_entry(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_
    // (task kernel + combine) per panel on the same stream: a panel of y is n*panel*4 bytes, which stays
    // inside the 256 MiB Infinity Cache when the whole y does not, and every pass runs at the efficiency of
    // the well-filled K = panel case.  Panels only change which columns a launch touches, never a result.
-   // max/min carry (value, id) pairs: their passes run best at 64 columns (two K=64 passes 4.17 ms, one K=128 pass 4.75 ms).
-   const int panel = aop == ISPLIB_AOP_ADD ? g_panel_cols : g_panel_cols_minmax;
+   // 64-column passes are the most efficient ones (sum K=128: two passes 3.45 ms, one pass 3.61 ms; max: 4.16 vs 4.75 ms)
+   // -- as long as panel boundaries fall on cache-line boundaries, i.e. rows are a multiple of 128 bytes.  Otherwise
+   // every panel would touch partial lines on both sides (K=100: 4.28 ms in 64 + 36 columns, 3.43 ms in one pass), so
+   // unaligned rows keep 128-column panels and only from K = 192.
+   int panel = aop == ISPLIB_AOP_ADD ? g_panel_cols : g_panel_cols_minmax;
+   if ((ldy % 32) != 0 && panel > 0 && panel < 128) panel = 128;
    const int64_t pw = (panel >= 4 && k >= panel + panel / 2) ? (int64_t)(panel / 4 * 4) : k;
    for (int64_t c0 = 0; c0 < k; c0 += pw) {
       TaskArgs p = a;

@@ -336,11 +336,12 @@ def test_slice_rule_lives_in_the_c_abi_and_handle_entries_validate():
     from isplib_amd import cabi, plugin
     L = cabi.lib()
     n, nnz = 232965, 114615892                                     # the Reddit shape: K=32 -> 4, 64 -> 8, >=128 -> 16
-    assert [L.isplib_suggest_slices(n, n, nnz, k, 0) for k in (32, 64, 128, 256, 608)] == [4, 8, 16, 16, 16]
-    assert [L.isplib_suggest_slices(n, n, nnz, k, 1) for k in (32, 64, 128, 256)] == [4, 8, 8, 8]      # max/min: 64-column panels
+    assert [L.isplib_suggest_slices(n, n, nnz, k, 0) for k in (32, 64, 128, 256, 608)] == [4, 8, 8, 8, 8]   # 64-column panels
+    assert [L.isplib_suggest_slices(n, n, nnz, k, 1) for k in (32, 64, 128, 256)] == [4, 8, 8, 8]
+    assert [L.isplib_suggest_slices(n, n, nnz, k, 0) for k in (41, 100, 602)] == [5, 13, 16]               # ragged rows: one pass / 128-column panels
     assert L.isplib_suggest_slices(2449029, 2449029, 123718280, 256, 0) == 0      # products: mean degree 50 -> plain
     assert L.isplib_suggest_slices(2708, 2708, 10556, 16, 0) == 0                  # Cora: launch-bound, no preparation
-    assert plugin.suggest_slices(n, n, nnz, 128, True) == 8 and plugin.suggest_slices(n, n, nnz, 128) == 16                    # the Python name is the same rule
+    assert plugin.suggest_slices(n, n, nnz, 128, True) == 8 and plugin.suggest_slices(n, n, nnz, 100) == 13                    # the Python name is the same rule
     assert L.isplib_graph_spmm(None, cabi.MSG_SPMM_SUM, 8, None, 8, None, 8, None, None) == cabi.FAIL
     assert "null handle" in cabi.last_error()
     assert L.isplib_graph_set_slices(None, 4) == cabi.FAIL
