@@ -226,7 +226,7 @@ static int run_side(isplib_graph *g, Side &s, const float *val, int32_t imessage
       }
       const Plan &p = it->second;
       if (p.usable) {
-         const size_t need = isplib_spmm_tasks_workspace_bytes(imessage, p.n_tasks, k < 192 ? k : 128);
+         const size_t need = isplib_spmm_tasks_workspace_bytes(imessage, p.n_tasks, k);
          const int rc = ensure_work(g, need, st);
          if (rc) return rc;
          return fusedMM_csr_tasks_hip(imessage, s.m, s.n, k, s.nnz, val, s.col, s.col32, s.rowptr, s.rowptr + 1, p.n_tasks,
