@@ -93,7 +93,7 @@ def suggest_slices(m: int, n: int, nnz: int, k: int, minmax: bool = False) -> in
     a few slices still pay because they cut rows into more, shorter tasks -- K/20 of them (6 at K=128, 2 at
     K=32) -- as long as the graph has work for the whole chip; (iii) a row must keep ~20 edges per slice or
     per-task overhead and the partial rows eat the gain.  Reddit-shaped graph (mean degree 492): K=32 -> 4,
-    K=64 -> 8, K=128 and wider (128-column panels) -> 16; max/min run in 64-column panels, so K >= 96 -> 8;
+    K=64 -> 8, K >= 96 with rows of whole cache lines (64-column panels) -> 8, ragged K=100 -> 13, K=602 -> 16;
     a tenth of the graph at K=128 -> 6;
     ogbn-products-shaped (mean degree 50) or under a million edges -> 0 (plain kernel, no preparation)."""
     from . import cabi
