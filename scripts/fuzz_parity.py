@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Randomised differential check of every SpMM schedule against the oracle (a longer-running companion of
+tests/test_gpu_parity.py): random shapes, degree profiles, widths, slice counts, plan parameters, weights,
+leading dimensions.  max/min: values and arg bit for bit; sum/mean: 1e-5 * sum|a||x| per element.
+
+    python scripts/fuzz_parity.py [--cases 300] [--seed 0]
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import oracle  # noqa: E402
+from isplib_amd import cabi  # noqa: E402
+from isplib_amd.plan import build_task_plan  # noqa: E402
+from tests import cases  # noqa: E402
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument("--cases", type=int, default=300)
+    p.add_argument("--seed", type=int, default=0)
+    a = p.parse_args()
+    rng = np.random.default_rng(a.seed)
+    dev = torch.device("cuda:0")
+    t = lambda x: None if x is None else torch.from_numpy(x).to(dev)  # noqa: E731
+    bad = 0
+    for case in range(a.cases):
+        m = int(rng.integers(1, 700))
+        n = int(rng.integers(1, 700))
+        deg = float(rng.choice([0.5, 3, 20, 90, 300]))
+        k = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 16, 31, 32, 33, 41, 64, 65, 96, 100, 128, 160, 192, 200, 256, 300, 602]))
+        hub = (int(rng.integers(0, m)), int(rng.integers(1, 4000))) if rng.random() < 0.4 else None
+        empties = tuple(int(v) for v in rng.integers(0, m, size=int(rng.integers(0, 4))))
+        rowptr, col = cases.random_csr(m, n, min(deg, n), seed=int(rng.integers(1 << 30)), empty_rows=empties, hub=hub,
+                                       duplicates=bool(rng.random() < 0.5))
+        integer = rng.random() < 0.5
+        val = cases.weights(col.size, int(rng.integers(1 << 30)), "signed_int" if integer else "uniform")
+        x = cases.dense(n, k, int(rng.integers(1 << 30)), "integer" if integer else "uniform")
+        unit = rng.random() < 0.3
+        hv = np.ones_like(val) if unit else val
+        ld = k + int(rng.choice([0, 0, 1, 3, 8]))
+        xp = np.zeros((n, ld), np.float32)
+        xp[:, :k] = x
+        d_rowptr, d_col, d_val = t(rowptr), t(col), None if unit else t(val)
+        d_x = t(xp)[:, :k]
+        tol = cases.sum_tolerance(oracle, rowptr, col, hv, x)
+        slices = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 24]))
+        chunk = int(rng.choice([64, 100, 512, 1024]))
+        short = int(rng.choice([0, 8, 128, 10 ** 6]))
+        plan = build_task_plan(d_rowptr, d_col, n, slices, chunk, short) if k >= 4 else None
+        table = cabi.spmm_slices(d_rowptr, d_col, n, slices)[0]
+        for red in cases.REDUCES:
+            ref, ref_arg = oracle.spmm_fw(rowptr, col, hv, x, red)
+            outs = {}
+            for name in ("plain", "sliced", "tasks"):
+                out = torch.full((m, ld), 7.0, device=dev)[:, :k]
+                arg = torch.full((m, ld), -5, dtype=torch.int64, device=dev)[:, :k] if red in ("max", "min") else None
+                if name == "plain":
+                    cabi.fusedMM_csr_hip(cabi.MESSAGE[red], d_rowptr, d_col, d_val, d_x, out, arg)
+                elif name == "sliced":
+                    cabi.fusedMM_csr_sliced_hip(cabi.MESSAGE[red], d_rowptr, d_col, d_val, table, slices, d_x, out, arg,
+                                                cabi.sliced_workspace(red, m, k, slices, dev))
+                elif plan is not None:
+                    cabi.fusedMM_csr_tasks_hip(cabi.MESSAGE[red], d_rowptr, d_col, d_val, plan, d_x, out, arg, plan.workspace(red, k))
+                else:
+                    continue
+                outs[name] = (out.cpu().numpy(), None if arg is None else arg.cpu().numpy())
+            for name, (o, ar) in outs.items():
+                if red in ("max", "min"):
+                    ok = np.array_equal(o.view(np.uint32), ref.view(np.uint32)) and np.array_equal(ar, ref_arg)
+                else:
+                    scale = np.maximum(np.diff(rowptr), 1)[:, None] if red == "mean" else 1
+                    ok = bool(np.all(np.abs(o - ref) <= tol / scale + 1e-12))
+                if not ok:
+                    bad += 1
+                    print(f"MISMATCH case {case}: {name}/{red} m={m} n={n} k={k} ld={ld} deg={deg} hub={hub} slices={slices} "
+                          f"chunk={chunk} short={short} unit={unit} integer={integer}", flush=True)
+        if case % 50 == 49:
+            print(f"{case + 1} cases, {bad} mismatches", flush=True)
+    print(f"done: {a.cases} cases, {bad} mismatches")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
