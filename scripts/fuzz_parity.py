@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised differential check of every SpMM schedule against the oracle (a longer-running companion of
 tests/test_gpu_parity.py): random shapes, degree profiles, widths, slice counts, plan parameters, weights,
-leading dimensions.  max/min: values and arg bit for bit; sum/mean: 1e-5 * sum|a||x| per element.
+leading dimensions.  max/min: values and arg bit for bit against the oracle; sum/mean: 1e-5 * sum|a||x| per
+element against the exact (fp64) sum, with a note whenever the fp32 oracle itself is further off than that.
 
     python scripts/fuzz_parity.py [--cases 300] [--seed 0]
 """
@@ -54,6 +55,9 @@ def main():
         short = int(rng.choice([0, 8, 128, 10 ** 6]))
         plan = build_task_plan(d_rowptr, d_col, n, slices, chunk, short) if k >= 4 else None
         table = cabi.spmm_slices(d_rowptr, d_col, n, slices)[0]
+        row_ids = np.repeat(np.arange(m), np.diff(rowptr))
+        ref64 = np.zeros((m, k))
+        np.add.at(ref64, row_ids, hv.astype(np.float64)[:, None] * x.astype(np.float64)[col])
         for red in cases.REDUCES:
             ref, ref_arg = oracle.spmm_fw(rowptr, col, hv, x, red)
             outs = {}
@@ -74,8 +78,13 @@ def main():
                 if red in ("max", "min"):
                     ok = np.array_equal(o.view(np.uint32), ref.view(np.uint32)) and np.array_equal(ar, ref_arg)
                 else:
+                    # the bar is the exact (fp64) sum: the fp32 oracle itself drifts on long rows of repeated terms
                     scale = np.maximum(np.diff(rowptr), 1)[:, None] if red == "mean" else 1
-                    ok = bool(np.all(np.abs(o - ref) <= tol / scale + 1e-12))
+                    ok = bool(np.all(np.abs(o - ref64 / scale) <= tol / scale + 1e-12))
+                    if not np.all(np.abs(o - ref) <= tol / scale + 1e-12) and ok:
+                        drift = float(np.max(np.abs(ref - ref64 / scale) / (tol / scale + 1e-30)))
+                        print(f"note case {case}: {name}/{red} differs from the fp32 oracle but matches fp64; oracle's own error is "
+                              f"{drift:.2f} x the tolerance", flush=True)
                 if not ok:
                     bad += 1
                     print(f"MISMATCH case {case}: {name}/{red} m={m} n={n} k={k} ld={ld} deg={deg} hub={hub} slices={slices} "
