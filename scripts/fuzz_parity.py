@@ -25,6 +25,7 @@ def main():
     p = argparse.ArgumentParser()
     p.add_argument("--cases", type=int, default=300)
     p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--backward", action="store_true", help="also check csr2csc, the handle's dX, SDDMM and the max/min scatter")
     a = p.parse_args()
     rng = np.random.default_rng(a.seed)
     dev = torch.device("cuda:0")
@@ -89,6 +90,45 @@ def main():
                     bad += 1
                     print(f"MISMATCH case {case}: {name}/{red} m={m} n={n} k={k} ld={ld} deg={deg} hub={hub} slices={slices} "
                           f"chunk={chunk} short={short} unit={unit} integer={integer}", flush=True)
+        # ---- the backward side on the same graph: transpose operands, dX of sum / mean, SDDMM dA, max/min scatter ----
+        if a.backward and col.size:
+            g = cases.dense(m, k, int(rng.integers(1 << 30)), "integer" if integer else "uniform")
+            d_g = t(g)
+            row_h, _, colptr_h, perm_h = oracle.csr_transpose(rowptr, col, n)
+            colptr, perm, row_t, val_t = cabi.csr2csc(d_rowptr, d_col, None if unit else t(val), n)
+            checks = [("csr2csc/colptr", np.array_equal(colptr.cpu().numpy(), colptr_h)),
+                      ("csr2csc/perm", np.array_equal(perm.cpu().numpy(), perm_h)),
+                      ("csr2csc/row_t", np.array_equal(row_t.cpu().numpy(), row_h[perm_h])),
+                      ("csr2csc/val_t", np.array_equal(val_t.cpu().numpy(), hv[perm_h]))]
+            h = cabi.GraphHandle(d_rowptr, d_col, None if unit else t(val), n)
+            h.set_slices(int(rng.choice([-1, 0, slices])))
+            dmag = oracle.spmm_sum_bw(rowptr, col, np.abs(hv), n, np.abs(g))
+            dx64 = np.zeros((n, k))
+            np.add.at(dx64, col, hv.astype(np.float64)[:, None] * g.astype(np.float64)[row_ids])
+            checks.append(("handle/dX sum", bool(np.all(np.abs(h.spmm_backward(d_g).cpu().numpy() - dx64) <= 1e-5 * dmag + 1e-30))))
+            w_mean = hv.astype(np.float64) / np.maximum(np.diff(rowptr), 1)[row_ids]
+            dxm64 = np.zeros((n, k))
+            np.add.at(dxm64, col, w_mean[:, None] * g.astype(np.float64)[row_ids])
+            checks.append(("handle/dX mean", bool(np.all(np.abs(h.spmm_backward(d_g, mean=True).cpu().numpy() - dxm64) <= 1e-5 * dmag + 1e-30))))
+            h.close()
+            xg = np.einsum("ek,ek->e", np.abs(x)[col].astype(np.float64), np.abs(g)[row_ids].astype(np.float64))
+            da64 = np.einsum("ek,ek->e", x[col].astype(np.float64), g[row_ids].astype(np.float64))
+            d_xc = t(np.ascontiguousarray(x))
+            checks.append(("sddmm", bool(np.all(np.abs(cabi.sddmm(d_rowptr, d_col, d_xc, d_g).cpu().numpy() - da64) <= 1e-5 * xg + 1e-30))))
+            if plan is not None:
+                checks.append(("sddmm_tasks", bool(np.all(np.abs(cabi.sddmm_tasks(d_rowptr, d_col, plan, d_xc, d_g).cpu().numpy() - da64)
+                                                          <= 1e-5 * xg + 1e-30))))
+            _, arg_h = oracle.spmm_fw(rowptr, col, hv, x, "max")
+            gv_h, gm_h = oracle.spmm_minmax_bw(col, hv, x, arg_h, g)
+            gv, gm = cabi.spmm_minmax_bw(d_col, None if unit else t(val), d_xc, t(arg_h), d_g)
+            lim_v = 1e-5 * np.abs(gv_h).max() + 1e-6 if gv_h.size else 0
+            checks.append(("minmax_bw/dval", bool(np.all(np.abs(gv.cpu().numpy() - gv_h) <= lim_v))))
+            checks.append(("minmax_bw/dmat", bool(np.all(np.abs(gm.cpu().numpy() - gm_h) <= 1e-5 * np.abs(gm_h).max() + 1e-6))))
+            for name, ok in checks:
+                if not ok:
+                    bad += 1
+                    print(f"MISMATCH case {case}: {name} m={m} n={n} k={k} deg={deg} hub={hub} slices={slices} unit={unit} "
+                          f"integer={integer}", flush=True)
         if case % 50 == 49:
             print(f"{case + 1} cases, {bad} mismatches", flush=True)
     print(f"done: {a.cases} cases, {bad} mismatches")
