@@ -131,6 +131,20 @@ int fusedMM_csr_udef_hip(int32_t imessage, int64_t m, int64_t n, int64_t k, floa
                          float *z /*[dev] m x ldz*/, int64_t ldz, int64_t *z_arg /*[dev] | NULL*/,
                          int sop_udef /*enum isplib_sop_udef*/, float sop_param, void *stream);
 
+/* The same pipeline over the task plan of the SpMM (isplib_spmm_tasks_*; one wave per task, partial rows in
+ * `workspace` = isplib_spmm_tasks_workspace_bytes(AOP word, n_tasks, k), folded like the SpMM's): the gathers of y
+ * get the L2 affinity of the column slices.  ROP needs whole rows, so there are no column panels: choose the
+ * slice count for the full width (about n*k*4 / 7 MB).  4 <= k <= 1024. */
+int fusedMM_csr_udef_tasks_hip(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t nnz,
+                               const float *val, const int64_t *indx, const int32_t *indx32 /*optional*/,
+                               const int64_t *pntrb, const int64_t *pntre,
+                               const float *x, int64_t ldx, int64_t n_tasks, const int32_t *task_row,
+                               const int64_t *task_b, const int32_t *task_len, const int32_t *seg_off,
+                               int slices, const int64_t *lane_off_host /*9, host*/,
+                               const float *y, int64_t ldy, float *z, int64_t ldz, int64_t *z_arg,
+                               int sop_udef, float sop_param, void *workspace, size_t workspace_bytes,
+                               void *stream);
+
 /*
  * Column-sliced SpMM: same result as fusedMM_csr_hip, faster when y does not fit an
  * XCD's 4 MiB L2 and rows are long (Reddit-like graphs).  The columns of A (= rows of

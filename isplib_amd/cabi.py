@@ -48,7 +48,7 @@ EXPORTS = (
     "fusedMM_csr_sliced_hip", "fusedMM_csr_sliced_phase_hip", "isplib_hip_tune",
     "isplib_spmm_tasks_workspace_bytes", "fusedMM_csr_tasks_hip",
     "isplib_spmm_tasks_plan_workspace_bytes", "isplib_spmm_tasks_count_hip", "isplib_spmm_tasks_fill_hip",
-    "isplib_sddmm_csr_tasks_hip", "fusedMM_csr_tasks_epilogue_hip", "fusedMM_csr_udef_hip", "isplib_pack_indices_hip",
+    "isplib_sddmm_csr_tasks_hip", "fusedMM_csr_tasks_epilogue_hip", "fusedMM_csr_udef_hip", "fusedMM_csr_udef_tasks_hip", "isplib_pack_indices_hip",
     "isplib_suggest_slices", "isplib_graph_create", "isplib_graph_set_slices", "isplib_graph_spmm", "isplib_graph_spmm_backward",
     "isplib_graph_destroy",
 )
@@ -79,6 +79,10 @@ def lib() -> ctypes.CDLL:
         L.fusedMM_csr_udef_hip.restype = ctypes.c_int
         L.fusedMM_csr_udef_hip.argtypes = [_i32, _i64, _i64, _i64, _f32, _i64, _i64, _i64, _vp, _vp, _vp, _vp,
                                            _vp, _i64, _vp, _i64, _f32, _vp, _i64, _vp, ctypes.c_int, _f32, _vp]
+        L.fusedMM_csr_udef_tasks_hip.restype = ctypes.c_int
+        L.fusedMM_csr_udef_tasks_hip.argtypes = [_i32, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp,
+                                                 _vp, _vp, ctypes.c_int, _vp, _vp, _i64, _vp, _i64, _vp, ctypes.c_int, _f32,
+                                                 _vp, ctypes.c_size_t, _vp]
         L.performDummySpMM_hip.restype = None
         L.performDummySpMM_hip.argtypes = [_i64, _vp]
         L.isplib_spmm_minmax_bw_hip.restype = ctypes.c_int
@@ -193,10 +197,11 @@ def fusedMM_csr_hip(imessage: int, rowptr: torch.Tensor, col: torch.Tensor, val:
     return st
 
 
-def fusedmm(imessage: int, rowptr, col, val, x, y, sop_udef="none", sop_param: float = 0.0, check: bool = True):
+def fusedmm(imessage: int, rowptr, col, val, x, y, sop_udef="none", sop_param: float = 0.0, check: bool = True, plan=None):
     """The generic FusedMM pipeline (fusedMM_csr_udef_hip): z[i,:] = AOP_j VSC(SOP(ROP(VOP(x_i, y_j))), .) over the
     stored entries of row i.  `imessage` is a word built from VOP/ROP/SOP/VSC/AOP (or PATTERNS[name][0]);
-    `sop_udef` names the built-in function a SOP_UDEF stage stands for.  Returns (status, z, z_arg | None)."""
+    `sop_udef` names the built-in function a SOP_UDEF stage stands for.  With `plan` (isplib_amd.plan.TaskPlan) the
+    task form runs (fusedMM_csr_udef_tasks_hip).  Returns (status, z, z_arg | None)."""
     rowptr = _dev(rowptr, "rowptr", torch.int64)
     col = _dev(col, "col", torch.int64)
     if val is not None:
@@ -210,11 +215,21 @@ def fusedmm(imessage: int, rowptr, col, val, x, y, sop_udef="none", sop_param: f
     rp = rowptr.data_ptr()
     kind = SOP_UDEF[sop_udef] if isinstance(sop_udef, str) else int(sop_udef)
     with torch.cuda.device(y.device):
-        st = lib().fusedMM_csr_udef_hip(int(imessage), m, n, k, 1.0, col.numel(), m, n, _ptr(val), _ptr(col),
-                                        ctypes.c_void_p(rp), ctypes.c_void_p(rp + 8), _ptr(x), k, _ptr(y), k, 0.0,
-                                        _ptr(z), k, _ptr(arg), kind, float(sop_param), _stream(y.device))
+        if plan is not None:
+            reduce = {1: "sum", 2: "max", 3: "min"}.get((imessage >> 16) & 0xF, "sum")
+            work = plan.workspace(reduce, k)
+            lane = (ctypes.c_int64 * 9)(*plan.lane_off)
+            st = lib().fusedMM_csr_udef_tasks_hip(int(imessage), m, n, k, col.numel(), _ptr(val), _ptr(col), _plan_col32(plan, col),
+                                                  ctypes.c_void_p(rp), ctypes.c_void_p(rp + 8), _ptr(x), k, plan.n_tasks,
+                                                  _ptr(plan.task_row), _ptr(plan.task_b), _ptr(plan.task_len), _ptr(plan.seg_off),
+                                                  plan.slices, lane, _ptr(y), k, _ptr(z), k, _ptr(arg), kind, float(sop_param),
+                                                  _ptr(work), work.numel(), _stream(y.device))
+        else:
+            st = lib().fusedMM_csr_udef_hip(int(imessage), m, n, k, 1.0, col.numel(), m, n, _ptr(val), _ptr(col),
+                                            ctypes.c_void_p(rp), ctypes.c_void_p(rp + 8), _ptr(x), k, _ptr(y), k, 0.0,
+                                            _ptr(z), k, _ptr(arg), kind, float(sop_param), _stream(y.device))
     if check:
-        _check(st, "fusedMM_csr_udef_hip")
+        _check(st, "fusedMM_csr_udef_tasks_hip" if plan is not None else "fusedMM_csr_udef_hip")
     return st, z, arg
 
 

@@ -36,6 +36,14 @@ struct GenArgs {
    int sop_udef;
    float sop_param;
    unsigned ybytes;
+   // task form (fusedMM_csr_udef_tasks_hip): the plan of the SpMM task list; partial rows instead of z
+   const int32_t *indx32;
+   const int *task_row;
+   const int64_t *task_b;
+   const int *task_len;
+   int64_t lane_off[9];
+   float *part_val;
+   int *part_idx;
 };
 
 enum { G_VOP_COPY_LHS = 1, G_VOP_COPY_RHS = 2, G_VOP_ADD = 3, G_VOP_SUBL = 4, G_VOP_SUBR = 5, G_VOP_MAX = 6, G_VOP_MIN = 7 };
@@ -78,16 +86,30 @@ __device__ __forceinline__ float vop_apply(int vop, float xx, float yv) {
    }
 }
 
-template <int LPR, int NCH, int WAVES, int PAT>
+// TASK = false: one wave per row, writes z.  TASK = true: one wave per task of the SpMM plan (a run of one row's
+// edges inside one column slice, tasks grouped by XCD lane), writes one partial row per task for the fold.
+template <int LPR, int NCH, int WAVES, int PAT, bool TASK>
 __global__ __launch_bounds__(WAVES * 64) void fusedmm_general_kernel(const GenArgs a) {
    constexpr int G = 64 / LPR, U = NCH >= 4 ? 2 : 4;
    const StageCodes<PAT> op(a);
    const int lane = threadIdx.x & 63;
    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
    const int g = lane / LPR, lc = lane % LPR;
-   const int64_t row = (int64_t)blockIdx.x * WAVES + wave;
-   if (row >= a.m) return;
-   const int64_t rb = a.pntrb[row], re = a.pntre[row];
+   int64_t row, task = 0, eb, ee;
+   if (TASK) {
+      const unsigned xcd = blockIdx.x & 7u, within = blockIdx.x >> 3;
+      task = a.lane_off[xcd] + (int64_t)within * WAVES + wave;
+      if (task >= a.lane_off[xcd + 1]) return;
+      row = a.task_row[task];
+      eb = a.task_b[task];
+      ee = eb + a.task_len[task];
+   } else {
+      row = (int64_t)blockIdx.x * WAVES + wave;
+      if (row >= a.m) return;
+      eb = a.pntrb[row];
+      ee = a.pntre[row];
+   }
+   const int64_t rb = a.pntrb[row], re = TASK ? ee : a.pntre[row];   // rb: origin of the row-relative edge ids
    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.y), 0, (int)a.ybytes, 0x00020000);
 
    // this lane's columns: 4 consecutive ones per chunk, masked past k (a 16-byte load may run into the next row
@@ -125,11 +147,11 @@ __global__ __launch_bounds__(WAVES * 64) void fusedmm_general_kernel(const GenAr
       for (int v = 0; v < 4; v++) { acc[j][v] = init; bi[j][v] = INT_MAX; }
 
    const unsigned ldyb = (unsigned)a.ldy * 4u;
-   for (int64_t base = rb; base < re; base += 64) {
+   for (int64_t base = eb; base < ee; base += 64) {
       const int64_t p = base + lane;
-      const unsigned off_l = p < re ? (unsigned)a.indx[p] * ldyb : GEN_BUF_OOB;
-      const float a_l = (p < re && a.val) ? a.val[p] : 1.0f;
-      const int64_t left = re - base;
+      const unsigned off_l = p < ee ? (a.indx32 ? (unsigned)a.indx32[p] : (unsigned)a.indx[p]) * ldyb : GEN_BUF_OOB;
+      const float a_l = (p < ee && a.val) ? a.val[p] : 1.0f;
+      const int64_t left = ee - base;
       const int cnt = left < 64 ? (int)left : 64;
 #pragma unroll 1
       for (int s0 = 0; s0 < cnt; s0 += G * U) {
@@ -217,6 +239,18 @@ __global__ __launch_bounds__(WAVES * 64) void fusedmm_general_kernel(const GenAr
       }
    }
    if (g != 0) return;
+   if (TASK) {                                   // partial row of this task; the fold applies mean / empty-row / arg rules
+#pragma unroll
+      for (int j = 0; j < NCH; j++)
+#pragma unroll
+         for (int v = 0; v < 4; v++) {
+            if (!ok[j][v]) continue;
+            const size_t off = (size_t)task * (size_t)a.k + (size_t)(j * LPR + lc) * 4 + v;
+            a.part_val[off] = acc[j][v];
+            if (op.aop != G_AOP_ADD) a.part_idx[off] = bi[j][v];
+         }
+      return;
+   }
    const float scale = op.vsc == G_VSC_MEAN ? (float)((re - rb) > 1 ? (re - rb) : 1) : 1.0f;
 #pragma unroll
    for (int j = 0; j < NCH; j++) {
@@ -238,12 +272,25 @@ __global__ __launch_bounds__(WAVES * 64) void fusedmm_general_kernel(const GenAr
 template <int LPR, int NCH>
 static int launch_general(const GenArgs &a, int pat, hipStream_t st) {
    constexpr int WAVES = 4;
+   const dim3 block(WAVES * 64);
+   if (a.task_row) {
+      int64_t most = 0;
+      for (int x = 0; x < 8; x++) most = (a.lane_off[x + 1] - a.lane_off[x]) > most ? (a.lane_off[x + 1] - a.lane_off[x]) : most;
+      const int64_t gx = 8 * ((most + WAVES - 1) / WAVES);
+      if (gx > 0x7fffffffLL) return fail(ISPLIB_FAIL, "fusedMM_csr_udef_tasks_hip: too many tasks for one launch");
+      if (gx == 0) return ISPLIB_SUCCESS;
+      const dim3 grid((unsigned)gx);
+      if (pat == 1) hipLaunchKernelGGL((fusedmm_general_kernel<LPR, NCH, WAVES, 1, true>), grid, block, 0, st, a);
+      else if (pat == 2) hipLaunchKernelGGL((fusedmm_general_kernel<LPR, NCH, WAVES, 2, true>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((fusedmm_general_kernel<LPR, NCH, WAVES, 0, true>), grid, block, 0, st, a);
+      return check_launch("fusedmm_general_kernel<tasks>");
+   }
    const int64_t nb = (a.m + WAVES - 1) / WAVES;
    if (nb > 0x7fffffffLL) return fail(ISPLIB_FAIL, "fusedMM_csr_udef_hip: too many rows for one launch");
-   const dim3 grid((unsigned)nb), block(WAVES * 64);
-   if (pat == 1) hipLaunchKernelGGL((fusedmm_general_kernel<LPR, NCH, WAVES, 1>), grid, block, 0, st, a);
-   else if (pat == 2) hipLaunchKernelGGL((fusedmm_general_kernel<LPR, NCH, WAVES, 2>), grid, block, 0, st, a);
-   else hipLaunchKernelGGL((fusedmm_general_kernel<LPR, NCH, WAVES, 0>), grid, block, 0, st, a);
+   const dim3 grid((unsigned)nb);
+   if (pat == 1) hipLaunchKernelGGL((fusedmm_general_kernel<LPR, NCH, WAVES, 1, false>), grid, block, 0, st, a);
+   else if (pat == 2) hipLaunchKernelGGL((fusedmm_general_kernel<LPR, NCH, WAVES, 2, false>), grid, block, 0, st, a);
+   else hipLaunchKernelGGL((fusedmm_general_kernel<LPR, NCH, WAVES, 0, false>), grid, block, 0, st, a);
    return check_launch("fusedmm_general_kernel");
 }
 
@@ -251,14 +298,23 @@ static int launch_general(const GenArgs &a, int pat, hipStream_t st) {
 
 using namespace isplib;
 
-extern "C" int fusedMM_csr_udef_hip(int32_t imessage, int64_t m, int64_t n, int64_t k, float alpha, int64_t nnz,
-                                    int64_t rows, int64_t cols, const float *val, const int64_t *indx,
-                                    const int64_t *pntrb, const int64_t *pntre, const float *x, int64_t ldx,
-                                    const float *y, int64_t ldy, float beta, float *z, int64_t ldz, int64_t *z_arg,
-                                    int sop_udef, float sop_param, void *stream) {
-   (void)alpha; (void)rows; (void)cols;
+struct GenPlan {            // task plan of the SpMM (isplib_spmm_tasks_*), or all null for the row-per-wave form
+   const int32_t *indx32 = nullptr;
+   int64_t n_tasks = 0;
+   const int32_t *task_row = nullptr, *task_len = nullptr, *seg_off = nullptr;
+   const int64_t *task_b = nullptr;
+   int slices = 0;
+   const int64_t *lane_off_host = nullptr;
+   void *workspace = nullptr;
+   size_t workspace_bytes = 0;
+};
+
+static int general_entry(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t nnz, const float *val,
+                         const int64_t *indx, const int64_t *pntrb, const int64_t *pntre, const float *x, int64_t ldx,
+                         const float *y, int64_t ldy, float beta, float *z, int64_t ldz, int64_t *z_arg, int sop_udef,
+                         float sop_param, const GenPlan &plan, void *stream) {
    clear_error();
-   GenArgs a;
+   GenArgs a = {};
    a.vop = imessage & 0xF; a.rop = (imessage >> 4) & 0xF; a.sop = (imessage >> 8) & 0xF;
    a.vsc = (imessage >> 12) & 0xF; a.aop = (imessage >> 16) & 0xF;
    if ((imessage >> 20) != 0) return fail(ISPLIB_NO_OPT_IMPL, "fusedMM_csr_udef_hip: unknown bits above the AOP nibble");
@@ -280,6 +336,7 @@ extern "C" int fusedMM_csr_udef_hip(int32_t imessage, int64_t m, int64_t n, int6
    if (k > 1024) return fail(ISPLIB_NO_OPT_IMPL, "fusedMM_csr_udef_hip: the generic pipeline holds a row in registers, k <= 1024");
    if (beta != 0.0f) return fail(ISPLIB_FAIL, "fusedMM_csr_udef_hip: beta must be 0 (z is write-only)");
    if (m == 0 || k == 0) return ISPLIB_SUCCESS;
+   if (plan.task_row && k < 4) return fail(ISPLIB_FAIL, "fusedMM_csr_udef_tasks_hip: k >= 4 required (use fusedMM_csr_udef_hip)");
    const bool needs_x = a.vop != G_VOP_COPY_RHS || a.rop == G_ROP_DOT || a.rop == G_ROP_ADD_LHS || a.rop == G_ROP_NORML;
    if (!pntrb || !pntre || !z || (nnz > 0 && (!indx || !y)) || (needs_x && !x))
       return fail(ISPLIB_FAIL, "fusedMM_csr_udef_hip: null operand");
@@ -293,11 +350,59 @@ extern "C" int fusedMM_csr_udef_hip(int32_t imessage, int64_t m, int64_t n, int6
    const int word = imessage & 0xFFFFF;
    const int pat = word == (0x2 | 0x10 | 0xF00 | 0x1000 | 0x10000) ? 1 : word == (0x5 | 0x50 | 0xF00 | 0x1000 | 0x10000) ? 2 : 0;
    hipStream_t st = (hipStream_t)stream;
+   if (plan.task_row) {
+      if (plan.n_tasks < 0 || plan.slices < 1 || plan.slices > ISPLIB_MAX_SLICES)
+         return fail(ISPLIB_FAIL, "fusedMM_csr_udef_tasks_hip: bad plan (n_tasks >= 0, slices in [1, 4096])");
+      if (!plan.task_b || !plan.task_len || !plan.seg_off || !plan.lane_off_host)
+         return fail(ISPLIB_FAIL, "fusedMM_csr_udef_tasks_hip: null plan operand");
+      const size_t plane = ((size_t)plan.n_tasks * (size_t)k * sizeof(float) + 255) & ~(size_t)255;
+      const size_t need = plane * (a.aop == G_AOP_ADD ? 1 : 2);
+      if (!plan.workspace || plan.workspace_bytes < need) return fail(ISPLIB_NOT_ENOUGH_MEM, "fusedMM_csr_udef_tasks_hip: workspace too small");
+      if (((uintptr_t)plan.workspace & 255) != 0) return fail(ISPLIB_FAIL, "fusedMM_csr_udef_tasks_hip: workspace must be 256-byte aligned");
+      a.indx32 = plan.indx32; a.task_row = plan.task_row; a.task_b = plan.task_b; a.task_len = plan.task_len;
+      for (int xl = 0; xl < 9; xl++) a.lane_off[xl] = plan.lane_off_host[xl];
+      if (a.lane_off[0] != 0 || a.lane_off[8] != plan.n_tasks) return fail(ISPLIB_FAIL, "fusedMM_csr_udef_tasks_hip: lane_off must run from 0 to n_tasks");
+      a.part_val = (float *)plan.workspace;
+      a.part_idx = a.aop == G_AOP_ADD ? nullptr : (int *)((char *)plan.workspace + plane);
+   }
    const int64_t w = (k + 3) / 4;
-   if (w <= 8) return launch_general<8, 1>(a, pat, st);
-   if (w <= 16) return launch_general<16, 1>(a, pat, st);
-   if (w <= 32) return launch_general<32, 1>(a, pat, st);
-   if (w <= 64) return launch_general<64, 1>(a, pat, st);
-   if (w <= 128) return launch_general<64, 2>(a, pat, st);
-   return launch_general<64, 4>(a, pat, st);
+   int rc;
+   if (w <= 8) rc = launch_general<8, 1>(a, pat, st);
+   else if (w <= 16) rc = launch_general<16, 1>(a, pat, st);
+   else if (w <= 32) rc = launch_general<32, 1>(a, pat, st);
+   else if (w <= 64) rc = launch_general<64, 1>(a, pat, st);
+   else if (w <= 128) rc = launch_general<64, 2>(a, pat, st);
+   else rc = launch_general<64, 4>(a, pat, st);
+   if (rc || !plan.task_row) return rc;
+   return combine_task_partials(a.aop, m, k, nnz, pntrb, pntre, plan.seg_off, plan.slices, a.vsc == G_VSC_MEAN ? 1 : 0, a.part_val,
+                                a.part_idx, z, ldz, z_arg, st);
+}
+
+extern "C" int fusedMM_csr_udef_hip(int32_t imessage, int64_t m, int64_t n, int64_t k, float alpha, int64_t nnz,
+                                    int64_t rows, int64_t cols, const float *val, const int64_t *indx,
+                                    const int64_t *pntrb, const int64_t *pntre, const float *x, int64_t ldx,
+                                    const float *y, int64_t ldy, float beta, float *z, int64_t ldz, int64_t *z_arg,
+                                    int sop_udef, float sop_param, void *stream) {
+   (void)alpha; (void)rows; (void)cols;
+   return general_entry(imessage, m, n, k, nnz, val, indx, pntrb, pntre, x, ldx, y, ldy, beta, z, ldz, z_arg, sop_udef, sop_param,
+                        GenPlan(), stream);
+}
+
+extern "C" int fusedMM_csr_udef_tasks_hip(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t nnz, const float *val,
+                                          const int64_t *indx, const int32_t *indx32, const int64_t *pntrb,
+                                          const int64_t *pntre, const float *x, int64_t ldx, int64_t n_tasks,
+                                          const int32_t *task_row, const int64_t *task_b, const int32_t *task_len,
+                                          const int32_t *seg_off, int slices, const int64_t *lane_off_host, const float *y,
+                                          int64_t ldy, float *z, int64_t ldz, int64_t *z_arg, int sop_udef, float sop_param,
+                                          void *workspace, size_t workspace_bytes, void *stream) {
+   if (!task_row) {
+      clear_error();
+      return fail(ISPLIB_FAIL, "fusedMM_csr_udef_tasks_hip: task_row is required");
+   }
+   GenPlan plan;
+   plan.indx32 = indx32; plan.n_tasks = n_tasks; plan.task_row = task_row; plan.task_b = task_b; plan.task_len = task_len;
+   plan.seg_off = seg_off; plan.slices = slices; plan.lane_off_host = lane_off_host; plan.workspace = workspace;
+   plan.workspace_bytes = workspace_bytes;
+   return general_entry(imessage, m, n, k, nnz, val, indx, pntrb, pntre, x, ldx, y, ldy, 0.0f, z, ldz, z_arg, sop_udef, sop_param,
+                        plan, stream);
 }

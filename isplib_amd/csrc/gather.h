@@ -289,6 +289,11 @@ template <int U, int LPR> __device__ __forceinline__ constexpr int transposed_ow
    return lane;
 }
 
+// fold of per-task partial rows (combine_tasks_kernel, spmm_tasks.hip) for other task kernels; aop = 1 add, 2 max, 3 min
+int combine_task_partials(int aop, int64_t m, int64_t k, int64_t nnz, const int64_t *pntrb, const int64_t *pntre,
+                          const int *seg_off, int slices, int mean, float *part_val, int *part_idx, float *z, int64_t ldz,
+                          int64_t *z_arg, hipStream_t st);
+
 // tuning knobs (isplib_hip_tune), defined in spmm.hip
 extern int g_force_lpr, g_addr_mode, g_tasks_per_wave, g_panel_cols, g_panel_cols_minmax;
 

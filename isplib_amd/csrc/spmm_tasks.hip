@@ -210,6 +210,23 @@ static int launch_tasks_op(const TaskArgs &a, hipStream_t st) {
    return launch_tasks_cfg<OP, 64, 4, ADDR>(a, st);
 }
 
+int combine_task_partials(int aop, int64_t m, int64_t k, int64_t nnz, const int64_t *pntrb, const int64_t *pntre,
+                          const int *seg_off, int slices, int mean, float *part_val, int *part_idx, float *z, int64_t ldz,
+                          int64_t *z_arg, hipStream_t st) {
+   TaskArgs a = {};
+   a.m = m; a.k = k; a.nnz = nnz; a.pntrb = pntrb; a.pntre = pntre; a.seg_off = seg_off; a.slices = slices; a.mean = mean;
+   a.part_val = part_val; a.part_idx = part_idx; a.z = z; a.ldz = ldz; a.z_arg = z_arg;
+   const bool v4 = k % 4 == 0 && ldz % 4 == 0 && ((uintptr_t)z & 15) == 0;
+   int64_t blocks = (m * (v4 ? k / 4 : k) + 255) / 256;
+   if (blocks > 8192) blocks = 8192;
+   if (blocks < 1) return ISPLIB_SUCCESS;
+   const dim3 grid((unsigned)blocks), block(256);
+   if (aop == 1) { if (v4) hipLaunchKernelGGL((combine_tasks_kernel<OP_ADD, 4>), grid, block, 0, st, a); else hipLaunchKernelGGL((combine_tasks_kernel<OP_ADD, 1>), grid, block, 0, st, a); }
+   else if (aop == 2) { if (v4) hipLaunchKernelGGL((combine_tasks_kernel<OP_MAX, 4>), grid, block, 0, st, a); else hipLaunchKernelGGL((combine_tasks_kernel<OP_MAX, 1>), grid, block, 0, st, a); }
+   else { if (v4) hipLaunchKernelGGL((combine_tasks_kernel<OP_MIN, 4>), grid, block, 0, st, a); else hipLaunchKernelGGL((combine_tasks_kernel<OP_MIN, 1>), grid, block, 0, st, a); }
+   return check_launch("combine_tasks_kernel");
+}
+
 }  // namespace isplib
 
 using namespace isplib;

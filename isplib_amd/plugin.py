@@ -189,7 +189,17 @@ def fusedmm(src, x: Optional[torch.Tensor], y: torch.Tensor, pattern="sigmoid_em
     else:
         word, fn = int(pattern), (sop_udef or "none")
     st = _storage_of(src, y)
-    return cabi.fusedmm(word, st._rowptr, st._col, st._value, x, y, sop_udef=sop_udef or fn, sop_param=sop_param)[1]
+    # the reduce stage needs whole rows of y, so there are no column panels here: slices for the full width
+    k, plan = y.size(1), None
+    nbytes = y.size(0) * k * 4
+    if 4 <= k <= 1024 and st._col.numel() >= (1 << 20) and st._col.numel() >= 64 * (st._rowptr.numel() - 1) and nbytes >= (14 << 20):
+        slices = min(64, max(1, int(nbytes / float(7 << 20) + 0.5), 1))
+        slices = max(1, min(slices, int(st._col.numel() / (st._rowptr.numel() - 1) / 20)))
+        held = st.plan(slices)
+        if held:
+            from .plan import TaskPlan
+            plan = TaskPlan(slices, held[0].numel(), held[0], held[1], held[2], held[3], [int(v) for v in held[4]], 1024, 128, held[5])
+    return cabi.fusedmm(word, st._rowptr, st._col, st._value, x, y, sop_udef=sop_udef or fn, sop_param=sop_param, plan=plan)[1]
 
 
 def gcn_norm_matmul(src, other: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:

@@ -81,3 +81,38 @@ def test_spmm_words_agree_with_the_tuned_kernels_and_status_codes(gpu, oracle_mo
     assert bad(_word(8, 0, 1, 1, 1)) == cabi.NO_OPT_IMPL
     assert bad(_word(2, 0, 1, 3, 2)) == cabi.NO_OPT_IMPL
     assert cabi.fusedmm(_word(3, 0, 1, 1, 1), d_rowptr, d_col, d_val, None, d_y, check=False)[0] == cabi.FAIL   # VOP_ADD without x
+
+
+@pytest.mark.parametrize("k", (8, 41, 128, 300))
+def test_task_form_of_the_generic_pipeline(gpu, oracle_mod, k):
+    """fusedMM_csr_udef_tasks_hip over SpMM task plans: exact on integer operands for a spread of stage words
+    (max/min incl. arg; hub rows chunked; odd slice counts), named patterns within tolerance on real operands."""
+    from isplib_amd import cabi
+    from isplib_amd.plan import build_task_plan
+    rowptr, col = cases.random_csr(300, 280, 25.0, seed=k, empty_rows=(0, 150), hub=(9, 300), duplicates=True)   # sums stay < 2^24: exact
+    val = cases.weights(col.size, 4, "signed_int")
+    x, y = cases.dense(300, k, 3, "integer"), cases.dense(280, k, 5, "integer")
+    d = [_t(a, gpu) for a in (rowptr, col, val, x, y)]
+    words = [_word(v, r, s, c, a) for v in (1, 2, 4, 5, 6) for r in (0, 1, 3, 5) for s, c in ((0, 1), (1, 1), (0xF, 2), (1, 3))
+             for a in (1, 2, 3) if not (c == 3 and a != 1)]
+    for slices, chunk, short in ((1, 256, 0), (5, 128, 16), (8, 1024, 128)):
+        plan = build_task_plan(d[0], d[1], 280, slices, chunk, short)
+        for w in words:
+            kind, prm = (4, 0.25) if ((w >> 8) & 0xF) == 0xF else (0, 0.0)
+            st, ref, ref_arg = oracle_mod.fusedmm_general(w, rowptr, col, val, x, y, kind, prm)
+            st2, z, arg = cabi.fusedmm(w, *d, sop_udef=kind, sop_param=prm, plan=plan)
+            assert st == 0 and st2 == 0, hex(w)
+            if ((w >> 12) & 0xF) == 3:
+                assert np.allclose(z.cpu().numpy(), ref, rtol=1e-6, atol=1e-6), (hex(w), slices)
+            else:
+                assert np.array_equal(z.cpu().numpy(), ref), (hex(w), slices)
+            if arg is not None:
+                assert np.array_equal(arg.cpu().numpy(), ref_arg), (hex(w), slices)
+    scale = np.float32(1.0 / np.sqrt(k))
+    xr, yr = cases.dense(300, k, 13) * scale, cases.dense(280, k, 15) * scale
+    plan = build_task_plan(d[0], d[1], 280, 6, 512, 64)
+    for pattern in ("sigmoid_embedding", "tdist_embedding", "attention_sum"):
+        word, fn = cabi.PATTERNS[pattern]
+        _, ref, _ = oracle_mod.fusedmm_general(word, rowptr, col, None, xr, yr, cabi.SOP_UDEF[fn], 0.2)
+        z = cabi.fusedmm(word, d[0], d[1], None, _t(xr, gpu), _t(yr, gpu), sop_udef=fn, sop_param=0.2, plan=plan)[1]
+        assert np.all(np.abs(z.cpu().numpy() - ref) <= 1e-4 * np.abs(ref).max() + 1e-7), pattern
