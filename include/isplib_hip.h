@@ -366,6 +366,11 @@ int  isplib_graph_spmm(isplib_graph *g, int32_t imessage, int64_t k, const float
                        float *z, int64_t ldz, int64_t *z_arg, void *stream);
 int  isplib_graph_spmm_backward(isplib_graph *g, int mean, int64_t k, const float *dy, int64_t lddy,
                                 float *dx, int64_t lddx, void *stream);
+/* dA[e] = <y[col[e],:], g[row(e),:]> (mean != 0: / max(deg,1)); its plan is sized for whole rows of y (the dot
+ * product cannot run in column panels): isplib_suggest_slices_whole_rows */
+int  isplib_suggest_slices_whole_rows(int64_t m, int64_t n, int64_t nnz, int64_t k);
+int  isplib_graph_sddmm(isplib_graph *g, int mean, int64_t k, const float *y, int64_t ldy,
+                        const float *gmat, int64_t ldg, float *dval, void *stream);
 void isplib_graph_destroy(isplib_graph *g);
 
 #ifdef __cplusplus

@@ -50,7 +50,7 @@ EXPORTS = (
     "isplib_spmm_tasks_plan_workspace_bytes", "isplib_spmm_tasks_count_hip", "isplib_spmm_tasks_fill_hip",
     "isplib_sddmm_csr_tasks_hip", "fusedMM_csr_tasks_epilogue_hip", "fusedMM_csr_udef_hip", "fusedMM_csr_udef_tasks_hip", "isplib_pack_indices_hip",
     "isplib_suggest_slices", "isplib_graph_create", "isplib_graph_set_slices", "isplib_graph_spmm", "isplib_graph_spmm_backward",
-    "isplib_graph_destroy",
+    "isplib_graph_destroy", "isplib_suggest_slices_whole_rows", "isplib_graph_sddmm",
 )
 
 _i64, _f32, _vp, _i32 = ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_int32
@@ -140,6 +140,10 @@ def lib() -> ctypes.CDLL:
         L.isplib_graph_spmm.argtypes = [_vp, _i32, _i64, _vp, _i64, _vp, _i64, _vp, _vp]
         L.isplib_graph_spmm_backward.restype = ctypes.c_int
         L.isplib_graph_spmm_backward.argtypes = [_vp, ctypes.c_int, _i64, _vp, _i64, _vp, _i64, _vp]
+        L.isplib_suggest_slices_whole_rows.restype = ctypes.c_int
+        L.isplib_suggest_slices_whole_rows.argtypes = [_i64, _i64, _i64, _i64]
+        L.isplib_graph_sddmm.restype = ctypes.c_int
+        L.isplib_graph_sddmm.argtypes = [_vp, ctypes.c_int, _i64, _vp, _i64, _vp, _i64, _vp, _vp]
         L.isplib_graph_destroy.restype = None
         L.isplib_graph_destroy.argtypes = [_vp]
         L.isplib_hip_tune.restype = ctypes.c_int
@@ -510,6 +514,15 @@ class GraphHandle:
             _check(lib().isplib_graph_spmm_backward(self._h, int(bool(mean)), k, _ptr(dy), k, _ptr(dx), k, _stream(dy.device)),
                    "isplib_graph_spmm_backward")
         return dx
+
+    def sddmm(self, y: torch.Tensor, g: torch.Tensor, mean: bool = False) -> torch.Tensor:
+        y, g = _dev(y, "y", torch.float32), _dev(g, "g", torch.float32)
+        k = y.size(1)
+        dval = torch.empty(self.col.numel(), dtype=torch.float32, device=y.device)
+        with torch.cuda.device(y.device):
+            _check(lib().isplib_graph_sddmm(self._h, int(bool(mean)), k, _ptr(y), k, _ptr(g), k, _ptr(dval), _stream(y.device)),
+                   "isplib_graph_sddmm")
+        return dval
 
     def close(self) -> None:
         if self._h:

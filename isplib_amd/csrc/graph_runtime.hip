@@ -96,6 +96,20 @@ extern "C" int isplib_suggest_slices(int64_t m, int64_t n, int64_t nnz, int64_t 
    return r < 1 ? 1 : (r > 64 ? 64 : r);
 }
 
+extern "C" int isplib_suggest_slices_whole_rows(int64_t m, int64_t n, int64_t nnz, int64_t k) {
+   // The same rule for kernels that need every column of a row per edge (SDDMM's dot product, the generic
+   // pipeline's ROP) and therefore cannot run in column panels: slices sized by the full row width.
+   if (m <= 0 || n <= 0 || k <= 0) return 0;
+   const double avg_deg = (double)nnz / (double)m;
+   if (nnz < (1 << 20) || avg_deg < 64.0) return 0;
+   const double by_cache = (double)n * (double)k * 4.0 / (double)(7 << 20);
+   const double floor_k = (double)(k < 128 ? k : 128) / 20.0;
+   double s = by_cache > floor_k ? by_cache : floor_k;
+   if (avg_deg / 20.0 < s) s = avg_deg / 20.0;
+   const int r = (int)(s + 0.5);
+   return r < 1 ? 1 : (r > 64 ? 64 : r);
+}
+
 extern "C" int isplib_graph_create(int64_t m, int64_t n, int64_t nnz, const int64_t *rowptr, const int64_t *col,
                                    const float *val, isplib_graph **out) {
    clear_error();
@@ -286,4 +300,33 @@ extern "C" int isplib_graph_spmm_backward(isplib_graph *g, int mean, int64_t k, 
    const int rc = ensure_transpose(g, st);
    if (rc) return rc;
    return run_side(g, g->bwd, mean ? g->mean_val_t : g->bwd.val, ISPLIB_MSG_SPMM_SUM, k, dy, lddy, dx, lddx, nullptr, st);
+}
+
+// dA[e] = <y[col[e], :], g[row(e), :]> (/ max(deg,1) for mean): the SDDMM the reference leaves commented out
+// (csrc/fusedmm.cpp:270,351), over a task plan whose slice count is chosen for WHOLE rows of y
+extern "C" int isplib_graph_sddmm(isplib_graph *g, int mean, int64_t k, const float *y, int64_t ldy, const float *gm,
+                                  int64_t ldg, float *dval, void *stream) {
+   clear_error();
+   if (!g) return fail(ISPLIB_FAIL, "isplib_graph_sddmm: null handle");
+   hipStream_t st = (hipStream_t)stream;
+   Side &s = g->fwd;
+   int slices = g->forced_slices >= 0 ? g->forced_slices : isplib_suggest_slices_whole_rows(s.m, s.n, s.nnz, k);
+   if (k < 4 || k > 1024 || (double)s.n * (double)ldy * 4.0 > 3.5 * 1073741824.0) slices = 0;
+   if (slices > 0) {
+      auto it = s.plans.find(slices);
+      if (it == s.plans.end()) {
+         Plan p;
+         const int rc = build_plan(g, s, slices, st, p);
+         if (rc) {
+            (void)hipFree(p.task_row); (void)hipFree(p.task_len); (void)hipFree(p.seg_off); (void)hipFree(p.task_b);
+            return rc;
+         }
+         it = s.plans.emplace(slices, p).first;
+      }
+      const Plan &p = it->second;
+      if (p.usable)
+         return isplib_sddmm_csr_tasks_hip(s.m, s.n, k, s.col, s.col32, s.rowptr, s.rowptr + 1, p.n_tasks, p.task_row, p.task_b,
+                                           p.task_len, p.lane_off, y, ldy, gm, ldg, mean, dval, st);
+   }
+   return isplib_sddmm_csr_hip(s.m, k, s.col, s.rowptr, s.rowptr + 1, y, ldy, gm, ldg, mean, dval, st);
 }

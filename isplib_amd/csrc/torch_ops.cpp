@@ -143,11 +143,9 @@ std::mutex g_graph_mutex;
 std::unordered_map<GraphKey, GraphCacheEntry, GraphKeyHash> g_graphs;
 
 // runs the SpMM through a cached handle; false = not applicable (caller falls through to the plain kernel)
-bool spmm_through_handle(int32_t msg, const Tensor &rowptr, const Tensor &col, const Tensor &value, const Tensor &mat,
-                         Tensor &out, Tensor &arg) {
-   const int64_t M = rowptr.numel() - 1, N = mat.size(0), K = mat.size(1), nnz = col.numel();
-   if (isplib_suggest_slices(M, N, nnz, K, (msg & 0xF0000) != ISPLIB_AOP_ADD) <= 0) return false;
-   std::lock_guard<std::mutex> lock(g_graph_mutex);        // also serialises the handle's shared workspace
+// the handle of (rowptr, col, value) with N dense rows; g_graph_mutex must be held
+isplib_graph *graph_handle_locked(const Tensor &rowptr, const Tensor &col, const Tensor &value, int64_t N) {
+   const int64_t M = rowptr.numel() - 1, nnz = col.numel();
    const GraphKey key{rowptr.data_ptr(), col.data_ptr(), value.defined() ? value.data_ptr() : nullptr, N};
    auto it = g_graphs.find(key);
    if (it != g_graphs.end() && !it->second.matches(rowptr, col, value)) {
@@ -170,7 +168,16 @@ bool spmm_through_handle(int32_t msg, const Tensor &rowptr, const Tensor &col, c
                    "isplib_graph_create");
       it = g_graphs.emplace(key, std::move(e)).first;
    }
-   const int st = isplib_graph_spmm(it->second.handle, msg, K, mat.data_ptr<float>(), K, out.data_ptr<float>(), K,
+   return it->second.handle;
+}
+
+bool spmm_through_handle(int32_t msg, const Tensor &rowptr, const Tensor &col, const Tensor &value, const Tensor &mat,
+                         Tensor &out, Tensor &arg) {
+   const int64_t M = rowptr.numel() - 1, N = mat.size(0), K = mat.size(1), nnz = col.numel();
+   if (isplib_suggest_slices(M, N, nnz, K, (msg & 0xF0000) != ISPLIB_AOP_ADD) <= 0) return false;
+   std::lock_guard<std::mutex> lock(g_graph_mutex);        // also serialises the handle's shared workspace
+   isplib_graph *handle = graph_handle_locked(rowptr, col, value, N);
+   const int st = isplib_graph_spmm(handle, msg, K, mat.data_ptr<float>(), K, out.data_ptr<float>(), K,
                                     arg.defined() ? arg.data_ptr<int64_t>() : nullptr, current_stream(mat));
    if (st == ISPLIB_NOT_ENOUGH_MEM) return false;      // no room for the plan beside torch's pool: the plain kernel needs none
    check_status(st, "isplib_graph_spmm");
@@ -275,12 +282,27 @@ Transposed build_transpose(const Tensor &rowptr, const Tensor &col, const Tensor
 }
 
 Tensor sddmm(const Tensor &rowptr, const Tensor &col, const Tensor &mat, const Tensor &grad_out, bool mean,
-             const std::vector<Tensor> &plan = {}) {
+             const std::vector<Tensor> &plan = {}, const Tensor &value = Tensor()) {
    c10::DeviceGuard guard(mat.device());
    const Tensor g = grad_out.contiguous(), y = mat.contiguous();
    const int64_t M = rowptr.numel() - 1, N = y.size(0), K = y.size(1);
    Tensor dval = at::empty({col.numel()}, y.options());
    const int64_t *rp = rowptr.data_ptr<int64_t>();
+   // The dot product needs whole rows of y, so the SpMM's plan (sized for 64-column panels) is the wrong one here:
+   // large graphs go through the graph's handle, which keeps a plan sized for whole rows (Reddit K=128: 3.7 ms with
+   // 16 slices, 4.6 ms on the SpMM's 8).  dA does not read the weights, and the weights tensor autograd hands back
+   // here is a different object from the forward's, so this handle is keyed by (rowptr, col) alone.
+   (void)value;
+   if (K >= 4 && rowptr.is_contiguous() && col.is_contiguous() && isplib_suggest_slices_whole_rows(M, N, col.numel(), K) > 0) {
+      std::lock_guard<std::mutex> lock(g_graph_mutex);
+      isplib_graph *handle = graph_handle_locked(rowptr, col, Tensor(), N);
+      const int st = isplib_graph_sddmm(handle, mean ? 1 : 0, K, y.data_ptr<float>(), K, g.data_ptr<float>(), K,
+                                        dval.data_ptr<float>(), current_stream(y));
+      if (st != ISPLIB_NOT_ENOUGH_MEM) {
+         check_status(st, "isplib_graph_sddmm");
+         return dval;
+      }
+   }
    if (is_task_plan(plan) && K >= 4 && K <= 1024 && (double)N * (double)K * 4.0 <= 3.5 * 1073741824.0) {
       const int st = isplib_sddmm_csr_tasks_hip(M, N, K, col.data_ptr<int64_t>(), plan_col32(plan, col), rp, rp + 1, plan[0].numel(),
                                                 plan[0].data_ptr<int32_t>(), plan[1].data_ptr<int64_t>(),
@@ -381,7 +403,7 @@ class SpmmSum : public torch::autograd::Function<SpmmSum> {
 
       auto grad_value = Variable();
       if (has_value && ctx->needs_input_grad(ctx->saved_data["value_edge"].toInt()))   // :269-272 (SDDMM, commented out there)
-         grad_value = sddmm(rowptr, col, mat, grad_out, false, ctx->saved_data["plan"].toTensorVector());
+         grad_value = sddmm(rowptr, col, mat, grad_out, false, ctx->saved_data["plan"].toTensorVector(), value);
 
       auto grad_mat = Variable();
       if (ctx->needs_input_grad(ctx->saved_data["mat_edge"].toInt())) {
@@ -432,7 +454,7 @@ class SpmmMean : public torch::autograd::Function<SpmmMean> {
 
       auto grad_value = Variable();
       if (has_value && ctx->needs_input_grad(ctx->saved_data["value_edge"].toInt()))
-         grad_value = sddmm(rowptr, col, mat, grad_out, true, ctx->saved_data["plan"].toTensorVector());   // :350-353
+         grad_value = sddmm(rowptr, col, mat, grad_out, true, ctx->saved_data["plan"].toTensorVector(), value);   // :350-353
 
       auto grad_mat = Variable();
       if (ctx->needs_input_grad(ctx->saved_data["mat_edge"].toInt())) {

@@ -192,9 +192,8 @@ def fusedmm(src, x: Optional[torch.Tensor], y: torch.Tensor, pattern="sigmoid_em
     # the reduce stage needs whole rows of y, so there are no column panels here: slices for the full width
     k, plan = y.size(1), None
     nbytes = y.size(0) * k * 4
-    if 4 <= k <= 1024 and st._col.numel() >= (1 << 20) and st._col.numel() >= 64 * (st._rowptr.numel() - 1) and nbytes >= (14 << 20):
-        slices = min(64, max(1, int(nbytes / float(7 << 20) + 0.5), 1))
-        slices = max(1, min(slices, int(st._col.numel() / (st._rowptr.numel() - 1) / 20)))
+    slices = int(cabi.lib().isplib_suggest_slices_whole_rows(st._rowptr.numel() - 1, y.size(0), st._col.numel(), k))
+    if 4 <= k <= 1024 and slices > 0 and nbytes >= (14 << 20):
         held = st.plan(slices)
         if held:
             from .plan import TaskPlan

@@ -51,8 +51,8 @@ for k in (64, 128):
         del adj
     res[f"k{k}/sddmm_ms"] = timeit(lambda: cabi.sddmm(rowptr, col, x, g))
     from isplib_amd.plan import build_task_plan
-    from isplib_amd.plugin import suggest_slices
-    tp = build_task_plan(rowptr, col, n, suggest_slices(n, n, nnz, k))
+    # the dot product needs whole rows: slices by the whole-row rule, not the SpMM's panel rule
+    tp = build_task_plan(rowptr, col, n, max(1, cabi.lib().isplib_suggest_slices_whole_rows(n, n, nnz, k)))
     res[f"k{k}/sddmm_tasks_ms"] = timeit(lambda: cabi.sddmm_tasks(rowptr, col, tp, x, g))
     del tp
     out, arg = cabi.spmm(rowptr, col, w, x, "max")

@@ -465,6 +465,9 @@ def test_graph_handle_runs_the_fast_path_for_torch_free_hosts(gpu, oracle_mod):
             dxm = h.spmm_backward(_t(g, gpu), mean=True).cpu().numpy()
             mref = oracle_mod.spmm_mean_bw(rowptr, col, hv, 260, g)
             assert np.all(np.abs(dxm - mref) <= 1e-5 * dmag + 1e-30), slices
+            for mean in (False, True):
+                da = h.sddmm(_t(x, gpu), _t(g, gpu), mean=mean).cpu().numpy()
+                assert np.allclose(da, oracle_mod.sddmm(rowptr, col, x, g, mean=mean), rtol=1e-5, atol=1e-5), (slices, mean)
         h.close()
         h.close()                                                   # idempotent
     with pytest.raises(RuntimeError):
@@ -498,10 +501,20 @@ def test_reference_schema_ops_get_the_task_schedule_through_cached_handles(gpu, 
         assert np.all(np.abs(out.detach().cpu().numpy() - ref) <= tol)
         assert np.all(np.abs(xs.grad.cpu().numpy() - dref) <= 1e-5 * dmag + 1e-30)
         assert ops.graph_cache_size() == 2, "one handle for A, one for the cached A^T operands; reused on the second pass"
+    # dA (the SDDMM the reference leaves commented out) runs off the same handle of A, on a plan sized for whole rows
+    d_val.requires_grad_(True)
+    out = ops.fusedmm_spmm(row, d_rowptr, d_col, d_val, colptr, perm, _t(x, gpu), val_t, row_t)
+    out.backward(_t(g, gpu))
+    assert np.allclose(d_val.grad.cpu().numpy(), oracle_mod.sddmm(rowptr, col, x, g), rtol=1e-5, atol=1e-4)
+    assert ops.graph_cache_size() == 3                                  # + the weight-free handle of (rowptr, col) for dA
+    out = ops.fusedmm_spmm(row, d_rowptr, d_col, d_val, colptr, perm, _t(x, gpu), val_t, row_t)
+    out.backward(_t(g, gpu))
+    assert ops.graph_cache_size() == 3                                  # and it is reused
+    d_val = d_val.detach()        # same storage, new tensor object: its stale handle is replaced, not added to
     mx, arg = ops.fusedmm_spmm_max(d_rowptr, d_col, d_val, _t(x, gpu))
     rmx, rarg = oracle_mod.spmm_fw(rowptr, col, val, x, "max")
     assert np.array_equal(mx.cpu().numpy(), rmx) and np.array_equal(arg.cpu().numpy(), rarg)
-    assert ops.graph_cache_size() == 2                                   # same (rowptr, col, value) triple: same handle
+    assert ops.graph_cache_size() == 3                                   # the (rowptr, col, value) slot was re-used
     # an in-place edit of the graph invalidates its handle (version counter), and the answer follows the edit
     d_val.mul_(2.0)
     out2 = ops.fusedmm_spmm_max(d_rowptr, d_col, d_val, _t(x, gpu))[0]
