@@ -155,12 +155,17 @@ def main():
     # operands once, isplib/__init__.py:76-106): slice table + workspace of the column-sliced path
     from isplib_amd.plugin import suggest_slices
     table = work = plan = None
+    user_slices = a.slices >= 0
+    if a.slices < 0 and a.schedule == "sliced":      # the one-pass sliced kernel has no column panels: whole-row rule
+        a.slices = int(cabi.lib().isplib_suggest_slices_whole_rows(m_local, x_in.size(0), l_col.numel(), k))
     if a.slices < 0:
         a.slices = suggest_slices(m_local, x_in.size(0), l_col.numel(), k, a.reduce in ("max", "min"))
+    sliced_slices = a.slices        # slice count of the one-pass column-sliced kernel (differs from the task plan's at N > 1)
     if multi and a.slices > 0:
-        plan = part.plan(k, a.reduce, slices=a.slices)     # slice count rounded to a multiple of world
+        # the sliced kernel has no column panels: its own rule (whole rows), rounded to a multiple of world
+        plan = part.plan(k, a.reduce, slices=a.slices if user_slices else None)
         if plan is not None:
-            a.slices, table, work = plan
+            sliced_slices, table, work = plan
     elif a.slices > 0:
         table, ok = cabi.spmm_slices(l_rowptr, l_col, x_in.size(0), a.slices)
         if not ok:
@@ -179,7 +184,7 @@ def main():
         if tp is not None:
             cabi.fusedMM_csr_tasks_hip(msg, rp, cl, vl, tp, xin, o, ar, twork)
         elif tb is not None:
-            cabi.fusedMM_csr_sliced_hip(msg, rp, cl, vl, tb, a.slices, xin, o, ar, work)
+            cabi.fusedMM_csr_sliced_hip(msg, rp, cl, vl, tb, sliced_slices, xin, o, ar, work)
         else:
             cabi.fusedMM_csr_hip(msg, rp, cl, vl, xin, o, ar)
 
@@ -389,7 +394,7 @@ def main():
                             + ("" if a.scale == 1.0 else f", SCALED x{a.scale} (debug)"),
                 "schedule": (f"task list: {a.slices} column slices, {tplan.n_tasks} tasks of <= {a.chunk} edges, rows < {a.short} unsliced"
                              if use_tasks else
-                             f"{a.slices} column slices, XCD-affine" if a.slices > 0 else "row-per-wave, unsliced"),
+                             f"{sliced_slices} column slices, XCD-affine" if a.slices > 0 else "row-per-wave, unsliced"),
                 "partition": "none" if not multi else f"1-D rows by nnz, {world} ranks, one all-gather(X) per step"
                              + f", schedule: {chosen}",
             },
@@ -401,7 +406,7 @@ def main():
                                                                               if k >= 96 and k % 32 == 0 else
                                                                               f", {-(-k // 128)} passes of 128 columns per launch"
                                                                               if k >= 192 else "")) if use_tasks else
-                           "spmm_csr_kernel" + (f"<sliced x{a.slices}> + combine_slices_kernel" if a.slices > 0 else "")),
+                           "spmm_csr_kernel" + (f"<sliced x{sliced_slices}> + combine_slices_kernel" if a.slices > 0 else "")),
                 "kernel_avg_ms": kern_avg_ms, "kernel_median_ms": sorted(kern_ms)[len(kern_ms) // 2], "kernel_min_ms": min(kern_ms),
                 "kernel_cold_cache_ms": cold_ms, "peak_measured_copy": copy_gbps,
                 "frac_of_measured_copy": None if not copy_gbps else achieved / copy_gbps,

@@ -111,8 +111,8 @@ class RowPartition:
         """Per-graph operands of the sliced path on this rank: (slices, table, workspace) or None.
         The slice count is a multiple of `world`, so each shard of X holds whole slices."""
         from . import cabi
-        from .plugin import suggest_slices
-        s = suggest_slices(self.rows, self.ncols_padded, self.nnz, k, reduce in ("max", "min")) if slices is None else slices
+        # the phased sliced kernel runs whole rows in one pass (no column panels): the whole-row slice rule
+        s = int(cabi.lib().isplib_suggest_slices_whole_rows(self.rows, self.ncols_padded, self.nnz, k)) if slices is None else slices
         if s <= 0:
             return None
         q = (s + self.world - 1) // self.world           # slices per shard: a divisor of the 192-row pitch unit
