@@ -262,7 +262,8 @@ def _spmm_auto(self, x_local: torch.Tensor) -> torch.Tensor:
         s = suggest_slices(self.rows, self.ncols_padded, self.nnz, k)
         ops = None
         if s > 0 and mode == "overlap":
-            ops = self.plan(k, "sum", slices=s)
+            forced = os.environ.get("ISPLIB_SLICES")        # one-pass sliced kernel: its own (whole-row) slice rule
+            ops = self.plan(k, "sum", slices=int(forced) if forced else None)
         elif s > 0 and mode == "pipelined" and k >= 32:
             ops = self.pipeline_state(k, 2, "sum")
         elif s > 0:

@@ -33,6 +33,7 @@ t = lambda a: torch.from_numpy(a).to(dev)
 # plain gather-then-SpMM, then the three schedules of a sliced graph (ISPLIB_DIST_SCHEDULE)
 for slices, mode in (("0", "tasks"), ("8", "tasks"), ("8", "overlap"), ("6", "pipelined")):
     os.environ["ISPLIB_DIST_SCHEDULE"] = mode
+    os.environ["ISPLIB_SLICES"] = slices            # the one-pass sliced kernel of `overlap` has its own rule: force it
     import isplib_amd.plugin as plugin
     plugin.suggest_slices = (lambda *a, **kw: int(slices))
     graph = DistGraph(t(rowptr), t(col), t(val), n, rank, world)
@@ -47,6 +48,7 @@ for slices, mode in (("0", "tasks"), ("8", "tasks"), ("8", "overlap"), ("6", "pi
     dref = oracle.spmm_sum_bw(rowptr, col, val, n, g)
     dmag = oracle.spmm_sum_bw(rowptr, col, np.abs(val), n, np.abs(g))
     assert np.all(np.abs(xs.grad.cpu().numpy() - dref[r0:r1]) <= 1e-5 * dmag[r0:r1] + 1e-30), (slices, mode)
+os.environ.pop("ISPLIB_SLICES", None)
 # pipelined K-panel schedule: bitwise the task-list SpMM run panel by panel after one gather (max/min: also
 # bitwise the unpanelled call; sums differ from it in the last bits, the slots per wave depend on the width)
 from isplib_amd import cabi
