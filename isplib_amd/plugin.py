@@ -262,7 +262,7 @@ class iSpLibPlugin:
                 _pyg_typing.WITH_PT20 = pt20
 
     @classmethod
-    def autotune(cls, src, k: int, reduce: str = "sum", candidates=(0, 8, 16, 24, 32), reps: int = 3, other_rows=None):
+    def autotune(cls, src, k: int, reduce: str = "sum", candidates=(0, 2, 4, 6, 8, 12, 16, 24), reps: int = 3, other_rows=None):
         """Times the SpMM of `src` at width `k` for each candidate slice count on the actual graph and keeps
         the fastest for every later call (the heir of the reference's tuning scripts: autotuner/findbestk.py:34-38
         sweeps K and prints a table, gpu/kernels/codegen.py:30-41 sweeps a launch parameter).  Returns

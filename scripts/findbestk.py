@@ -24,7 +24,7 @@ def main():
     p.add_argument("--scale", type=float, default=1.0)
     p.add_argument("--reduce", default="sum", choices=("sum", "mean", "max", "min"))
     p.add_argument("--ks", default="16,32,64,128,256,512,1024")      # findbestk.py:34
-    p.add_argument("--candidates", default="0,8,16,24,32")
+    p.add_argument("--candidates", default="0,2,4,6,8,12,16,24")
     p.add_argument("--save", help="merge the winning slice counts into this JSON tuning file")
     a = p.parse_args()
     if (a.mtx is None) == (a.workload is None):
