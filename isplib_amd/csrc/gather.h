@@ -157,6 +157,24 @@ __device__ __forceinline__ void buf_step(const __amdgpu_buffer_rsrc_t rsrc, unsi
          t[u][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)o, 0, 0);
       }
    }
+   if (OP == OP_ADD) {
+      // The UU values of a step are summed among themselves first and enter the running sum as ONE term: the same
+      // number of adds (one more for weighted rows), but the long dependent chain on acc is UU times shorter, and so
+      // is the worst-case rounding growth on rows of many like-signed terms (measured on a 2,903-edge row over 3
+      // distinct columns: 0.1-0.3 of the 1e-5 tolerance; the fp32 sequential oracle is at 4.8).
+#pragma unroll
+      for (int j = 0; j < NCH; j++) {
+#pragma unroll
+         for (int v = 0; v < 4; v++) {
+            float part = HAS_VAL ? vv[0] * __int_as_float(t[0][j][v]) : __int_as_float(t[0][j][v]);
+#pragma unroll
+            for (int u = 1; u < UU; u++)
+               part = HAS_VAL ? fmaf(vv[u], __int_as_float(t[u][j][v]), part) : part + __int_as_float(t[u][j][v]);
+            acc[j][v] += part;
+         }
+      }
+      return;
+   }
 #pragma unroll
    for (int u = 0; u < UU; u++) {
       const int ei = s + u * G + g;
