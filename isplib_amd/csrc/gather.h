@@ -103,6 +103,19 @@ __device__ __forceinline__ void wave_edges(const Args &a, int64_t row_b, int64_t
                }
             }
          }
+         if (OP == OP_ADD) {            // a step's values are summed first, then enter the running sum as one term
+#pragma unroll
+            for (int j = 0; j < NCH; j++) {
+#pragma unroll
+               for (int v = 0; v < VEC; v++) {
+                  float part = 0.0f;
+#pragma unroll
+                  for (int u = 0; u < U; u++) part = ok[u] ? fmaf(vv[u], t[u][j][v], part) : part;
+                  acc[j][v] += part;
+               }
+            }
+            continue;
+         }
 #pragma unroll
          for (int u = 0; u < U; u++) {
             const int ei = s + u * G + g;
