@@ -4,10 +4,13 @@
  * This is the drop-in boundary: plain pointers and sizes, no torch types.
  * Every pointer marked [dev] is a DEVICE pointer (HBM); every entry point is
  * asynchronous on `stream` (a hipStream_t passed as void*; NULL = the default
- * stream) and returns a FusedMM status code.  Nothing here allocates, frees or
- * synchronises, so all of it is hipGraph-capturable; entry points that need
- * scratch take a caller-owned workspace whose size a *_workspace_bytes query
- * reports.
+ * stream) and returns a FusedMM status code.  The compute entries neither
+ * allocate, free nor synchronise, so they are hipGraph-capturable; those that
+ * need scratch take a caller-owned workspace whose size a *_workspace_bytes
+ * query reports.  The two exceptions say so where they are declared: the plan
+ * builder isplib_spmm_tasks_count_hip (one stream synchronisation, once per
+ * graph) and the isplib_graph_* handle, which owns device memory on the
+ * caller's behalf.
  *
  * Reference interfaces replaced (paths relative to the iSpLib tree):
  *   fusedMM_csr_hip            <- fusedMM_csr, csrc/fusedMM.h:77-99, called at
@@ -24,6 +27,12 @@
  *   isplib_csr_* (graph prep)  <- torch_sparse storage getters the wrapper
  *                                 forces at isplib/__init__.py:67-73 and the two
  *                                 nnz-sized gathers it caches at :79-80,:86-99.
+ *   isplib_graph_*             <- the per-graph caches of isplib/__init__.py:35-40,
+ *                                 50,76-106 (class-level dicts keyed by data pointers).
+ *   isplib_suggest_slices*     <- autotuner/findbestk.py, gpu/kernels/codegen.py
+ *                                 (sweep a parameter, keep the fastest).
+ *   fusedMM_csr_udef*_hip      <- the other message words of csrc/fusedMM.h:18-74
+ *                                 (defined there, never sent by iSpLib).
  */
 #ifndef ISPLIB_HIP_H
 #define ISPLIB_HIP_H
