@@ -88,11 +88,20 @@ __global__ __launch_bounds__(WAVES * 64, (min_waves_of<OP, LPR, NCH, ADDR>())) v
 #pragma unroll
          for (int j = 0; j < NCH; j++) {
             if (!cok[j]) continue;
-            store_tail<VEC>(a.part_val + off + ccol[j], acc[j], vfirst[j]);
+            // partial rows are written once and read once by the fold: non-temporal, so they do not push rows of y out
+            // of the L2 (3.44 -> 3.39 ms at K=128)
+            float *pp = a.part_val + off + ccol[j];
+            if (vfirst[j] == 0 && ((uintptr_t)pp & 15) == 0) {
+               typedef float f4nt __attribute__((ext_vector_type(4)));
+               const f4nt tv = {acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
+               __builtin_nontemporal_store(tv, reinterpret_cast<f4nt *>(pp));
+            } else {
+               store_tail<VEC>(pp, acc[j], vfirst[j]);
+            }
             if (OP != OP_ADD) {
 #pragma unroll
                for (int v = 0; v < VEC; v++)
-                  if (v >= vfirst[j]) a.part_idx[off + ccol[j] + v] = bi[j][v];
+                  if (v >= vfirst[j]) __builtin_nontemporal_store(bi[j][v], a.part_idx + off + ccol[j] + v);
             }
          }
       }
