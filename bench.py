@@ -176,6 +176,12 @@ def main():
     if a.schedule == "tasks" and a.slices > 0:
         from isplib_amd.plan import build_task_plan
         tplan = build_task_plan(l_rowptr, l_col, x_in.size(0), a.slices, a.chunk, a.short)
+        if not user_slices and tplan is not None and l_col.numel() / max(tplan.n_tasks, 1) >= 120.0:
+            # hub-dominated graph: tasks are long even with the whole-row slice count -> that plan, run in one pass
+            whole = int(cabi.lib().isplib_suggest_slices_whole_rows(m_local, x_in.size(0), l_col.numel(), k))
+            if whole > a.slices:
+                a.slices = whole
+                tplan = build_task_plan(l_rowptr, l_col, x_in.size(0), a.slices, a.chunk, a.short)
         twork = tplan.workspace(a.reduce, k)
     use_tasks = tplan is not None and not multi      # N > 1: decided by a short measurement below
 

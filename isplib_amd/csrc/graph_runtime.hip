@@ -227,6 +227,24 @@ static int run_side(isplib_graph *g, Side &s, const float *val, int32_t imessage
    const int minmax = (imessage & 0xF0000) != ISPLIB_AOP_ADD;
    int slices = g->forced_slices >= 0 ? g->forced_slices : isplib_suggest_slices(s.m, s.n, s.nnz, k, minmax);
    if (k < 4 || (double)s.n * (double)ldy * 4.0 > 3.5 * 1073741824.0) slices = 0;      // outside the task entry's domain
+   if (slices > 0 && g->forced_slices < 0) {
+      // The panel rule halves the slice count to make tasks long enough.  If they are long anyway (hub-dominated
+      // graphs: >= 120 edges per task on the panel plan), the whole-row plan with one pass is the better schedule.
+      const int whole = isplib_suggest_slices_whole_rows(s.m, s.n, s.nnz, k);
+      if (whole > slices) {
+         auto it = s.plans.find(slices);
+         if (it == s.plans.end()) {
+            Plan p;
+            const int rc = build_plan(g, s, slices, st, p);
+            if (rc) {
+               (void)hipFree(p.task_row); (void)hipFree(p.task_len); (void)hipFree(p.seg_off); (void)hipFree(p.task_b);
+               return rc;
+            }
+            it = s.plans.emplace(slices, p).first;
+         }
+         if (it->second.usable && it->second.n_tasks > 0 && (double)s.nnz / (double)it->second.n_tasks >= 120.0) slices = whole;
+      }
+   }
    if (slices > 0) {
       auto it = s.plans.find(slices);
       if (it == s.plans.end()) {

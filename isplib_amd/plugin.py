@@ -133,7 +133,19 @@ def choose_slices(storage: SparseStorage, rows: int, k: int, minmax: bool = Fals
         if tuned is not None:
             storage._tuned[(rows, k, minmax)] = int(tuned)
             return int(tuned)
-    return suggest_slices(storage._rowptr.numel() - 1, rows, storage._col.numel(), k, minmax)
+    m, nnz = storage._rowptr.numel() - 1, storage._col.numel()
+    s = suggest_slices(m, rows, nnz, k, minmax)
+    if s > 0:
+        # the panel rule halves the slice count to make tasks long enough; on hub-dominated graphs they are long anyway
+        # (>= 120 edges per task on the panel plan) and the whole-row plan, run in one pass, is the better schedule
+        from . import cabi
+        whole = int(cabi.lib().isplib_suggest_slices_whole_rows(m, rows, nnz, k))
+        if whole > s:
+            plan_p = storage.plan(s) if rows == storage.sparse_sizes()[1] else storage.plan_t(s)
+            if plan_p and nnz / max(plan_p[0].numel(), 1) >= 120.0:
+                s = whole
+        storage._tuned[(rows, k, minmax)] = s
+    return s
 
 
 def spmm_autotuned(src, other: torch.Tensor, reduce: str = "sum") -> torch.Tensor:
