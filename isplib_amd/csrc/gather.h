@@ -326,6 +326,6 @@ int combine_task_partials(int aop, int64_t m, int64_t k, int64_t nnz, const int6
                           int64_t *z_arg, hipStream_t st);
 
 // tuning knobs (isplib_hip_tune), defined in spmm.hip
-extern int g_force_lpr, g_addr_mode, g_tasks_per_wave, g_panel_cols, g_panel_cols_minmax;
+extern int g_force_lpr, g_addr_mode, g_tasks_per_wave, g_panel_cols, g_panel_cols_minmax, g_one_pass_kib;
 
 }  // namespace isplib

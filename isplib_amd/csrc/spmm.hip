@@ -372,6 +372,7 @@ static int launch_addr(const SpmmArgs &a0, hipStream_t st) {
 int g_force_lpr = 0;   // tuning knob (isplib_hip_tune): lanes per row slot, 0 = by K
 int g_addr_mode = 1;   // tuning knob: 0 = always 64-bit addressing, 1 = buffer descriptors when they fit
 int g_tasks_per_wave = 1;   // tuning knob: consecutive tasks handled by one wave of the task kernel
+int g_one_pass_kib = 10752;     // per-slice footprint of whole rows (KiB) up to which a plan runs in one pass (isplib_hip_tune(8, kib))
 int g_panel_cols_minmax = 64;   // the same for max / min (isplib_hip_tune(5, w))
 int g_panel_cols = 64;      // column-panel width of the task schedule for wide K (isplib_hip_tune(4, w); 0 = one pass)
 
@@ -512,6 +513,7 @@ extern "C" int isplib_hip_tune(int key, int value) {
    if (key == 2) { g_tasks_per_wave = value; return ISPLIB_SUCCESS; }
    if (key == 4) { g_panel_cols = value; return ISPLIB_SUCCESS; }
    if (key == 5) { g_panel_cols_minmax = value; return ISPLIB_SUCCESS; }
+   if (key == 8 && value >= 0) { g_one_pass_kib = value; return ISPLIB_SUCCESS; }
    return ISPLIB_FAIL;
 }
 

@@ -307,7 +307,7 @@ static int tasks_entry(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_
    // budget (<= 1.5 x 7 MB), panels would only shorten the gathers and read the index stream again -- one pass.
    // (The callers pick such a plan when tasks stay long with twice the slices, e.g. hub-dominated R-MAT graphs:
    // 3.43 ms in one pass over 16 slices, 3.67 ms in two passes over 8.)
-   if ((double)n * (double)k * 4.0 / (double)slices <= 1.5 * (double)(7 << 20)) panel = 0;
+   if ((double)n * (double)k * 4.0 / (double)slices <= (double)g_one_pass_kib * 1024.0) panel = 0;
    const int64_t pw = (panel >= 4 && k >= panel + panel / 2) ? (int64_t)(panel / 4 * 4) : k;
    for (int64_t c0 = 0; c0 < k; c0 += pw) {
       TaskArgs p = a;
