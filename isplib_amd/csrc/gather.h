@@ -209,10 +209,24 @@ __device__ __forceinline__ void buf_step(const __amdgpu_buffer_rsrc_t rsrc, unsi
    }
 }
 
-template <int OP, bool HAS_VAL, int LPR, int NCH, int U, class Args>
+// metadata of the 64 edges [p0, p0 + 64) n [.., re): byte offset of the dense row (past the descriptor when masked), weight
+template <bool HAS_VAL, class Args>
+__device__ __forceinline__ void load_edge_batch(const Args &a, int64_t p0, int64_t re, unsigned ldyb, unsigned &off_l, float &v_l) {
+   const int64_t p = p0 + (threadIdx.x & 63);
+   off_l = BUF_OOB;
+   v_l = 0.0f;
+   if (p < re) {
+      off_l = (a.indx32 ? (unsigned)a.indx32[p] : (unsigned)a.indx[p]) * ldyb;
+      if (HAS_VAL) v_l = a.val[p];
+   }
+}
+
+// PRE: the metadata of the first batch was loaded by the caller (prefetched while the previous task was gathering)
+template <int OP, bool HAS_VAL, int LPR, int NCH, int U, class Args, bool PRE = false>
 __device__ __forceinline__ void wave_edges_buf(const Args &a, const __amdgpu_buffer_rsrc_t rsrc, int64_t row_b,
                                                int64_t rb, int64_t re, const int (&ccol)[NCH], const bool (&cok)[NCH],
-                                               float (&acc)[NCH][4], int (&bi)[NCH][4]) {
+                                               float (&acc)[NCH][4], int (&bi)[NCH][4], unsigned pre_off = 0u,
+                                               float pre_val = 0.0f) {
    constexpr int G = 64 / LPR;
    constexpr int UT = U >= 4 ? 2 : 1;   // tail granularity: fewer all-masked gathers on short segments
    const int lane = threadIdx.x & 63;
@@ -225,13 +239,10 @@ __device__ __forceinline__ void wave_edges_buf(const Args &a, const __amdgpu_buf
       poison[j] = cok[j] ? 0u : BUF_OOB;
    }
    for (int64_t base = rb; base < re; base += 64) {
-      const int64_t p = base + lane;
-      unsigned off_l = BUF_OOB;
-      float v_l = 0.0f;
-      if (p < re) {
-         off_l = (a.indx32 ? (unsigned)a.indx32[p] : (unsigned)a.indx[p]) * ldyb;
-         if (HAS_VAL) v_l = a.val[p];
-      }
+      unsigned off_l;
+      float v_l;
+      if (PRE && base == rb) { off_l = pre_off; v_l = pre_val; }
+      else load_edge_batch<HAS_VAL>(a, base, re, ldyb, off_l, v_l);
       const int64_t left = re - base;
       const int cnt = left < 64 ? (int)left : 64;
       const int rel0 = (int)(base - row_b);
@@ -324,6 +335,11 @@ template <int U, int LPR> __device__ __forceinline__ constexpr int transposed_ow
 int combine_task_partials(int aop, int64_t m, int64_t k, int64_t nnz, const int64_t *pntrb, const int64_t *pntre,
                           const int *seg_off, int slices, int mean, float *part_val, int *part_idx, float *z, int64_t ldz,
                           int64_t *z_arg, hipStream_t st);
+
+// task-kernel variants that run the software-pipelined task loop (spmm_tasks.hip) and take two tasks per wave
+template <int OP, int LPR, int NCH, int ADDR> constexpr bool pipelined_tasks() {
+   return OP == OP_ADD && ADDR == 1 && NCH == 1 && LPR >= 16;
+}
 
 // tuning knobs (isplib_hip_tune), defined in spmm.hip
 extern int g_force_lpr, g_addr_mode, g_tasks_per_wave, g_panel_cols, g_panel_cols_minmax, g_one_pass_kib;

@@ -71,9 +71,37 @@ __global__ __launch_bounds__(WAVES * 64, (min_waves_of<OP, LPR, NCH, ADDR>())) v
       vfirst[j] = 0;
       if (cok[j] && ccol[j] + 4 > (int)a.k) { vfirst[j] = ccol[j] + 4 - (int)a.k; ccol[j] = (int)a.k - 4; }
    }
+   // PIPE (the variants with registers to spare: unit-weight sums of 64 columns and more): software pipeline over the
+   // wave's tasks.  While task t gathers, the edge metadata of task t+1 is already on its way (vector load) and the
+   // task record of t+2 too (scalar loads), so a task no longer starts with two dependent round trips to memory
+   // (K=128: 3.39 -> 3.25 ms with two tasks per wave).  The others keep the plain loop: the two extra live values
+   // would spill (weighted 3.60 -> 4.10 ms, max 4.10 -> 4.52 ms, K=32 0.96 -> 1.09 ms when tried).
+   constexpr bool PIPE = pipelined_tasks<OP, LPR, NCH, ADDR>();
+   const unsigned ldyb_pre = (unsigned)a.ldy * 4u;
+   int64_t b_n = 0, e_n = 0, b_nn = 0, e_nn = 0;
+   int row_n = 0, row_nn = 0;
+   unsigned off_n = 0u;
+   float val_n = 0.0f;
+   if (PIPE) {
+      b_n = a.task_b[t0]; e_n = b_n + a.task_len[t0]; row_n = a.task_row[t0];
+      load_edge_batch<ADDR == 2>(a, b_n, e_n, ldyb_pre, off_n, val_n);
+      if (t0 + 1 < t_end) { b_nn = a.task_b[t0 + 1]; e_nn = b_nn + a.task_len[t0 + 1]; row_nn = a.task_row[t0 + 1]; }
+   }
    for (int64_t t = t0; t < t_end; t++) {              // tpw consecutive tasks of this lane per wave
-      const int row = a.task_row[t];
-      const int64_t b = a.task_b[t], e = b + a.task_len[t];
+      int row;
+      int64_t b, e;
+      unsigned off_c = 0u;
+      float val_c = 0.0f;
+      if (PIPE) {
+         row = row_n; b = b_n; e = e_n; off_c = off_n; val_c = val_n;
+         b_n = b_nn; e_n = e_nn; row_n = row_nn;
+         if (t + 1 < t_end) load_edge_batch<ADDR == 2>(a, b_n, e_n, ldyb_pre, off_n, val_n);
+         if (t + 2 < t_end) { b_nn = a.task_b[t + 2]; e_nn = b_nn + a.task_len[t + 2]; row_nn = a.task_row[t + 2]; }
+      } else {
+         row = a.task_row[t];
+         b = a.task_b[t];
+         e = b + a.task_len[t];
+      }
       const int64_t row_b = OP == OP_ADD ? b : a.pntrb[row];
       float acc[NCH][VEC];
       int bi[NCH][VEC];
@@ -81,7 +109,7 @@ __global__ __launch_bounds__(WAVES * 64, (min_waves_of<OP, LPR, NCH, ADDR>())) v
       for (int j = 0; j < NCH; j++)
 #pragma unroll
          for (int v = 0; v < VEC; v++) { acc[j][v] = identity<OP>(); bi[j][v] = INT_MAX; }
-      wave_edges_buf<OP, ADDR == 2, LPR, NCH, U>(a, rsrc, row_b, b, e, ccol, cok, acc, bi);
+      wave_edges_buf<OP, ADDR == 2, LPR, NCH, U, TaskArgs, PIPE>(a, rsrc, row_b, b, e, ccol, cok, acc, bi, off_c, val_c);
       slot_reduce<OP, VEC, LPR, NCH>(acc, bi);
       if (g == 0) {
          const size_t off = (size_t)t * (size_t)a.k;
@@ -180,8 +208,10 @@ __global__ __launch_bounds__(256) void combine_tasks_kernel(const TaskArgs a) {
 }
 
 template <int OP, int LPR, int NCH, int ADDR>
-static int launch_tasks_cfg(const TaskArgs &a, hipStream_t st) {
+static int launch_tasks_cfg(const TaskArgs &a0, hipStream_t st) {
    constexpr int WAVES = 4;
+   TaskArgs a = a0;
+   if (g_tasks_per_wave <= 0) a.tpw = pipelined_tasks<OP, LPR, NCH, ADDR>() ? 2 : 1;      // the pipeline needs a successor
    int64_t most = 0;
    for (int x = 0; x < 8; x++) most = (a.lane_off[x + 1] - a.lane_off[x]) > most ? (a.lane_off[x + 1] - a.lane_off[x]) : most;
    const int64_t gx = 8 * ((most + (int64_t)WAVES * a.tpw - 1) / ((int64_t)WAVES * a.tpw));
@@ -281,7 +311,7 @@ static int tasks_entry(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_
    if (a.lane_off[0] != 0 || a.lane_off[8] != n_tasks) return fail(ISPLIB_FAIL, "fusedMM_csr_tasks_hip: lane_off must run from 0 to n_tasks");
    for (int x = 0; x < 8; x++)
       if (a.lane_off[x + 1] < a.lane_off[x]) return fail(ISPLIB_FAIL, "fusedMM_csr_tasks_hip: lane_off must be non-decreasing");
-   a.tpw = g_tasks_per_wave > 0 ? g_tasks_per_wave : 1;
+   a.tpw = g_tasks_per_wave > 0 ? g_tasks_per_wave : 1;      // 0: chosen per kernel variant at launch
    a.ep_row_scale = a.ep_self = a.ep_bias = nullptr; a.ep_ld_self = 0; a.ep_relu = 0;
    if (ep) {
       if (aop != ISPLIB_AOP_ADD) return fail(ISPLIB_FAIL, "fusedMM_csr_tasks_epilogue_hip: the epilogue is defined for sum / mean only");
