@@ -284,6 +284,7 @@ template <int OP, int NCH, int ADDR, bool TASK = false, int LPR = 64> constexpr 
    if (NCH > 1) return (8 / NCH) > 2 ? 8 / NCH : 2;
    if (TASK) {          // the task kernel keeps less state per wave: 8 gathers in flight fit 64 VGPRs almost everywhere
       if (LPR == 8 && OP != OP_ADD && ADDR == 2) return 4;
+      if (LPR == 8 && OP == OP_ADD && ADDR == 1) return 6;
       if (LPR == 8 && (OP != OP_ADD || ADDR == 2)) return 6;
       if (LPR >= 32 && OP != OP_ADD) return 4;      // measured: 8 is no faster unit-weight and 14 % slower weighted
       if (LPR >= 16 && (OP != OP_ADD || ADDR == 2)) return 6;      // room for the pipelined task loop's prefetch
@@ -339,7 +340,7 @@ int combine_task_partials(int aop, int64_t m, int64_t k, int64_t nnz, const int6
 
 // task-kernel variants that run the software-pipelined task loop (spmm_tasks.hip) and take two tasks per wave
 template <int OP, int LPR, int NCH, int ADDR> constexpr bool pipelined_tasks() {
-   return ADDR != 0 && NCH == 1 && LPR >= 16 && !(OP != OP_ADD && ADDR == 2);   // weighted max/min would spill
+   return ADDR != 0 && NCH == 1 && (LPR >= 16 || (OP == OP_ADD && ADDR == 1)) && !(OP != OP_ADD && ADDR == 2);   // weighted max/min would spill
 }
 
 // tuning knobs (isplib_hip_tune), defined in spmm.hip
