@@ -408,10 +408,10 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                 "traffic_source": None if traffic is None else "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, gfx950-corrected)",
-                "kernel": (("spmm_task_kernel + combine_tasks_kernel" + (f", {-(-k // 64)} passes of 64 columns per launch"
-                                                                              if k >= 96 and k % 32 == 0 else
-                                                                              f", {-(-k // 128)} passes of 128 columns per launch"
-                                                                              if k >= 192 else "")) if use_tasks else
+                "kernel": (("spmm_task_kernel + combine_tasks_kernel" + (
+                    "" if x_in.size(0) * k * 4 / max(a.slices, 1) <= 10752 * 1024 else      # whole-row plan: one pass
+                    f", {-(-k // 64)} passes of 64 columns per launch" if k >= 96 and k % 32 == 0 else
+                    f", {-(-k // 128)} passes of 128 columns per launch" if k >= 192 else "")) if use_tasks else
                            "spmm_csr_kernel" + (f"<sliced x{sliced_slices}> + combine_slices_kernel" if a.slices > 0 else "")),
                 "kernel_avg_ms": kern_avg_ms, "kernel_median_ms": sorted(kern_ms)[len(kern_ms) // 2], "kernel_min_ms": min(kern_ms),
                 "kernel_cold_cache_ms": cold_ms, "peak_measured_copy": copy_gbps,
