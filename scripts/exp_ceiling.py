@@ -12,7 +12,7 @@ nnz = m * deg
 for n in (2048, 8192, 16384, 65536, 232965):
     col = torch.randint(0, n, (m, deg), device=dev).sort(dim=1).values.reshape(-1).contiguous()
     x = torch.rand((n, k), device=dev)
-    for S in (1, 8):
+    for S in ((1, 8) if n < 232965 else (1, 8, 12, 16, 24, 32)):
         plan = build_task_plan(rowptr, col, n, S, 1024, 128)
         work = plan.workspace("sum", k)
         out = torch.empty((m, k), device=dev)
