@@ -364,8 +364,8 @@ int    isplib_csr2csc_hip(int64_t m, int64_t n, int64_t nnz,
  *                         backward, csrc/fusedmm.cpp:375); the CSC operands are built on first use
  *   isplib_suggest_slices the measured rule (0 = plain row-per-wave kernel)
  * The first call that needs a new plan (or the transpose) allocates device memory and synchronises the
- * stream once; every later call is asynchronous and allocation-free.  Not thread-safe; the calls of one
- * handle must be ordered on one stream at a time (they share the workspace).
+ * stream once; every later call is asynchronous and allocation-free.  Not thread-safe (serialise the calls of
+ * one handle), but usable on several streams: each stream it is used on gets its own workspace.
  */
 typedef struct isplib_graph isplib_graph;
 int  isplib_suggest_slices(int64_t m, int64_t n, int64_t nnz, int64_t k, int minmax /*nonzero for max / min*/);

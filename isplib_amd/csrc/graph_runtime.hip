@@ -9,8 +9,8 @@
 //   backward  dX  = A^T dY             isplib_graph_spmm_backward   (sum, or mean with val/deg weights,
 //                                                                    csrc/fusedmm.cpp:285,375)
 // First use of a (side, slice count) allocates and synchronises the stream once; after that every call is
-// asynchronous and allocation-free.  A handle is not thread-safe and its calls must be ordered on one
-// stream at a time (the workspace is shared).
+// asynchronous and allocation-free.  A handle is not thread-safe (serialise the CALLS; the operator library does so
+// with a mutex), but it may be used on several streams: each stream gets its own workspace.
 #include <map>
 #include <new>
 
@@ -65,8 +65,8 @@ struct isplib_graph {
    Side fwd, bwd;                // bwd = A^T, built on first backward call
    bool has_bwd = false;
    float *mean_val_t = nullptr;  // val[csr2csc] / max(deg(row),1): the mean backward's weights
-   void *work = nullptr;
-   size_t work_bytes = 0;
+   struct Work { void *ptr = nullptr; size_t bytes = 0; };
+   std::map<hipStream_t, Work> works;   // one grow-only workspace per stream the handle has been used on
    int forced_slices = -1;       // -1: isplib_suggest_slices
 };
 
@@ -130,7 +130,7 @@ extern "C" void isplib_graph_destroy(isplib_graph *g) {
    free_side(g->fwd, false);
    free_side(g->bwd, true);
    (void)hipFree(g->mean_val_t);
-   (void)hipFree(g->work);
+   for (auto &kv : g->works) (void)hipFree(kv.second.ptr);
    delete g;
 }
 
@@ -142,15 +142,17 @@ extern "C" int isplib_graph_set_slices(isplib_graph *g, int slices) {
    return ISPLIB_SUCCESS;
 }
 
-static int ensure_work(isplib_graph *g, size_t bytes, hipStream_t st) {
-   if (g->work_bytes >= bytes) return ISPLIB_SUCCESS;
-   if (g->work) {
-      ISPLIB_HIP_TRY(hipStreamSynchronize(st));          // an earlier call may still be reading the old one
-      (void)hipFree(g->work);
-      g->work = nullptr; g->work_bytes = 0;
+static int ensure_work(isplib_graph *g, size_t bytes, hipStream_t st, isplib_graph::Work **out) {
+   isplib_graph::Work &w = g->works[st];
+   *out = &w;
+   if (w.bytes >= bytes) return ISPLIB_SUCCESS;
+   if (w.ptr) {
+      ISPLIB_HIP_TRY(hipStreamSynchronize(st));          // an earlier call on this stream may still be reading the old one
+      (void)hipFree(w.ptr);
+      w.ptr = nullptr; w.bytes = 0;
    }
-   TRY_ALLOC(g->work, bytes);
-   g->work_bytes = bytes;
+   TRY_ALLOC(w.ptr, bytes);
+   w.bytes = bytes;
    return ISPLIB_SUCCESS;
 }
 
@@ -259,11 +261,12 @@ static int run_side(isplib_graph *g, Side &s, const float *val, int32_t imessage
       const Plan &p = it->second;
       if (p.usable) {
          const size_t need = isplib_spmm_tasks_workspace_bytes(imessage, p.n_tasks, k);
-         const int rc = ensure_work(g, need, st);
+         isplib_graph::Work *w = nullptr;
+         const int rc = ensure_work(g, need, st, &w);
          if (rc) return rc;
          return fusedMM_csr_tasks_hip(imessage, s.m, s.n, k, s.nnz, val, s.col, s.col32, s.rowptr, s.rowptr + 1, p.n_tasks,
                                       p.task_row, p.task_b, p.task_len, p.seg_off, slices, p.lane_off, y, ldy, z, ldz, z_arg,
-                                      g->work, g->work_bytes, st);
+                                      w->ptr, w->bytes, st);
       }
    }
    return fusedMM_csr_hip(imessage, s.m, s.n, k, 1.0f, s.nnz, s.m, s.n, val, s.col, s.rowptr, s.rowptr + 1, nullptr, k, y, ldy,
