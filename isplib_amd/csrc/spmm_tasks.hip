@@ -71,11 +71,12 @@ __global__ __launch_bounds__(WAVES * 64, (min_waves_of<OP, LPR, NCH, ADDR>())) v
       vfirst[j] = 0;
       if (cok[j] && ccol[j] + 4 > (int)a.k) { vfirst[j] = ccol[j] + 4 - (int)a.k; ccol[j] = (int)a.k - 4; }
    }
-   // PIPE (every variant of 64 columns and more except weighted max/min): software pipeline over the wave's tasks.
-   // While task t gathers, the edge metadata of task t+1 is already on its way (vector load) and the task record of
-   // t+2 too (scalar loads), so a task no longer starts with two dependent round trips to memory (K=128 sum:
-   // 3.39 -> 3.25 ms with two tasks per wave; max 4.13 -> 4.00 ms at 6 gathers in flight).  The others keep the plain
-   // loop: the two extra live values spill there (weighted max 4.5 -> 5.5 ms, K=32 0.96 -> 1.09 ms when tried).
+   // PIPE (pipelined_tasks(), gather.h: panels of 64 columns and more except weighted max/min, plus the unit-weight
+   // sum at 32 columns and fewer): software pipeline over the wave's tasks.  While task t gathers, the edge metadata of
+   // task t+1 is already on its way (vector load) and the task record of t+2 too (scalar loads), so a task no longer
+   // starts with two dependent round trips to memory (K=128 sum: 3.39 -> 3.25 ms with two tasks per wave; max
+   // 4.13 -> 4.00 ms and K=32 sum 0.96 -> 0.92 ms at 6 gathers in flight).  The others keep the plain loop: the two
+   // extra live values spill there (weighted max 4.5 -> 5.5 ms when tried).
    constexpr bool PIPE = pipelined_tasks<OP, LPR, NCH, ADDR>();
    const unsigned ldyb_pre = (unsigned)a.ldy * 4u;
    int64_t b_n = 0, e_n = 0, b_nn = 0, e_nn = 0;
