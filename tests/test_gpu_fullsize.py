@@ -29,16 +29,27 @@ def reddit(gpu):
 def reddit_plan(reddit):
     from isplib_amd.plan import build_task_plan
     rowptr, col, n, _ = reddit
-    plan = build_task_plan(rowptr, col, n, 16)            # the default schedule of bench.py / the plug-in
+    plan = build_task_plan(rowptr, col, n, 16)            # a whole-row plan: K=128 runs in ONE pass over 16 slices
     assert plan is not None and int(plan.task_len.sum()) == col.numel() and int(plan.task_len.max()) <= 1024
     return plan
+
+
+@pytest.fixture(scope="module")
+def reddit_plan_default(reddit):
+    """The default schedule of bench.py / the plug-in at K >= 96: 8 slices, 64-column panels, pipelined task loop."""
+    from isplib_amd import cabi
+    from isplib_amd.plan import build_task_plan
+    rowptr, col, n, _ = reddit
+    s = cabi.lib().isplib_suggest_slices(n, n, col.numel(), 128, 0)
+    assert s == 8
+    return build_task_plan(rowptr, col, n, s)
 
 
 def _host(*ts):
     return [t.cpu().numpy() for t in ts]
 
 
-def test_config2_reddit_sum_k128_against_oracle(gpu, reddit, reddit_plan, oracle_mod):
+def test_config2_reddit_sum_k128_against_oracle(gpu, reddit, reddit_plan, reddit_plan_default, oracle_mod):
     from isplib_amd import cabi, synth
     rowptr, col, n, table = reddit
     k = 128
@@ -50,18 +61,21 @@ def test_config2_reddit_sum_k128_against_oracle(gpu, reddit, reddit_plan, oracle
     tasks, _ = cabi.spmm_tasks(rowptr, col, None, reddit_plan, x, "sum")
     again, _ = cabi.spmm_tasks(rowptr, col, None, reddit_plan, x, "sum")
     assert torch.equal(tasks, again), "task schedule must be bitwise reproducible"
+    panels, _ = cabi.spmm_tasks(rowptr, col, None, reddit_plan_default, x, "sum")          # the headline schedule
+    again, _ = cabi.spmm_tasks(rowptr, col, None, reddit_plan_default, x, "sum")
+    assert torch.equal(panels, again), "panelled task schedule must be bitwise reproducible"
     rp, cl, xx = _host(rowptr, col, x)
     ones = np.ones(cl.size, np.float32)
     ref, _ = oracle_mod.spmm_fw(rp, cl, ones, xx, "sum")
     mag, _ = oracle_mod.spmm_fw(rp, cl, ones, np.abs(xx), "sum")
-    for name, got in (("plain", plain), ("sliced", sliced), ("tasks", tasks)):
+    for name, got in (("plain", plain), ("sliced", sliced), ("tasks", tasks), ("tasks, 2 x 64 columns", panels)):
         err = np.abs(got.cpu().numpy() - ref)
         assert np.all(err <= 1e-5 * mag + 1e-30), f"{name}: max err/bound {np.max(err / (1e-5 * mag + 1e-30)):.3f}"
     # checksum of checksums in fp64: sum_i out[i,:] == sum_j deg[j] * x[j,:]  (unit weights, symmetric graph)
     deg = (rowptr[1:] - rowptr[:-1]).double()
     expect = (deg[:, None] * x.double()).sum(0)
     slack = 1e-8 * (deg[:, None] * x.double().abs()).sum(0)      # fp32 rounding of 233K row sums, random sign
-    for got in (plain, sliced, tasks):
+    for got in (plain, sliced, tasks, panels):
         assert bool(((got.double().sum(0) - expect).abs() <= slack).all())
     # linearity: A(x + 2y) == Ax + 2Ay within fp32 rounding of the sums
     y = synth.features(n, k, seed=11, device=gpu)
@@ -143,3 +157,16 @@ def test_config4_products_k256_row_partition_equivalence(gpu):
         assert abs(part.nnz - col.numel() / world) < 0.02 * col.numel() / world + 20000, "nnz balance"
         del part, out
     assert nnz_seen == col.numel()
+
+
+def test_config2_max_k128_default_schedule_bit_exact(gpu, reddit, reddit_plan_default, oracle_mod):
+    """max (+arg) at K=128 through the default schedule (two 64-column panels, 8 slices, pipelined task loop),
+    integer-valued X so that ties are everywhere: values and arg indices bit for bit at full size."""
+    from isplib_amd import cabi, synth
+    rowptr, col, n, _ = reddit
+    x = synth.features(n, 128, device=gpu, integer=True)
+    out, arg = cabi.spmm_tasks(rowptr, col, None, reddit_plan_default, x, "max")
+    rp, cl, xx = _host(rowptr, col, x)
+    ref, ref_arg = oracle_mod.spmm_fw(rp, cl, np.ones(cl.size, np.float32), xx, "max")
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    assert np.array_equal(arg.cpu().numpy(), ref_arg)
