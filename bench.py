@@ -74,7 +74,21 @@ def cpu_baseline(rowptr, col, x, nnz):
         times.append(time.perf_counter() - t0)
         budget -= times[-1]
     t = statistics.median(times) if len(times) > 1 else times[0]
-    return {"value": nnz / t, "unit": "edges/s", "cores": oracle.num_threads(), "kind": "port",
+    # context only: torch.sparse.mm on a CSR tensor on the same host cores
+    torch_ms = None
+    try:
+        csr = torch.sparse_csr_tensor(torch.from_numpy(rp), torch.from_numpy(cl), torch.from_numpy(val), size=(rp.size - 1, xx.shape[0]))
+        xt = torch.from_numpy(xx)
+        torch.sparse.mm(csr, xt)
+        tt = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            torch.sparse.mm(csr, xt)
+            tt.append(time.perf_counter() - t0)
+        torch_ms = min(tt) * 1e3
+    except Exception:  # noqa: BLE001 - context figure only
+        pass
+    return {"value": nnz / t, "unit": "edges/s", "cores": oracle.num_threads(), "kind": "port", "torch_sparse_mm_ms": torch_ms,
             "sample": f"whole workload, {len(times)} pass(es), median {t * 1e3:.1f} ms/pass; "
                       "oracle/fusedmm_oracle.c (restated FusedMM-semantics kernel, -O3 -march=native -fopenmp)",
             "ms_per_step": t * 1e3, "host_cpus": os.cpu_count()}
