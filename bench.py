@@ -173,7 +173,8 @@ def main():
     if a.slices < 0 and a.schedule == "sliced":      # the one-pass sliced kernel has no column panels: whole-row rule
         a.slices = int(cabi.lib().isplib_suggest_slices_whole_rows(m_local, x_in.size(0), l_col.numel(), k))
     if a.slices < 0:
-        a.slices = suggest_slices(m_local, x_in.size(0), l_col.numel(), k, a.reduce in ("max", "min"))
+        from isplib_amd.plugin import skew_adjusted
+        a.slices = skew_adjusted(l_rowptr, suggest_slices(m_local, x_in.size(0), l_col.numel(), k, a.reduce in ("max", "min")))
     sliced_slices = a.slices        # slice count of the one-pass column-sliced kernel (differs from the task plan's at N > 1)
     if multi and a.slices > 0:
         # the sliced kernel has no column panels: its own rule (whole rows), rounded to a multiple of world
@@ -423,7 +424,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                 "traffic_source": None if traffic is None else "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, gfx950-corrected)",
                 "kernel": (("spmm_task_kernel + combine_tasks_kernel" + (
-                    "" if x_in.size(0) * k * 4 / max(a.slices, 1) <= 10752 * 1024 else      # whole-row plan: one pass
+                    "" if x_in.size(0) * k * 4 / max(a.slices, 1) <= 9216 * 1024 else      # whole-row plan: one pass
                     f", {-(-k // 64)} passes of 64 columns per launch" if k >= 96 and k % 32 == 0 else
                     f", {-(-k // 128)} passes of 128 columns per launch" if k >= 192 else "")) if use_tasks else
                            "spmm_csr_kernel" + (f"<sliced x{sliced_slices}> + combine_slices_kernel" if a.slices > 0 else "")),

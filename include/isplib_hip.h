@@ -290,7 +290,7 @@ int    fusedMM_csr_tasks_epilogue_hip(int32_t imessage, int64_t m, int64_t n, in
  *   0  lanes per row slot of the row kernels (0 = by k)      1  0: 64-bit addressing instead of buffer descriptors
  *   2  consecutive tasks per wave of the task kernel (0=auto) 4  column-panel width of the task entries, sum / mean (64)
  *   5  the same for max / min (64)                            8  per-slice footprint of whole rows (KiB) up to which a
- *      returns ISPLIB_FAIL for an unknown key                    task plan runs in one pass (10752; 0 = always panels) */
+ *      returns ISPLIB_FAIL for an unknown key                    task plan runs in one pass (9216; 0 = always panels) */
 int isplib_hip_tune(int key, int value);
 
 /* Warm-up hook with the reference's name; launches one empty kernel. */

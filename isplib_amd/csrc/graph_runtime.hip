@@ -32,6 +32,7 @@ struct Side {                    // A, or A^T, as CSR
    int64_t m = 0, n = 0, nnz = 0;
    const int64_t *rowptr = nullptr, *col = nullptr;
    const float *val = nullptr;
+   double cv2 = -1.0;            // squared coefficient of variation of the row degrees (-1: not measured yet)
    int unit = -1;                // val examined once: 1 = every weight is exactly 1.0f (isplib/__init__.py:51-57
                                  // materialises unit weights as a ones vector) -> the kernels skip the value stream
    int32_t *col32 = nullptr;
@@ -43,6 +44,18 @@ __global__ __launch_bounds__(256) void not_all_ones_kernel(int64_t nnz, const fl
    bool other = false;
    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += stride) other |= val[i] != 1.0f;
    if (other) atomicOr(flag, 1);
+}
+
+// sum of the row degrees' squares (double), for the degree-skew test of the slice rule
+__global__ __launch_bounds__(256) void degree_squares_kernel(int64_t m, const int64_t *__restrict__ rowptr, double *__restrict__ out) {
+   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+   double acc = 0.0;
+   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
+      const double d = (double)(rowptr[i + 1] - rowptr[i]);
+      acc += d * d;
+   }
+   for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+   if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
 }
 
 void free_side(Side &s, bool owns_arrays) {
@@ -223,12 +236,40 @@ static int weights_are_unit(Side &s, hipStream_t st) {
    return s.unit = host ? 0 : 1;
 }
 
+// The rule's 7 MB per slice leans on the popularity skew of real degree distributions (the hot rows of y stay in
+// the L2).  A graph whose degrees hardly vary has no hot rows, and its slices must be closer to the L2 size:
+// CV^2 of the row degrees under 0.25 -> half as many columns per slice again (uniform random graph of the Reddit
+// size, K=128: 4.09 ms with 8 slices, 3.49 ms with 12).  Measured once per side (one small reduction + sync).
+static int skew_adjusted(Side &s, int slices, hipStream_t st) {
+   if (slices <= 0 || s.m <= 0 || s.nnz <= 0) return slices;
+   if (s.cv2 < 0.0) {
+      double *acc = nullptr, host = 0.0;
+      if (hipMalloc((void **)&acc, 256) != hipSuccess) { (void)hipGetLastError(); return slices; }
+      bool ok = hipMemsetAsync(acc, 0, sizeof(double), st) == hipSuccess;
+      if (ok) {
+         const int64_t blocks = (s.m + 255) / 256;
+         hipLaunchKernelGGL(degree_squares_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, s.m, s.rowptr, acc);
+         ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(&host, acc, sizeof(double), hipMemcpyDeviceToHost, st) == hipSuccess &&
+              hipStreamSynchronize(st) == hipSuccess;
+      }
+      (void)hipFree(acc);
+      if (!ok) { (void)hipGetLastError(); return slices; }
+      const double mean = (double)s.nnz / (double)s.m;
+      s.cv2 = host / (double)s.m / (mean * mean) - 1.0;
+      if (s.cv2 < 0.0) s.cv2 = 0.0;
+   }
+   if (s.cv2 >= 0.25) return slices;
+   const int more = (int)(1.5 * slices + 0.5);
+   return more > 64 ? 64 : more;
+}
+
 static int run_side(isplib_graph *g, Side &s, const float *val, int32_t imessage, int64_t k, const float *y, int64_t ldy,
                     float *z, int64_t ldz, int64_t *z_arg, hipStream_t st) {
    if (val && val == s.val && weights_are_unit(s, st) == 1) val = nullptr;
    const int minmax = (imessage & 0xF0000) != ISPLIB_AOP_ADD;
    int slices = g->forced_slices >= 0 ? g->forced_slices : isplib_suggest_slices(s.m, s.n, s.nnz, k, minmax);
    if (k < 4 || (double)s.n * (double)ldy * 4.0 > 3.5 * 1073741824.0) slices = 0;      // outside the task entry's domain
+   if (g->forced_slices < 0) slices = skew_adjusted(s, slices, st);
    if (slices > 0 && g->forced_slices < 0) {
       // The panel rule halves the slice count to make tasks long enough.  If they are long anyway (hub-dominated
       // graphs: >= 120 edges per task on the panel plan), the whole-row plan with one pass is the better schedule.

@@ -372,7 +372,7 @@ static int launch_addr(const SpmmArgs &a0, hipStream_t st) {
 int g_force_lpr = 0;   // tuning knob (isplib_hip_tune): lanes per row slot, 0 = by K
 int g_addr_mode = 1;   // tuning knob: 0 = always 64-bit addressing, 1 = buffer descriptors when they fit
 int g_tasks_per_wave = 0;   // tuning knob: consecutive tasks handled by one wave of the task kernel (0 = 2 for the pipelined variants, else 1)
-int g_one_pass_kib = 10752;     // per-slice footprint of whole rows (KiB) up to which a plan runs in one pass (isplib_hip_tune(8, kib))
+int g_one_pass_kib = 9216;     // per-slice footprint of whole rows (KiB) up to which a plan runs in one pass (isplib_hip_tune(8, kib))
 int g_panel_cols_minmax = 64;   // the same for max / min (isplib_hip_tune(5, w))
 int g_panel_cols = 64;      // column-panel width of the task schedule for wide K (isplib_hip_tune(4, w); 0 = one pass)
 

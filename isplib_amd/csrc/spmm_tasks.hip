@@ -335,7 +335,7 @@ static int tasks_entry(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_
    int panel = aop == ISPLIB_AOP_ADD ? g_panel_cols : g_panel_cols_minmax;
    if ((ldy % 32) != 0 && panel > 0 && panel < 128) panel = 128;
    // The slice count says which schedule the plan was made for: when a slice of WHOLE rows of y already fits the L2
-   // budget (<= 1.5 x 7 MB), panels would only shorten the gathers and read the index stream again -- one pass.
+   // budget (<= 9 MB), panels would only shorten the gathers and read the index stream again -- one pass.
    // (The callers pick such a plan when tasks stay long with twice the slices, e.g. hub-dominated R-MAT graphs:
    // 3.43 ms in one pass over 16 slices, 3.67 ms in two passes over 8.)
    if ((double)n * (double)k * 4.0 / (double)slices <= (double)g_one_pass_kib * 1024.0) panel = 0;

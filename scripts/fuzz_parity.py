@@ -54,7 +54,7 @@ def main():
         slices = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 24]))
         chunk = int(rng.choice([64, 100, 512, 1024]))
         short = int(rng.choice([0, 8, 128, 10 ** 6]))
-        cabi.lib().isplib_hip_tune(8, int(rng.choice([0, 10752])))       # column panels forced on half of the cases
+        cabi.lib().isplib_hip_tune(8, int(rng.choice([0, 9216])))       # column panels forced on half of the cases
         plan = build_task_plan(d_rowptr, d_col, n, slices, chunk, short) if k >= 4 else None
         table = cabi.spmm_slices(d_rowptr, d_col, n, slices)[0]
         row_ids = np.repeat(np.arange(m), np.diff(rowptr))

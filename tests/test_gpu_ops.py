@@ -425,7 +425,7 @@ def test_task_epilogue_entry_point(gpu, oracle_mod):
     x = cases.dense(260, 300, 3)                      # 300 columns: three 128-column panels
     self_term, rs, bias = cases.dense(200, 300, 4), cases.dense(200, 1, 5)[:, 0].copy(), cases.dense(1, 300, 6)[0]
     plan = build_task_plan(_t(rowptr, gpu), _t(col, gpu), 260, 8, 64, 16)
-    for one_pass_kib in (0, 10752):               # 0: forced through the column panels (a graph this small would not use them)
+    for one_pass_kib in (0, 9216):               # 0: forced through the column panels (a graph this small would not use them)
         cabi.lib().isplib_hip_tune(8, one_pass_kib)
         for red in ("sum", "mean"):
             got = cabi.spmm_tasks_epilogue(_t(rowptr, gpu), _t(col, gpu), None, plan, _t(x, gpu), red, _t(rs, gpu),

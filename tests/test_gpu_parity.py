@@ -277,7 +277,7 @@ def test_task_list_schedule(gpu, oracle_mod, k):
     tol = cases.sum_tolerance(oracle_mod, rowptr, col, val, x)
     for slices, chunk, short in ((8, 512, 256), (16, 64, 16), (8, 100, 0), (24, 512, 10 ** 9), (1, 128, 64), (3, 256, 0), (13, 512, 128)):
         # small operands would always run in one pass: every other plan is forced through the column-panel path
-        cabi.lib().isplib_hip_tune(8, 0 if slices in (8, 3, 13) else 10752)
+        cabi.lib().isplib_hip_tune(8, 0 if slices in (8, 3, 13) else 9216)
         plan = build_task_plan(d_rowptr, d_col, 900, slices, chunk, short)
         assert plan is not None and plan.lane_off[0] == 0 and plan.lane_off[8] == plan.n_tasks
         assert int(plan.task_len.sum()) == col.size and int(plan.task_len.max()) <= chunk
@@ -292,4 +292,4 @@ def test_task_list_schedule(gpu, oracle_mod, k):
                 else:
                     assert np.array_equal(out.cpu().numpy().view(np.uint32), ref.view(np.uint32)), (red, slices)
                     assert np.array_equal(arg.cpu().numpy(), ref_arg), (red, slices)
-    cabi.lib().isplib_hip_tune(8, 10752)
+    cabi.lib().isplib_hip_tune(8, 9216)
