@@ -349,3 +349,13 @@ def test_slice_rule_lives_in_the_c_abi_and_handle_entries_validate():
     assert L.isplib_graph_create(4, 1 << 31, 0, ctypes.c_void_p(8), None, None, ctypes.byref(out)) == cabi.FAIL
     assert L.isplib_graph_create(-1, 4, 0, ctypes.c_void_p(8), None, None, ctypes.byref(out)) == cabi.FAIL
     L.isplib_graph_destroy(None)                                   # a no-op, like free(NULL)
+
+
+def test_degree_skew_adjustment_of_the_slice_rule():
+    from isplib_amd import plugin
+    flat = torch.arange(0, 101 * 50, 50, dtype=torch.int64)                       # every row has 50 entries
+    assert plugin.degree_cv2(flat) == 0.0 and plugin.skew_adjusted(flat, 8) == 12 and plugin.skew_adjusted(flat, 0) == 0
+    deg = torch.tensor([1] * 90 + [500] * 10, dtype=torch.int64)                   # a few hubs: strongly skewed
+    skewed = torch.cat([torch.zeros(1, dtype=torch.int64), deg.cumsum(0)])
+    assert plugin.degree_cv2(skewed) > 2.0 and plugin.skew_adjusted(skewed, 8) == 8
+    assert plugin.skew_adjusted(flat, 60) == 64                                     # capped like the rule itself
