@@ -94,13 +94,56 @@ def cpu_baseline(rowptr, col, x, nnz):
             "ms_per_step": t * 1e3, "host_cpus": os.cpu_count()}
 
 
+def launcher_command(gpus: int, argv, port: int):
+    """The command `python bench.py --gpus N ...` turns into when no launcher set WORLD_SIZE: one fresh process per
+    GPU under torch.distributed.run, rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(a, argv) -> int:
+    """`--gpus N` with N > 1 and no WORLD_SIZE: this process becomes the launcher.  It must not touch the GPU (a
+    process that has initialised HIP may neither fork ranks nor be replaced): it only counts devices, starts the
+    ranks as children, relays rank 0's JSON line and returns non-zero if any child failed."""
+    import socket
+    import subprocess
+    backend = os.environ.get("ISPLIB_BENCH_BACKEND", "nccl")
+    have = torch.cuda.device_count()             # counting devices does not initialise the GPU
+    if backend == "nccl" and have < a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but only {have} GPU(s) visible: refusing to print a number for fewer ranks "
+              "(ISPLIB_BENCH_BACKEND=gloo rehearses N ranks on one GPU, labelled as a rehearsal)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = launcher_command(a.gpus, argv, port)
+    print("[bench] launching: " + " ".join(cmd), file=sys.stderr)
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        print(f"bench.py: the {a.gpus}-rank run failed (exit {proc.returncode}, JSON line {'present' if line else 'missing'})", file=sys.stderr)
+        return proc.returncode or 3
+    if json.loads(line).get("n_gpus") != a.gpus:
+        print(f"bench.py: the ranks reported n_gpus={json.loads(line).get('n_gpus')}, expected {a.gpus}", file=sys.stderr)
+        return 4
+    print(line, flush=True)
+    return 0
+
+
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        raise SystemExit(self_launch(a, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or drop WORLD_SIZE and let bench.py start them)")
     # ISPLIB_BENCH_FORCE_DIST=1 under `torch.distributed.run --nproc-per-node 1` walks the N > 1 code (RCCL init,
     # partition, async all-gather, overlapped schedule) with a single rank: a rehearsal of the API calls on a
     # 1-GPU box, labelled as such in the output line.
@@ -121,6 +164,9 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        if rank == 0:
+            print(f"[bench] process group up: backend={dist.get_backend()} world_size={dist.get_world_size()} "
+                  f"(RCCL ranks: {dist.get_world_size() if backend == 'nccl' else 0})", file=sys.stderr)
 
     from isplib_amd import cabi, synth
     k = a.k or {"reddit": 128, "cora": 16, "products": 256}[a.workload]

@@ -286,11 +286,55 @@ int    fusedMM_csr_tasks_epilogue_hip(int32_t imessage, int64_t m, int64_t n, in
                                       const isplib_epilogue *epilogue /*host, may be NULL*/,
                                       void *stream);
 
+/*
+ * Sweep schedule: the same SpMM with the running rows kept in LDS instead of per-task partial rows in HBM.
+ * A launch ("generation") holds only waves that are resident together; every wave owns up to rows_per_wave
+ * (virtual) rows, whose sums live in LDS, and walks the column slices 0, 1, 2, ... of those rows; equal edge
+ * mass per wave keeps all waves of the chip on the same one or two slices at any moment, so a slice can be as
+ * small as an XCD's L2 without the partial-row traffic that short tasks cost the task-list schedule.  z is written
+ * once, there is no fold kernel; rows longer than the plan's chunk are cut into virtual rows owned by different
+ * waves, and only their partial rows (n_parts of them) pass through the workspace.  No atomics: a row's tasks are
+ * folded by one wave in ascending CSR order, results are bitwise reproducible and max/min ties go to the lowest
+ * CSR position.  Requires column-sorted rows, k % 4 == 0, ldy % 4 == 0, ldz % 4 == 0, y and z 16-byte aligned,
+ * n*ldy*4 <= 3.5 GiB (otherwise use fusedMM_csr_tasks_hip / fusedMM_csr_hip).
+ *   plan (host struct, device arrays; isplib_amd/plan.py builds it on the device):
+ *     wave w of generation g = global wave g*waves_per_gen + w;
+ *     wave_row [wave][slot]  row of the slot, -1 = unused      wave_part[wave][slot]  -1 = whole row, else partial row id
+ *     tasks of a wave: [wave_task_off[wave], wave_task_off[wave+1]), sorted by (slice, slot);
+ *     task_b first CSR position, task_meta = (slot << 24) | edges (edges < 2^24)
+ *     hub_row[h] = a row cut into chunks; its partial rows are [hub_off[h], hub_off[h+1]), in CSR order.
+ *   isplib_spmm_sweep_resident_waves: waves of this kernel family the device holds at once at width k -- what
+ *     waves_per_gen should not exceed (a larger generation is still correct, only slower).
+ *   epilogue: as fusedMM_csr_tasks_epilogue_hip (sum / mean only), may be NULL.
+ */
+typedef struct isplib_sweep_plan {
+   int64_t rows;                    /* m of the graph the plan was built for */
+   int32_t slices, gens, waves_per_gen, rows_per_wave /* 8, 16 or 32 (max / min: <= 16) */;
+   int64_t n_tasks, n_parts, n_hub;
+   const int32_t *wave_row;         /* [dev] gens*waves_per_gen*rows_per_wave */
+   const int32_t *wave_part;        /* [dev] same shape */
+   const int64_t *wave_task_off;    /* [dev] gens*waves_per_gen + 1 */
+   const int64_t *task_b;           /* [dev] n_tasks */
+   const int32_t *task_meta;        /* [dev] n_tasks */
+   const int32_t *hub_row;          /* [dev] n_hub */
+   const int32_t *hub_off;          /* [dev] n_hub + 1 */
+} isplib_sweep_plan;
+int    isplib_spmm_sweep_resident_waves(int32_t imessage, int64_t k, int rows_per_wave);
+size_t isplib_spmm_sweep_workspace_bytes(int32_t imessage, const isplib_sweep_plan *plan, int64_t k);
+int    fusedMM_csr_sweep_hip(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t nnz,
+                             const float *val, const int64_t *indx, const int32_t *indx32 /*optional*/,
+                             const int64_t *pntrb, const int64_t *pntre,
+                             const isplib_sweep_plan *plan /*host*/,
+                             const float *y, int64_t ldy, float *z, int64_t ldz, int64_t *z_arg,
+                             void *workspace, size_t workspace_bytes,
+                             const isplib_epilogue *epilogue /*host, may be NULL*/, void *stream);
+
 /* Tuning knobs for experiments (process-wide, not thread-safe; every setting gives the same results):
  *   0  lanes per row slot of the row kernels (0 = by k)      1  0: 64-bit addressing instead of buffer descriptors
  *   2  consecutive tasks per wave of the task kernel (0=auto) 4  column-panel width of the task entries, sum / mean (64)
  *   5  the same for max / min (64)                            8  per-slice footprint of whole rows (KiB) up to which a
- *      returns ISPLIB_FAIL for an unknown key                    task plan runs in one pass (9216; 0 = always panels) */
+ *      returns ISPLIB_FAIL for an unknown key                    task plan runs in one pass (9216; 0 = always panels)
+ *   9  column-panel width of the sweep schedule: 32, 64 (default) or 128 */
 int isplib_hip_tune(int key, int value);
 
 /* Warm-up hook with the reference's name; launches one empty kernel. */

@@ -51,6 +51,7 @@ EXPORTS = (
     "isplib_sddmm_csr_tasks_hip", "fusedMM_csr_tasks_epilogue_hip", "fusedMM_csr_udef_hip", "fusedMM_csr_udef_tasks_hip", "isplib_pack_indices_hip",
     "isplib_suggest_slices", "isplib_graph_create", "isplib_graph_set_slices", "isplib_graph_spmm", "isplib_graph_spmm_backward",
     "isplib_graph_destroy", "isplib_suggest_slices_whole_rows", "isplib_graph_sddmm",
+    "fusedMM_csr_sweep_hip", "isplib_spmm_sweep_workspace_bytes", "isplib_spmm_sweep_resident_waves",
 )
 
 _i64, _f32, _vp, _i32 = ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_int32
@@ -64,6 +65,16 @@ class Epilogue(ctypes.Structure):          # isplib_epilogue
 class TaskPlanInfo(ctypes.Structure):      # isplib_task_plan_info
     _fields_ = [("n_tasks", ctypes.c_int64), ("lane_off", ctypes.c_int64 * 9), ("slices", ctypes.c_int32),
                 ("chunk", ctypes.c_int32), ("short_row", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class SweepPlanStruct(ctypes.Structure):   # isplib_sweep_plan
+    _fields_ = [("rows", ctypes.c_int64), ("slices", ctypes.c_int32), ("gens", ctypes.c_int32),
+                ("waves_per_gen", ctypes.c_int32), ("rows_per_wave", ctypes.c_int32), ("n_tasks", ctypes.c_int64),
+                ("n_parts", ctypes.c_int64), ("n_hub", ctypes.c_int64), ("wave_row", ctypes.c_void_p),
+                ("wave_part", ctypes.c_void_p), ("wave_task_off", ctypes.c_void_p), ("task_b", ctypes.c_void_p),
+                ("task_meta", ctypes.c_void_p), ("hub_row", ctypes.c_void_p), ("hub_off", ctypes.c_void_p)]
+
+
 _sigs_set = False
 
 
@@ -148,6 +159,13 @@ def lib() -> ctypes.CDLL:
         L.isplib_graph_destroy.argtypes = [_vp]
         L.isplib_hip_tune.restype = ctypes.c_int
         L.isplib_hip_tune.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.isplib_spmm_sweep_resident_waves.restype = ctypes.c_int
+        L.isplib_spmm_sweep_resident_waves.argtypes = [_i32, _i64, ctypes.c_int]
+        L.isplib_spmm_sweep_workspace_bytes.restype = ctypes.c_size_t
+        L.isplib_spmm_sweep_workspace_bytes.argtypes = [_i32, ctypes.POINTER(SweepPlanStruct), _i64]
+        L.fusedMM_csr_sweep_hip.restype = ctypes.c_int
+        L.fusedMM_csr_sweep_hip.argtypes = [_i32, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(SweepPlanStruct),
+                                            _vp, _i64, _vp, _i64, _vp, _vp, ctypes.c_size_t, ctypes.POINTER(Epilogue), _vp]
         _sigs_set = True
     return L
 
@@ -477,6 +495,49 @@ def spmm_tasks_epilogue(rowptr, col, val, plan, y, reduce="sum", row_scale=None,
                                                   k, _ptr(work), work.numel(), ctypes.byref(ep), _stream(y.device))
     _check(st, "fusedMM_csr_tasks_epilogue_hip")
     return out
+
+
+def fusedMM_csr_sweep_hip(imessage: int, rowptr, col, val, plan, y, z, z_arg, workspace=None, epilogue=None, check: bool = True) -> int:
+    """Raw boundary call of the sweep-schedule SpMM; ``plan`` is an isplib_amd.plan.SweepPlan."""
+    assert y.is_cuda and y.dtype == torch.float32 and y.dim() == 2 and y.stride(1) == 1
+    m, n, k = rowptr.numel() - 1, y.size(0), y.size(1)
+    rp = rowptr.data_ptr()
+    ps = plan.struct()
+    with torch.cuda.device(y.device):
+        st = lib().fusedMM_csr_sweep_hip(int(imessage), m, n, k, col.numel(), _ptr(val), _ptr(col), _plan_col32(plan, col),
+                                         ctypes.c_void_p(rp), ctypes.c_void_p(rp + 8), ctypes.byref(ps), _ptr(y),
+                                         y.stride(0) if n > 1 else max(k, y.stride(0)), _ptr(z),
+                                         z.stride(0) if m > 1 else max(k, z.stride(0)), _ptr(z_arg), _ptr(workspace),
+                                         0 if workspace is None else workspace.numel(),
+                                         None if epilogue is None else ctypes.byref(epilogue), _stream(y.device))
+    if check:
+        _check(st, "fusedMM_csr_sweep_hip")
+    return st
+
+
+def spmm_sweep(rowptr, col, val, plan, y, reduce: str = "sum", workspace=None, row_scale=None, self_term=None, bias=None,
+               relu=False):
+    """Allocate outputs (+ workspace) and call the sweep boundary; returns (out, arg|None)."""
+    rowptr = _dev(rowptr, "rowptr", torch.int64)
+    col = _dev(col, "col", torch.int64)
+    if val is not None:
+        val = _dev(val, "val", torch.float32)
+    y = y.contiguous()
+    m, k = rowptr.numel() - 1, y.size(1)
+    out = torch.empty((m, k), dtype=torch.float32, device=y.device)
+    arg = torch.empty((m, k), dtype=torch.int64, device=y.device) if reduce in ("max", "min") else None
+    if workspace is None:
+        workspace = plan.workspace(reduce, k)
+    ep = None
+    if row_scale is not None or self_term is not None or bias is not None or relu:
+        ep = Epilogue(None if row_scale is None else row_scale.data_ptr(), None if self_term is None else self_term.data_ptr(),
+                      k if self_term is None else self_term.stride(0), None if bias is None else bias.data_ptr(), int(bool(relu)))
+    fusedMM_csr_sweep_hip(MESSAGE[reduce], rowptr, col, val, plan, y, out, arg, workspace, ep)
+    return out, arg
+
+
+def sweep_resident_waves(reduce: str, k: int, rows_per_wave: int = 16) -> int:
+    return int(lib().isplib_spmm_sweep_resident_waves(MESSAGE[reduce], int(k), int(rows_per_wave)))
 
 
 class GraphHandle:

@@ -514,6 +514,7 @@ extern "C" int isplib_hip_tune(int key, int value) {
    if (key == 4) { g_panel_cols = value; return ISPLIB_SUCCESS; }
    if (key == 5) { g_panel_cols_minmax = value; return ISPLIB_SUCCESS; }
    if (key == 8 && value >= 0) { g_one_pass_kib = value; return ISPLIB_SUCCESS; }
+   if (key == 9 && (value == 32 || value == 64 || value == 128)) { g_sweep_panel = value; return ISPLIB_SUCCESS; }
    return ISPLIB_FAIL;
 }
 

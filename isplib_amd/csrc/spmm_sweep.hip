@@ -1,0 +1,404 @@
+// spmm_sweep.hip -- the row-resident "sweep" schedule of the SpMM (fusedMM_csr_sweep_hip): see include/isplib_hip.h
+// and DESIGN.md 4.2.  Shares the gather loop (gather.h) with the other schedules.
+//
+// The task-list schedule (spmm_tasks.hip) gets its L2 locality from the ORDER in which the hardware hands out
+// workgroups (slice-major task list), and pays for it with one partial row per task, written to HBM and folded by a
+// second kernel.  Here the locality comes from TIME instead: a launch holds only as many waves as are resident at
+// once, every wave owns a fixed set of (virtual) rows whose running sums live in LDS, and all waves walk the column
+// slices 0, 1, 2, ... of their own rows together.  Equal edge mass per wave (plan) keeps them in step, so at any
+// moment an XCD's L2 serves one or two slices -- which can therefore be as small as the L2 -- and nothing but the
+// finished rows ever leaves the CU:
+//   * no partial rows, no fold kernel, z is written once;
+//   * a task is still "the edges of one row inside one slice" and keeps the software-pipelined loop of the task
+//     kernel (metadata of task t+1 and the record of task t+2 in flight while task t gathers);
+//   * a row's tasks are met in ascending CSR order by ONE wave and folded into its LDS row in that order: no atomics,
+//     bitwise reproducible, max/min ties still go to the lowest CSR position;
+//   * rows over `chunk` edges are cut into virtual rows owned by different waves (hub rows would otherwise decide
+//     the length of the launch); their few partial rows go to the workspace and a small kernel folds them.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <float.h>
+#include <limits.h>
+
+#include "../../include/isplib_hip.h"
+#include "common.h"
+#include "gather.h"
+
+namespace isplib {
+
+struct SweepArgs {
+   int64_t k, nnz;
+   const float *val;
+   const int64_t *indx, *pntrb, *pntre;
+   const int32_t *indx32;
+   const float *y;
+   int64_t ldy;
+   unsigned ybytes;
+   float *z;
+   int64_t ldz;
+   int64_t *z_arg;
+   int mean;
+   const int32_t *wave_row;        // [waves][NVMAX] row of the slot, -1 = unused slot
+   const int32_t *wave_part;       // [waves][NVMAX] -1: the slot is a whole row (written to z); else index of its partial row
+   const int64_t *wave_task_off;   // [waves + 1]
+   const int64_t *task_b;          // [n_tasks] first CSR position
+   const int32_t *task_meta;       // [n_tasks] (slot << 24) | edges
+   int wave_base, wave_count;      // waves of this launch (one generation): [wave_base, wave_base + wave_count)
+   float *part_val;                // [n_parts][k]
+   int *part_idx;                  // [n_parts][k] row-relative edge ids (max/min)
+   const int32_t *hub_row, *hub_off;
+   int64_t n_hub;
+   const float *ep_row_scale, *ep_self, *ep_bias;
+   int64_t ep_ld_self;
+   int ep_relu;
+};
+
+// finished value of a whole row: mean scale / epilogue (sum, mean), empty-row value and absolute arg (max, min)
+template <int OP>
+__device__ __forceinline__ void finish_row(const SweepArgs &a, int row, int c, float (&v)[4], int (&bi)[4], int64_t (&arg)[4]) {
+   const int64_t rb = a.pntrb[row];
+   const int64_t deg = a.pntre[row] - rb;
+   if (OP == OP_ADD) {
+      if (a.mean) {
+         const float d = (float)(deg > 1 ? deg : 1);
+#pragma unroll
+         for (int i = 0; i < 4; i++) v[i] = v[i] / d;
+      }
+      if (a.ep_self) {
+         const float *sr = a.ep_self + (size_t)row * (size_t)a.ep_ld_self + c;
+#pragma unroll
+         for (int i = 0; i < 4; i++) v[i] += sr[i];
+      }
+      if (a.ep_row_scale) {
+         const float rs = a.ep_row_scale[row];
+#pragma unroll
+         for (int i = 0; i < 4; i++) v[i] *= rs;
+      }
+      if (a.ep_bias) {
+#pragma unroll
+         for (int i = 0; i < 4; i++) v[i] += a.ep_bias[c + i];
+      }
+      if (a.ep_relu) {
+#pragma unroll
+         for (int i = 0; i < 4; i++) v[i] = v[i] > 0.0f ? v[i] : 0.0f;
+      }
+   } else {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+         if (deg <= 0) v[i] = 0.0f;
+         arg[i] = bi[i] == INT_MAX ? a.nnz : rb + (int64_t)bi[i];
+      }
+   }
+}
+
+// LDS of one workgroup (4 waves x NVMAX rows x one panel row, values and for max / min the ids) and the workgroups
+// a CU holds at once: the launch bound (one wave of each workgroup per SIMD) and the plan's wave count follow from it
+template <int OP, int LPR, int NVMAX> constexpr int sweep_lds_bytes() { return (OP == OP_ADD ? 1 : 2) * 4 * NVMAX * LPR * 4 * 4; }
+template <int OP, int LPR, int NVMAX> constexpr int sweep_wgs_per_cu() {
+   return 163840 / sweep_lds_bytes<OP, LPR, NVMAX>() < 8 ? 163840 / sweep_lds_bytes<OP, LPR, NVMAX>() : 8;
+}
+
+template <int OP, int LPR, int ADDR, int NVMAX>
+__global__ __launch_bounds__(256, (sweep_wgs_per_cu<OP, LPR, NVMAX>())) void spmm_sweep_kernel(const SweepArgs a) {
+   constexpr int VEC = 4, WAVES = 4, G = 64 / LPR, PANEL = LPR * VEC;
+   constexpr int U = unroll_of<OP, 1, ADDR, true, LPR>();
+   constexpr int PLANES = OP == OP_ADD ? 1 : 2;
+   // one array (two objects can cost a drained pipeline: guide 5, item 4a): values, then ids
+   __shared__ __attribute__((aligned(16))) float s_all[PLANES * WAVES * NVMAX * PANEL];
+   const int lane = threadIdx.x & 63;
+   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+   const int g = lane / LPR, lc = lane % LPR;
+   const int wl = (int)blockIdx.x * WAVES + wave;
+   if (wl >= a.wave_count) return;                       // no barrier anywhere below
+   const int64_t w = (int64_t)a.wave_base + wl;
+   float *my_val = s_all + wave * (NVMAX * PANEL);
+   int *my_idx = reinterpret_cast<int *>(s_all + WAVES * NVMAX * PANEL) + wave * (NVMAX * PANEL);
+#pragma unroll
+   for (int i = 0; i < NVMAX * PANEL / 256; i++) {
+      *reinterpret_cast<float4 *>(my_val + (i * 64 + lane) * 4) = make_float4(identity<OP>(), identity<OP>(), identity<OP>(), identity<OP>());
+      if (OP != OP_ADD) *reinterpret_cast<int4 *>(my_idx + (i * 64 + lane) * 4) = make_int4(INT_MAX, INT_MAX, INT_MAX, INT_MAX);
+   }
+   __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.y), 0, (int)a.ybytes, 0x00020000);
+   int ccol[1];
+   bool cok[1];
+   ccol[0] = lc * VEC;
+   cok[0] = ccol[0] < a.k;
+   // max/min: first CSR position of the row of slot `lane` (edge ids are kept relative to the row start)
+   int64_t slot_rb = 0;
+   if (OP != OP_ADD && lane < NVMAX) {
+      const int r = a.wave_row[(size_t)w * NVMAX + lane];
+      slot_rb = r >= 0 ? a.pntrb[r] : 0;
+   }
+   const int64_t t0 = a.wave_task_off[w], t_end = a.wave_task_off[w + 1];
+   const unsigned ldyb = (unsigned)a.ldy * 4u;
+   int64_t b_n = 0, b_nn = 0;
+   int m_n = 0, m_nn = 0;
+   unsigned off_n = 0u;
+   float val_n = 0.0f;
+   if (t0 < t_end) {
+      b_n = a.task_b[t0]; m_n = a.task_meta[t0];
+      load_edge_batch<ADDR == 2>(a, b_n, b_n + (m_n & 0xFFFFFF), ldyb, off_n, val_n);
+      if (t0 + 1 < t_end) { b_nn = a.task_b[t0 + 1]; m_nn = a.task_meta[t0 + 1]; }
+   }
+   for (int64_t t = t0; t < t_end; t++) {
+      const int64_t b = b_n, e = b_n + (m_n & 0xFFFFFF);
+      const int slot = __builtin_amdgcn_readfirstlane(m_n >> 24);
+      const unsigned off_c = off_n;
+      const float val_c = val_n;
+      b_n = b_nn; m_n = m_nn;
+      if (t + 1 < t_end) load_edge_batch<ADDR == 2>(a, b_n, b_n + (m_n & 0xFFFFFF), ldyb, off_n, val_n);
+      if (t + 2 < t_end) { b_nn = a.task_b[t + 2]; m_nn = a.task_meta[t + 2]; }
+      int64_t row_b = b;
+      if (OP != OP_ADD) {
+         const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(slot_rb & 0xffffffffLL), slot);
+         const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((uint64_t)slot_rb >> 32), slot);
+         row_b = (int64_t)(((uint64_t)hi << 32) | lo);
+      }
+      float acc[1][VEC];
+      int bi[1][VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; v++) { acc[0][v] = identity<OP>(); bi[0][v] = INT_MAX; }
+      wave_edges_buf<OP, ADDR == 2, LPR, 1, U, SweepArgs, true>(a, rsrc, row_b, b, e, ccol, cok, acc, bi, off_c, val_c);
+      slot_reduce<OP, VEC, LPR, 1>(acc, bi);
+      if (g == 0) {                                      // fold into the slot's LDS row: this wave is its only writer
+         float4 *pv = reinterpret_cast<float4 *>(my_val + slot * PANEL + lc * VEC);
+         float4 cur = *pv;
+         if (OP == OP_ADD) {
+            cur.x += acc[0][0]; cur.y += acc[0][1]; cur.z += acc[0][2]; cur.w += acc[0][3];
+            *pv = cur;
+         } else {
+            int4 *pi = reinterpret_cast<int4 *>(my_idx + slot * PANEL + lc * VEC);
+            int4 ci = *pi;
+            bool tk;
+            tk = better<OP>(acc[0][0], bi[0][0], cur.x, ci.x); cur.x = tk ? acc[0][0] : cur.x; ci.x = tk ? bi[0][0] : ci.x;
+            tk = better<OP>(acc[0][1], bi[0][1], cur.y, ci.y); cur.y = tk ? acc[0][1] : cur.y; ci.y = tk ? bi[0][1] : ci.y;
+            tk = better<OP>(acc[0][2], bi[0][2], cur.z, ci.z); cur.z = tk ? acc[0][2] : cur.z; ci.z = tk ? bi[0][2] : ci.z;
+            tk = better<OP>(acc[0][3], bi[0][3], cur.w, ci.w); cur.w = tk ? acc[0][3] : cur.w; ci.w = tk ? bi[0][3] : ci.w;
+            *pv = cur;
+            *pi = ci;
+         }
+      }
+   }
+   // write-out: G slots per step, the LPR lanes of a slot hold one row of the panel
+#pragma unroll 1
+   for (int j0 = 0; j0 < NVMAX; j0 += G) {
+      const int j = j0 + g;
+      if (j >= NVMAX) continue;
+      const int row = a.wave_row[(size_t)w * NVMAX + j];
+      if (row < 0 || !cok[0]) continue;
+      const int part = a.wave_part[(size_t)w * NVMAX + j];
+      const float4 t4 = *reinterpret_cast<const float4 *>(my_val + j * PANEL + lc * VEC);
+      float v[4] = {t4.x, t4.y, t4.z, t4.w};
+      int bi[4] = {INT_MAX, INT_MAX, INT_MAX, INT_MAX};
+      if (OP != OP_ADD) {
+         const int4 i4 = *reinterpret_cast<const int4 *>(my_idx + j * PANEL + lc * VEC);
+         bi[0] = i4.x; bi[1] = i4.y; bi[2] = i4.z; bi[3] = i4.w;
+      }
+      const int c = ccol[0];
+      if (part >= 0) {                                   // a chunk of a hub row: folded by sweep_hub_fold_kernel
+         const size_t po = (size_t)part * (size_t)a.k + c;
+         store_vec<4>(a.part_val + po, v);
+         if (OP != OP_ADD) *reinterpret_cast<int4 *>(a.part_idx + po) = make_int4(bi[0], bi[1], bi[2], bi[3]);
+         continue;
+      }
+      int64_t arg[4];
+      finish_row<OP>(a, row, c, v, bi, arg);
+      store_vec<4>(a.z + (size_t)row * (size_t)a.ldz + c, v);
+      if (OP != OP_ADD && a.z_arg) {
+         int64_t *ar = a.z_arg + (size_t)row * (size_t)a.ldz + c;
+#pragma unroll
+         for (int i = 0; i < 4; i++) ar[i] = arg[i];
+      }
+   }
+}
+
+// rows cut into several virtual rows: fold their partial rows in chunk order (= ascending CSR position)
+template <int OP>
+__global__ __launch_bounds__(256) void sweep_hub_fold_kernel(const SweepArgs a) {
+   const int64_t kv = a.k / 4;
+   const int64_t total = a.n_hub * kv;
+   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+      const int64_t h = i / kv;
+      const int c = (int)(i - h * kv) * 4;
+      float v[4];
+      int bi[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) { v[q] = identity<OP>(); bi[q] = INT_MAX; }
+      const int p1 = a.hub_off[h + 1];
+      for (int p = a.hub_off[h]; p < p1; p++) {
+         const size_t po = (size_t)p * (size_t)a.k + c;
+         float t[4];
+         load_vec<4>(a.part_val + po, t);
+#pragma unroll
+         for (int q = 0; q < 4; q++) {
+            if (OP == OP_ADD) {
+               v[q] += t[q];
+            } else {
+               const int oi = a.part_idx[po + q];
+               const bool take = better<OP>(t[q], oi, v[q], bi[q]);
+               v[q] = take ? t[q] : v[q];
+               bi[q] = take ? oi : bi[q];
+            }
+         }
+      }
+      const int row = a.hub_row[h];
+      int64_t arg[4];
+      finish_row<OP>(a, row, c, v, bi, arg);
+      store_vec<4>(a.z + (size_t)row * (size_t)a.ldz + c, v);
+      if (OP != OP_ADD && a.z_arg) {
+         int64_t *ar = a.z_arg + (size_t)row * (size_t)a.ldz + c;
+#pragma unroll
+         for (int q = 0; q < 4; q++) ar[q] = arg[q];
+      }
+   }
+}
+
+template <int OP, int LPR, int ADDR>
+static int launch_sweep_nv(const SweepArgs &a, int nvmax, hipStream_t st) {
+   const unsigned blocks = (unsigned)((a.wave_count + 3) / 4);
+   if (blocks == 0) return ISPLIB_SUCCESS;
+   if (nvmax == 8) hipLaunchKernelGGL((spmm_sweep_kernel<OP, LPR, ADDR, 8>), dim3(blocks), dim3(256), 0, st, a);
+   else if (nvmax == 16) hipLaunchKernelGGL((spmm_sweep_kernel<OP, LPR, ADDR, 16>), dim3(blocks), dim3(256), 0, st, a);
+   else if constexpr (OP == OP_ADD) hipLaunchKernelGGL((spmm_sweep_kernel<OP, LPR, ADDR, 32>), dim3(blocks), dim3(256), 0, st, a);
+   else return fail(ISPLIB_FAIL, "fusedMM_csr_sweep_hip: max / min need rows_per_wave <= 16");
+   return check_launch("spmm_sweep_kernel");
+}
+
+template <int OP, int ADDR>
+static int launch_sweep_op(const SweepArgs &a, int nvmax, hipStream_t st) {
+   const int64_t width = (a.k + 3) / 4;
+   if (width <= 8) return launch_sweep_nv<OP, 8, ADDR>(a, nvmax, st);
+   if (width <= 16) return launch_sweep_nv<OP, 16, ADDR>(a, nvmax, st);
+   if constexpr (OP == OP_ADD) return launch_sweep_nv<OP, 32, ADDR>(a, nvmax, st);
+   return fail(ISPLIB_FAIL, "fusedMM_csr_sweep_hip: max / min panels are at most 64 columns");
+}
+
+// waves of one launch that are resident together (what a plan's waves_per_gen should not exceed)
+static int sweep_resident_waves(bool add, int64_t pk, int nvmax, int cus) {
+   const int lpr = pk <= 32 ? 8 : (pk <= 64 ? 16 : 32);
+   const int lds = (add ? 1 : 2) * 4 * nvmax * lpr * 4 * 4;
+   int wgs = 163840 / lds;
+   if (wgs > 8) wgs = 8;
+   return cus * wgs * 4;
+}
+
+int g_sweep_panel = 64;     // tuning knob (isplib_hip_tune(9, w)): column-panel width of the sweep schedule, 32 / 64 / 128
+
+}  // namespace isplib
+
+using namespace isplib;
+
+extern "C" int isplib_spmm_sweep_resident_waves(int32_t imessage, int64_t k, int rows_per_wave) {
+   clear_error();
+   if (k <= 0 || (rows_per_wave != 8 && rows_per_wave != 16 && rows_per_wave != 32)) return 0;
+   int dev = 0, cus = 0;
+   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+      (void)hipGetLastError();
+      cus = 256;                                          // MI355X
+   }
+   const bool add = (imessage & 0xF0000) == ISPLIB_AOP_ADD;
+   int panel = g_sweep_panel;
+   if (panel != 32 && panel != 64 && panel != 128) panel = 64;
+   if (!add && panel > 64) panel = 64;
+   return sweep_resident_waves(add, k < panel ? k : panel, rows_per_wave, cus);
+}
+
+extern "C" size_t isplib_spmm_sweep_workspace_bytes(int32_t imessage, const isplib_sweep_plan *plan, int64_t k) {
+   if (!plan || plan->n_parts <= 0 || k <= 0) return 256;
+   const int64_t pk = k < 128 ? k : 128;                  // widest panel of a pass
+   const size_t plane = ((size_t)plan->n_parts * (size_t)pk * sizeof(float) + 255) & ~(size_t)255;
+   return plane * (((imessage & 0xF0000) != ISPLIB_AOP_ADD) ? 2 : 1);
+}
+
+extern "C" int fusedMM_csr_sweep_hip(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t nnz, const float *val,
+                                     const int64_t *indx, const int32_t *indx32, const int64_t *pntrb,
+                                     const int64_t *pntre, const isplib_sweep_plan *plan, const float *y, int64_t ldy,
+                                     float *z, int64_t ldz, int64_t *z_arg, void *workspace, size_t workspace_bytes,
+                                     const isplib_epilogue *ep, void *stream) {
+   clear_error();
+   const int32_t vop = imessage & 0xF, rop = imessage & 0xF0, sop = imessage & 0xF00, vsc = imessage & 0xF000,
+                 aop = imessage & 0xF0000;
+   if (vop != ISPLIB_VOP_COPY_RHS || rop != ISPLIB_ROP_NOOP || sop != ISPLIB_SOP_COPY ||
+       (vsc != ISPLIB_VSC_MUL && vsc != ISPLIB_VSC_MEAN) ||
+       (aop != ISPLIB_AOP_ADD && aop != ISPLIB_AOP_MAX && aop != ISPLIB_AOP_MIN) ||
+       (vsc == ISPLIB_VSC_MEAN && aop != ISPLIB_AOP_ADD))
+      return fail(ISPLIB_NO_OPT_IMPL, "fusedMM_csr_sweep_hip: message outside the SpMM set");
+   if (m < 0 || n < 0 || k < 0 || nnz < 0) return fail(ISPLIB_FAIL, "fusedMM_csr_sweep_hip: negative dimension");
+   if (m == 0 || k == 0) return ISPLIB_SUCCESS;
+   if (!plan) return fail(ISPLIB_FAIL, "fusedMM_csr_sweep_hip: plan is required");
+   if (plan->rows != m) return fail(ISPLIB_FAIL, "fusedMM_csr_sweep_hip: the plan was built for another row count");
+   if (plan->gens < 1 || plan->waves_per_gen < 1 || (plan->rows_per_wave != 8 && plan->rows_per_wave != 16 && plan->rows_per_wave != 32))
+      return fail(ISPLIB_FAIL, "fusedMM_csr_sweep_hip: bad plan geometry (rows_per_wave must be 8, 16 or 32)");
+   if (aop != ISPLIB_AOP_ADD && plan->rows_per_wave > 16)
+      return fail(ISPLIB_FAIL, "fusedMM_csr_sweep_hip: max / min need rows_per_wave <= 16 (two LDS planes)");
+   if ((k % 4) != 0 || (ldy % 4) != 0 || (ldz % 4) != 0 || ((uintptr_t)y & 15) != 0 || ((uintptr_t)z & 15) != 0)
+      return fail(ISPLIB_FAIL, "fusedMM_csr_sweep_hip: k, ldy, ldz must be multiples of 4 and y, z 16-byte aligned (use fusedMM_csr_tasks_hip)");
+   if (ldy < k || ldz < k) return fail(ISPLIB_FAIL, "fusedMM_csr_sweep_hip: leading dimension smaller than k");
+   const unsigned long long yb = (unsigned long long)n * (unsigned long long)ldy * 4ull;
+   if (yb > BUF_LIMIT) return fail(ISPLIB_FAIL, "fusedMM_csr_sweep_hip: dense operand larger than 3.5 GiB (use fusedMM_csr_hip)");
+   if (!pntrb || !pntre || !z || !y || (nnz > 0 && !indx) || !plan->wave_row || !plan->wave_part || !plan->wave_task_off ||
+       (plan->n_tasks > 0 && (!plan->task_b || !plan->task_meta)) || (plan->n_hub > 0 && (!plan->hub_row || !plan->hub_off)))
+      return fail(ISPLIB_FAIL, "fusedMM_csr_sweep_hip: null operand");
+   const size_t need = isplib_spmm_sweep_workspace_bytes(imessage, plan, k);
+   if (plan->n_parts > 0) {
+      if (!workspace || workspace_bytes < need) return fail(ISPLIB_NOT_ENOUGH_MEM, "fusedMM_csr_sweep_hip: workspace too small");
+      if (((uintptr_t)workspace & 255) != 0) return fail(ISPLIB_FAIL, "fusedMM_csr_sweep_hip: workspace must be 256-byte aligned");
+   }
+   SweepArgs a;
+   a.k = k; a.nnz = nnz; a.val = val; a.indx = indx; a.indx32 = indx32; a.pntrb = pntrb; a.pntre = pntre;
+   a.y = y; a.ldy = ldy; a.ybytes = (unsigned)yb; a.z = z; a.ldz = ldz; a.z_arg = z_arg;
+   a.mean = (vsc == ISPLIB_VSC_MEAN) ? 1 : 0;
+   a.wave_row = plan->wave_row; a.wave_part = plan->wave_part; a.wave_task_off = plan->wave_task_off;
+   a.task_b = plan->task_b; a.task_meta = plan->task_meta;
+   a.wave_base = 0; a.wave_count = 0;
+   a.hub_row = plan->hub_row; a.hub_off = plan->hub_off; a.n_hub = plan->n_hub;
+   a.ep_row_scale = a.ep_self = a.ep_bias = nullptr; a.ep_ld_self = 0; a.ep_relu = 0;
+   if (ep) {
+      if (aop != ISPLIB_AOP_ADD) return fail(ISPLIB_FAIL, "fusedMM_csr_sweep_hip: the epilogue is defined for sum / mean only");
+      if (ep->self && ep->ld_self < k) return fail(ISPLIB_FAIL, "fusedMM_csr_sweep_hip: ld_self smaller than k");
+      a.ep_row_scale = ep->row_scale; a.ep_self = ep->self; a.ep_ld_self = ep->ld_self; a.ep_bias = ep->bias;
+      a.ep_relu = ep->relu ? 1 : 0;
+   }
+   const int64_t pk_max = k < 128 ? k : 128;
+   const size_t plane = ((size_t)(plan->n_parts > 0 ? plan->n_parts : 0) * (size_t)pk_max * sizeof(float) + 255) & ~(size_t)255;
+   a.part_val = (float *)workspace;
+   a.part_idx = (aop == ISPLIB_AOP_ADD || !workspace) ? nullptr : (int *)((char *)workspace + plane);
+   hipStream_t st = (hipStream_t)stream;
+   // column panels: one complete sweep (every generation, then the hub fold) per panel on the same stream; panels
+   // never change a result.  64 columns = 256-byte gathers, 16 KB of LDS per workgroup at 16 rows per wave.
+   int panel = g_sweep_panel;
+   if (panel != 32 && panel != 64 && panel != 128) panel = 64;
+   if ((ldy % 32) != 0 && panel < 128) panel = 128;       // rows that are not whole cache lines: fewer, wider panels
+   if (aop != ISPLIB_AOP_ADD && panel > 64) panel = 64;   // two LDS planes
+   const int64_t pw = k > panel ? panel : k;
+   for (int64_t c0 = 0; c0 < k; c0 += pw) {
+      SweepArgs p = a;
+      p.k = (k - c0) < pw ? (k - c0) : pw;
+      p.y = y + c0;
+      p.z = z + c0;
+      p.ep_self = a.ep_self ? a.ep_self + c0 : nullptr;
+      p.ep_bias = a.ep_bias ? a.ep_bias + c0 : nullptr;
+      p.z_arg = z_arg ? z_arg + c0 : nullptr;
+      p.ybytes = (unsigned)(yb - (unsigned long long)c0 * 4ull);
+      for (int gen = 0; gen < plan->gens; gen++) {
+         p.wave_base = gen * plan->waves_per_gen;
+         p.wave_count = plan->waves_per_gen;
+         int rc;
+         if (aop == ISPLIB_AOP_ADD) rc = val ? launch_sweep_op<OP_ADD, 2>(p, plan->rows_per_wave, st) : launch_sweep_op<OP_ADD, 1>(p, plan->rows_per_wave, st);
+         else if (aop == ISPLIB_AOP_MAX) rc = val ? launch_sweep_op<OP_MAX, 2>(p, plan->rows_per_wave, st) : launch_sweep_op<OP_MAX, 1>(p, plan->rows_per_wave, st);
+         else rc = val ? launch_sweep_op<OP_MIN, 2>(p, plan->rows_per_wave, st) : launch_sweep_op<OP_MIN, 1>(p, plan->rows_per_wave, st);
+         if (rc) return rc;
+      }
+      if (plan->n_hub > 0) {
+         int64_t blocks = (plan->n_hub * (p.k / 4) + 255) / 256;
+         if (blocks > 4096) blocks = 4096;
+         if (aop == ISPLIB_AOP_ADD) hipLaunchKernelGGL((sweep_hub_fold_kernel<OP_ADD>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+         else if (aop == ISPLIB_AOP_MAX) hipLaunchKernelGGL((sweep_hub_fold_kernel<OP_MAX>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+         else hipLaunchKernelGGL((sweep_hub_fold_kernel<OP_MIN>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+         const int rc = check_launch("sweep_hub_fold_kernel");
+         if (rc) return rc;
+      }
+   }
+   return ISPLIB_SUCCESS;
+}

@@ -80,3 +80,131 @@ def build_task_plan(rowptr: torch.Tensor, col: torch.Tensor, ncols: int, slices:
         col32 = cabi.pack_indices(col)
     return TaskPlan(slices, n_tasks, task_row[:n_tasks], task_b[:n_tasks], task_len[:n_tasks], seg_off,
                     [int(v) for v in info.lane_off], chunk, short_row, col32)
+
+
+@dataclass
+class SweepPlan:
+    """Plan of the sweep schedule (``fusedMM_csr_sweep_hip``, include/isplib_hip.h: isplib_sweep_plan)."""
+    rows: int
+    slices: int
+    gens: int
+    waves_per_gen: int
+    rows_per_wave: int
+    n_tasks: int
+    n_parts: int
+    n_hub: int
+    wave_row: torch.Tensor       # int32 [gens*waves_per_gen*rows_per_wave]
+    wave_part: torch.Tensor      # int32, same shape
+    wave_task_off: torch.Tensor  # int64 [gens*waves_per_gen + 1]
+    task_b: torch.Tensor         # int64 [n_tasks]
+    task_meta: torch.Tensor      # int32 [n_tasks]  (slot << 24) | edges
+    hub_row: torch.Tensor        # int32 [n_hub]
+    hub_off: torch.Tensor        # int32 [n_hub + 1]
+    chunk: int
+    min_seg: int
+    col32: Optional[torch.Tensor] = None
+
+    def struct(self) -> "cabi.SweepPlanStruct":
+        p = lambda t: t.data_ptr() if t is not None and t.numel() else None  # noqa: E731
+        return cabi.SweepPlanStruct(self.rows, self.slices, self.gens, self.waves_per_gen, self.rows_per_wave, self.n_tasks,
+                                    self.n_parts, self.n_hub, p(self.wave_row), p(self.wave_part), p(self.wave_task_off),
+                                    p(self.task_b), p(self.task_meta), p(self.hub_row), p(self.hub_off))
+
+    def workspace(self, reduce: str, k: int) -> torch.Tensor:
+        import ctypes
+        ps = self.struct()
+        nbytes = cabi.lib().isplib_spmm_sweep_workspace_bytes(cabi.MESSAGE[reduce], ctypes.byref(ps), k)
+        return torch.empty(nbytes, dtype=torch.uint8, device=self.wave_row.device)
+
+
+def sweep_plan_arrays(rowptr: torch.Tensor, table: torch.Tensor, slices: int, waves_per_gen: int, rows_per_wave: int = 16,
+                      chunk: int = 2048, min_seg: int = 16) -> dict:
+    """The arrays of a sweep plan from the slice table (``table[i, s]`` = first CSR position of row i with column
+    >= s * ceil(n / slices), ``isplib_spmm_slices_build_hip``); plain torch ops on the table's device.
+
+      * rows over `chunk` edges are cut evenly into virtual rows (so no wave is longer than the others by a hub row);
+      * virtual rows are dealt to the gens*waves_per_gen waves longest first, back and forth: every wave gets the
+        same number of rows (<= rows_per_wave) and, within a fraction of a percent, the same number of edges;
+      * a virtual row of e edges is cut at the boundaries of min(slices, e // min_seg) groups of adjacent column
+        slices (short rows are not shredded into segments of two or three edges); a segment is a task, met by its
+        wave in the phase of its first slice;
+      * a wave's tasks are stored in (slice, slot) order."""
+    assert 1 <= slices <= 4096 and rows_per_wave in (8, 16, 32) and waves_per_gen >= 1 and 1 <= chunk < (1 << 24)
+    m = rowptr.numel() - 1
+    dev = table.device
+    table = table.view(m, slices + 1)
+    i64 = dict(dtype=torch.int64, device=dev)
+    deg = rowptr[1:] - rowptr[:-1]
+    nchunk = ((deg + chunk - 1) // chunk).clamp(min=1)
+    csize = (deg + nchunk - 1) // nchunk
+    nv = int(nchunk.sum())
+    vrow = torch.repeat_interleave(torch.arange(m, **i64), nchunk)
+    first = torch.cumsum(nchunk, 0) - nchunk
+    ci = torch.arange(nv, **i64) - first[vrow]
+    vb = rowptr[vrow] + ci * csize[vrow]
+    ve = torch.minimum(vb + csize[vrow], rowptr[vrow + 1])
+    vb = torch.minimum(vb, ve)
+    vlen = ve - vb
+    # deal the virtual rows to the waves, longest first, boustrophedon
+    gens = max(1, -(-nv // (waves_per_gen * rows_per_wave)))
+    nw = gens * waves_per_gen
+    order = torch.sort(vlen, descending=True, stable=True).indices
+    rank = torch.empty(nv, **i64)
+    rank[order] = torch.arange(nv, **i64)
+    rnd, pos = rank // nw, rank % nw
+    wave = torch.where(rnd % 2 == 0, pos, nw - 1 - pos)
+    slot = rnd
+    is_hub = nchunk[vrow] > 1
+    part = torch.where(is_hub, torch.cumsum(is_hub.to(torch.int64), 0) - 1, torch.full((nv,), -1, **i64))
+    wave_row = torch.full((nw * rows_per_wave,), -1, dtype=torch.int32, device=dev)
+    wave_part = torch.full((nw * rows_per_wave,), -1, dtype=torch.int32, device=dev)
+    at = wave * rows_per_wave + slot
+    wave_row[at] = vrow.to(torch.int32)
+    wave_part[at] = part.to(torch.int32)
+    hub_rows = torch.nonzero(nchunk > 1).flatten()
+    hub_off = torch.zeros(hub_rows.numel() + 1, dtype=torch.int32, device=dev)
+    if hub_rows.numel():
+        hub_off[1:] = torch.cumsum(nchunk[hub_rows], 0).to(torch.int32)
+    # segments: groups of adjacent slices per virtual row
+    s_r = (vlen // max(min_seg, 1)).clamp(min=1, max=slices)                       # groups of this virtual row
+    sl = torch.arange(slices, **i64)
+    grp = (sl[None, :] * s_r[:, None]) // slices                                   # [nv, S] group of slice s
+    is_start = torch.ones((nv, slices), dtype=torch.bool, device=dev)
+    is_start[:, 1:] = grp[:, 1:] != grp[:, :-1]
+    e_slice = ((grp + 1) * slices + s_r[:, None] - 1) // s_r[:, None]              # first slice of the next group
+    tb = table[vrow]                                                               # [nv, S+1]
+    seg_b = torch.minimum(torch.maximum(tb[:, :-1], vb[:, None]), ve[:, None])
+    seg_e = torch.minimum(torch.maximum(torch.gather(tb, 1, e_slice.clamp(max=slices)), vb[:, None]), ve[:, None])
+    seg_len = seg_e - seg_b
+    keep = is_start & (seg_len > 0)
+    del grp, e_slice, tb, is_start
+    vi, si = torch.nonzero(keep, as_tuple=True)
+    t_b, t_len = seg_b[vi, si], seg_len[vi, si]
+    del seg_b, seg_e, seg_len, keep
+    t_wave, t_slot = wave[vi], slot[vi]
+    key = (t_wave * slices + si) * rows_per_wave + t_slot
+    perm = torch.sort(key).indices
+    t_b, t_len, t_wave, t_slot = t_b[perm], t_len[perm], t_wave[perm], t_slot[perm]
+    wave_task_off = torch.zeros(nw + 1, **i64)
+    if t_wave.numel():
+        wave_task_off[1:] = torch.cumsum(torch.bincount(t_wave, minlength=nw), 0)
+    task_meta = ((t_slot << 24) | t_len).to(torch.int32)
+    return dict(rows=m, slices=slices, gens=gens, waves_per_gen=waves_per_gen, rows_per_wave=rows_per_wave,
+                n_tasks=int(t_b.numel()), n_parts=int(is_hub.sum()), n_hub=int(hub_rows.numel()), wave_row=wave_row,
+                wave_part=wave_part, wave_task_off=wave_task_off, task_b=t_b.contiguous(), task_meta=task_meta.contiguous(),
+                hub_row=hub_rows.to(torch.int32), hub_off=hub_off, chunk=chunk, min_seg=min_seg)
+
+
+def build_sweep_plan(rowptr: torch.Tensor, col: torch.Tensor, ncols: int, slices: int, waves_per_gen: int,
+                     rows_per_wave: int = 16, chunk: int = 2048, min_seg: int = 16,
+                     col32: Optional[torch.Tensor] = None) -> Optional[SweepPlan]:
+    """Plan of the sweep schedule, built on the device (once per graph and geometry, independent of K): the slice
+    table through the C ABI, the rest with torch ops (`sweep_plan_arrays`).  None when the rows are not column-sorted."""
+    table, ok = cabi.spmm_slices(rowptr, col, ncols, slices)
+    if not ok:
+        return None
+    arrays = sweep_plan_arrays(rowptr, table, slices, waves_per_gen, rows_per_wave, chunk, min_seg)
+    del table
+    if col32 is None:
+        col32 = cabi.pack_indices(col)
+    return SweepPlan(col32=col32, **arrays)

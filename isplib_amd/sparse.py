@@ -39,6 +39,10 @@ class SparseStorage:
         self._row_t: Optional[torch.Tensor] = None
         self._val_t: Optional[torch.Tensor] = None
         self._mean_val_t: Optional[torch.Tensor] = None
+        # state of `value` (data pointer, in-place version counter) the two weight vectors above were built from:
+        # an optimiser stepping trainable edge weights in place must not leave the backward on stale A^T weights
+        self._val_t_state = None
+        self._mean_val_t_state = None
         # task plans of A and A^T per slice count ([] when the rows are not column-sorted: plain kernel)
         self._plans = {}
         self._plans_t = {}
@@ -66,10 +70,15 @@ class SparseStorage:
             self._rowcount = self._rowptr[1:] - self._rowptr[:-1]
         return self._rowcount
 
+    def _value_state(self):
+        v = self._value
+        return None if v is None else (v.data_ptr(), v._version)
+
     def _build_transpose(self) -> None:
         colptr, perm, row_t, val_t = cabi.csr2csc(self._rowptr, self._col, self._value, self._sparse_sizes[1],
                                                   want_val=self._value is not None)
         self._colptr, self._csr2csc, self._row_t, self._val_t = colptr, perm, row_t, val_t
+        self._val_t_state = self._value_state()
 
     def colptr(self) -> torch.Tensor:
         if self._colptr is None:
@@ -88,8 +97,16 @@ class SparseStorage:
         return self._row_t
 
     def val_t(self) -> Optional[torch.Tensor]:
-        if self._value is not None and self._val_t is None:
+        """value[csr2csc] (isplib/__init__.py:79), rebuilt when `value` was replaced or written in place since."""
+        if self._value is None:
+            return None
+        if self._val_t is None:
             self._build_transpose()
+        elif self._val_t_state != self._value_state():
+            # the structure (colptr, csr2csc, row_t) is unchanged: only permute the fresh weights, into a NEW tensor
+            # (a saved-for-backward reference to the old one stays what it was)
+            self._val_t = self._value.detach()[self.csr2csc()].contiguous()
+            self._val_t_state = self._value_state()
         return self._val_t
 
     def plan(self, n_slices: int):
@@ -127,9 +144,10 @@ class SparseStorage:
 
     def mean_val_t(self) -> torch.Tensor:
         """value[csr2csc] / max(rowcount,1)[row[csr2csc]] (csrc/fusedmm.cpp:357-364)."""
-        if self._mean_val_t is None:
+        if self._mean_val_t is None or self._mean_val_t_state != self._value_state():
             _, _, _, self._mean_val_t = cabi.csr2csc(self._rowptr, self._col, self._value, self._sparse_sizes[1],
                                                      mean_scale=True, want_perm=False, want_row=False)
+            self._mean_val_t_state = self._value_state()
         return self._mean_val_t
 
 

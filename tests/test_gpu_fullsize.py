@@ -170,3 +170,149 @@ def test_config2_max_k128_default_schedule_bit_exact(gpu, reddit, reddit_plan_de
     ref, ref_arg = oracle_mod.spmm_fw(rp, cl, np.ones(cl.size, np.float32), xx, "max")
     assert np.array_equal(out.cpu().numpy().view(np.uint32), ref.view(np.uint32))
     assert np.array_equal(arg.cpu().numpy(), ref_arg)
+
+
+# ---- round 2: the holes VERDICT r01 listed, plus a third-party arbiter at full size ---------------------------------
+
+def _quantiles(name, got, ref):
+    """Plain relative error |got - ref| / |ref| (BASELINE.md section 3 promised it beside the summation bound);
+    printed (pytest -s / -rP) and appended to gpurun_out/parity_quantiles.txt when that directory exists."""
+    import os
+    nz = ref != 0
+    rel = np.abs(got[nz].astype(np.float64) - ref[nz].astype(np.float64)) / np.abs(ref[nz].astype(np.float64))
+    q = np.quantile(rel, (0.5, 0.99, 0.9999, 1.0))
+    line = f"{name}: plain relative error median {q[0]:.2e}  p99 {q[1]:.2e}  p99.99 {q[2]:.2e}  max {q[3]:.2e}  (n={rel.size})"
+    print(line)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "parity_quantiles.txt"), "a") as f:
+            f.write(line + "\n")
+    return q
+
+
+def _torch_cpu_spmm(rp, cl, ww, xx, red):
+    """torch.sparse.mm(csr, X, reduce) on the CPU: an arbiter that shares no code with the oracle or the product."""
+    a = torch.sparse_csr_tensor(torch.from_numpy(rp), torch.from_numpy(cl), torch.from_numpy(ww), size=(rp.size - 1, xx.shape[0]))
+    tred = {"sum": "sum", "mean": "mean", "max": "amax", "min": "amin"}[red]
+    return torch.sparse.mm(a, torch.from_numpy(xx), tred).numpy()
+
+
+@pytest.fixture(scope="module")
+def reddit_sweep(reddit):
+    from isplib_amd import cabi
+    from isplib_amd.plan import build_sweep_plan
+    rowptr, col, n, _ = reddit
+    return build_sweep_plan(rowptr, col, n, 16, cabi.sweep_resident_waves("sum", 64, 16), 16)
+
+
+@pytest.mark.parametrize("red", ("mean", "min"))
+def test_config3_reddit_k64_default_plan_and_torch_arbiter(gpu, reddit, reddit_sweep, oracle_mod, red):
+    """mean / min, K=64, weighted, through the DEFAULT schedule (isplib_suggest_slices -> 8 slices, task list) and the
+    sweep schedule; checked against the oracle AND against torch.sparse.mm on the CPU."""
+    from isplib_amd import cabi, synth
+    from isplib_amd.plan import build_task_plan
+    rowptr, col, n, _ = reddit
+    k = 64
+    s = cabi.lib().isplib_suggest_slices(n, n, col.numel(), k, int(red == "min"))
+    assert s == 8
+    plan = build_task_plan(rowptr, col, n, s)
+    x = synth.features(n, k, device=gpu, integer=(red == "min"))
+    w = synth.edge_weights(col.numel(), device=gpu)
+    tasks, targ = cabi.spmm_tasks(rowptr, col, w, plan, x, red)
+    sweep, sarg = cabi.spmm_sweep(rowptr, col, w, reddit_sweep, x, red)
+    rp, cl, ww, xx = _host(rowptr, col, w, x)
+    ref, ref_arg = oracle_mod.spmm_fw(rp, cl, ww, xx, red)
+    third = _torch_cpu_spmm(rp, cl, ww, xx, red)
+    if red == "mean":
+        mag, _ = oracle_mod.spmm_fw(rp, cl, ww, np.abs(xx), "mean")
+        for name, got in (("tasks", tasks), ("sweep", sweep)):
+            got = got.cpu().numpy()
+            assert np.all(np.abs(got - ref) <= 1e-5 * mag + 1e-30), name
+            assert np.all(np.abs(got - third) <= 2e-5 * mag + 1e-30), f"{name} vs torch.sparse.mm"
+            _quantiles(f"reddit mean K=64 {name} vs oracle", got, ref)
+    else:
+        for name, got, arg in (("tasks", tasks, targ), ("sweep", sweep, sarg)):
+            assert np.array_equal(got.cpu().numpy().view(np.uint32), ref.view(np.uint32)), name
+            assert np.array_equal(arg.cpu().numpy(), ref_arg), name
+            assert np.array_equal(got.cpu().numpy(), third), f"{name} vs torch.sparse.mm amin"
+
+
+def test_config2_sum_k128_sweep_and_torch_arbiter(gpu, reddit, reddit_sweep, oracle_mod):
+    """The headline workload through the sweep schedule: bitwise reproducible, within the bound of the oracle, and
+    within twice the bound of torch.sparse.mm on the CPU (two fp32 summation orders)."""
+    from isplib_amd import cabi, synth
+    rowptr, col, n, _ = reddit
+    k = 128
+    x = synth.features(n, k, device=gpu)
+    out, _ = cabi.spmm_sweep(rowptr, col, None, reddit_sweep, x, "sum")
+    again, _ = cabi.spmm_sweep(rowptr, col, None, reddit_sweep, x, "sum")
+    assert torch.equal(out, again)
+    rp, cl, xx = _host(rowptr, col, x)
+    ones = np.ones(cl.size, np.float32)
+    ref, _ = oracle_mod.spmm_fw(rp, cl, ones, xx, "sum")
+    mag, _ = oracle_mod.spmm_fw(rp, cl, ones, np.abs(xx), "sum")
+    got = out.cpu().numpy()
+    assert np.all(np.abs(got - ref) <= 1e-5 * mag + 1e-30)
+    third = _torch_cpu_spmm(rp, cl, ones, xx, "sum")
+    assert np.all(np.abs(got - third) <= 2e-5 * mag + 1e-30)
+    q = _quantiles("reddit sum K=128 sweep vs oracle", got, ref)
+    assert q[0] < 1e-5
+    deg = (rowptr[1:] - rowptr[:-1]).double()
+    expect = (deg[:, None] * x.double()).sum(0)
+    slack = 1e-8 * (deg[:, None] * x.double().abs()).sum(0)
+    assert bool(((out.double().sum(0) - expect).abs() <= slack).all())
+    # max through the sweep schedule, integer X (ties everywhere): bit for bit, values and arg
+    xi = synth.features(n, 64, device=gpu, integer=True)
+    mx, marg = cabi.spmm_sweep(rowptr, col, None, reddit_sweep, xi, "max")
+    ref, ref_arg = oracle_mod.spmm_fw(rp, cl, ones, xi.cpu().numpy(), "max")
+    assert np.array_equal(mx.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    assert np.array_equal(marg.cpu().numpy(), ref_arg)
+
+
+def test_fullsize_weighted_nonsymmetric_backward(gpu, reddit, oracle_mod):
+    """A DIRECTED graph at full size (a random half of the Reddit-shaped edges: A^T != A), weighted: dX of sum and of
+    mean through isplib_graph_spmm_backward and dA through isplib_graph_sddmm, against the oracle's restatement of
+    csrc/fusedmm.cpp:285,375 and of the commented-out SDDMM (:270) -- the val_t permutation and the mean weights are
+    checked where the symmetric identity of test_config2_backward_on_symmetric_graph cannot see them."""
+    from isplib_amd import cabi, synth
+    rowptr, col, n, _ = reddit
+    gen = torch.Generator(device=gpu)
+    gen.manual_seed(17)
+    keep = torch.rand(col.numel(), generator=gen, device=gpu) < 0.5
+    row = cabi.csr_row_ids(rowptr, col.numel())
+    d_col = col[keep].contiguous()
+    d_rowptr = torch.zeros(n + 1, dtype=torch.int64, device=gpu)
+    torch.cumsum(torch.bincount(row[keep], minlength=n), 0, out=d_rowptr[1:])
+    del row, keep
+    k = 64
+    w = synth.edge_weights(d_col.numel(), device=gpu)
+    dy = synth.features(n, k, seed=5, device=gpu)
+    x = synth.features(n, k, device=gpu)
+    h = cabi.GraphHandle(d_rowptr, d_col, w, n)
+    try:
+        dx_sum = h.spmm_backward(dy, mean=False)
+        dx_mean = h.spmm_backward(dy, mean=True)
+        dval = h.sddmm(x, dy, mean=False)
+        dval_mean = h.sddmm(x, dy, mean=True)
+        torch.cuda.synchronize()
+    finally:
+        h.close()
+    rp, cl, ww, gg, xx = _host(d_rowptr, d_col, w, dy, x)
+    colptr, row_t, val_t = None, None, None
+    row_np, rowcount, colptr, csr2csc = oracle_mod.csr_transpose(rp, cl, n)
+    assert not np.array_equal(colptr, rp), "the graph must not be symmetric"
+    row_t, val_t = row_np[csr2csc], ww[csr2csc]
+    ref, _ = oracle_mod.spmm_fw(colptr, row_t, val_t, gg, "sum")
+    mag, _ = oracle_mod.spmm_fw(colptr, row_t, val_t, np.abs(gg), "sum")
+    assert np.all(np.abs(dx_sum.cpu().numpy() - ref) <= 1e-5 * mag + 1e-30)
+    mean_w = (val_t / np.maximum(rowcount, 1).astype(np.float32)[row_t]).astype(np.float32)
+    ref, _ = oracle_mod.spmm_fw(colptr, row_t, mean_w, gg, "sum")
+    mag, _ = oracle_mod.spmm_fw(colptr, row_t, mean_w, np.abs(gg), "sum")
+    assert np.all(np.abs(dx_mean.cpu().numpy() - ref) <= 1e-5 * mag + 1e-30)
+    del ref, mag
+    ref = oracle_mod.sddmm(rp, cl, xx, gg)
+    bound = 1e-5 * oracle_mod.sddmm(rp, cl, np.abs(xx), np.abs(gg)) + 1e-30
+    assert np.all(np.abs(dval.cpu().numpy() - ref) <= bound)
+    ref = oracle_mod.sddmm(rp, cl, xx, gg, mean=True)
+    bound = 1e-5 * oracle_mod.sddmm(rp, cl, np.abs(xx), np.abs(gg), mean=True) + 1e-30
+    assert np.all(np.abs(dval_mean.cpu().numpy() - ref) <= bound)

@@ -531,3 +531,86 @@ def test_reference_schema_ops_get_the_task_schedule_through_cached_handles(gpu, 
     assert ops.graph_cache_size() <= 1
     ops.graph_cache_clear()
     assert ops.graph_cache_size() == 0
+
+
+def test_config1_cora_k16_through_patch_pyg(gpu, oracle_mod, monkeypatch):
+    """BASELINE.json configs[0]: the Cora-shaped adjacency (2,708 nodes, 10,556 nnz), K=16, through the reference's
+    drop-in surface -- iSpLibPlugin.patch_pyg() and then torch_sparse.matmul / torch.sparse.mm exactly as PyG calls
+    them (isplib/__init__.py:140-151,177-178) -- forward and backward, all four reductions, against the oracle.
+    torch_sparse is not part of this image: a stand-in module object takes its place for the patch, and the graph is
+    a duck-typed object with the members the wrapper reads (csr(), storage, sparse_sizes())."""
+    import types
+
+    import isplib_amd
+    from isplib_amd import plugin, synth
+
+    class ForeignStorage:
+        _row = _rowcount = _csr2csc = _colptr = None
+
+    class Foreign:
+        def __init__(self, rowptr, col, value, sizes):
+            self._csr, self._sizes, self.storage = (rowptr, col, value), sizes, ForeignStorage()
+
+        def csr(self):
+            return self._csr
+
+        def sparse_sizes(self):
+            return self._sizes
+
+    fake_ts = types.SimpleNamespace(matmul=lambda *a, **k: (_ for _ in ()).throw(AssertionError("unpatched torch_sparse.matmul")))
+    monkeypatch.setattr(plugin, "_torch_sparse", fake_ts)
+    rowptr_t, col_t, n = synth.dataset_like("cora", device="cpu")
+    assert n == 2708 and col_t.numel() == 10556
+    rowptr, col = rowptr_t.numpy(), col_t.numpy()
+    k = 16
+    x = synth.features(n, k, device="cpu").numpy()
+    g = synth.features(n, k, seed=5, device="cpu").numpy()
+    for weighted in (False, True):
+        val = synth.edge_weights(col.size, device="cpu").numpy() if weighted else np.ones(col.size, np.float32)
+        src = Foreign(_t(rowptr, gpu), _t(col, gpu), _t(val, gpu) if weighted else None, (n, n))
+        tol = cases.sum_tolerance(oracle_mod, rowptr, col, val, x)
+        gtol = cases.sum_tolerance(oracle_mod, *_transpose_np(oracle_mod, rowptr, col, val, n), g)
+        isplib_amd.iSpLibPlugin.patch_pyg()
+        try:
+            assert fake_ts.matmul is plugin.spmm_autotuned
+            for red in cases.REDUCES:
+                for entry in (fake_ts.matmul, torch.sparse.mm):
+                    xs = _t(x, gpu).requires_grad_(True)
+                    out = entry(src, xs, red) if red != "sum" or entry is fake_ts.matmul else entry(src, xs)
+                    out.backward(_t(g, gpu))
+                    ref, ref_arg = oracle_mod.spmm_fw(rowptr, col, val, x, red)
+                    got, dx = out.detach().cpu().numpy(), xs.grad.cpu().numpy()
+                    if red in ("sum", "mean"):
+                        assert np.all(np.abs(got - ref) <= tol), red
+                        bw = oracle_mod.spmm_sum_bw if red == "sum" else oracle_mod.spmm_mean_bw
+                        assert np.all(np.abs(dx - bw(rowptr, col, val, n, g)) <= gtol), red
+                    else:
+                        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), red
+                        _, r_dx = oracle_mod.spmm_minmax_bw(col, val, x, ref_arg, g)
+                        _close(dx, r_dx, rtol=1e-5, atol=1e-5)
+        finally:
+            isplib_amd.iSpLibPlugin.unpatch_pyg()
+    assert not isplib_amd.iSpLibPlugin.is_patched()
+
+
+def _transpose_np(oracle_mod, rowptr, col, val, ncols):
+    row, _, colptr, csr2csc = oracle_mod.csr_transpose(rowptr, col, ncols)
+    return colptr, row[csr2csc], np.asarray(val, np.float32)[csr2csc]
+
+
+def test_backward_sees_edge_weights_updated_in_place(gpu, oracle_mod):
+    """Trainable edge weights stepped in place between two iterations: the second backward must use the NEW
+    weights in A^T (the cached value[csr2csc] / mean weights are rebuilt when `value` changes), for sum and mean."""
+    import isplib_amd
+    rowptr, col = cases.random_csr(90, 70, 8.0, seed=12, empty_rows=(3,))
+    x, g = cases.dense(70, 24, 3), cases.dense(90, 24, 5)
+    val0 = cases.weights(col.size, 4)
+    val1 = cases.weights(col.size, 99)
+    for red, bw in (("sum", oracle_mod.spmm_sum_bw), ("mean", oracle_mod.spmm_mean_bw)):
+        value = _t(val0, gpu)
+        adj = isplib_amd.SparseTensor.from_csr(_t(rowptr, gpu), _t(col, gpu), value, (90, 70))
+        for cur in (val0, val1):
+            xs = _t(x, gpu).requires_grad_(True)
+            isplib_amd.matmul(adj, xs, red).backward(_t(g, gpu))
+            _close(xs.grad, bw(rowptr, col, cur, 70, g), rtol=1e-5, atol=2e-5)
+            value.copy_(_t(val1, gpu))              # what optimizer.step() does to a trainable weight vector

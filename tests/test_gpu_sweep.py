@@ -1,0 +1,136 @@
+"""GPU parity of the sweep schedule (fusedMM_csr_sweep_hip: rows resident in LDS, no partial rows) against the CPU
+oracle, through the C ABI.  Bar as everywhere: max/min values and arg indices bit-exact, sum/mean within
+1e-5 * sum|val*x| per element.  Small seeded cases here; the full-size ones are in test_gpu_fullsize.py."""
+import numpy as np
+import pytest
+import torch
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _check(oracle, rowptr, col, val, x, red, out, arg, tol=None):
+    ref, ref_arg = oracle.spmm_fw(rowptr, col, val, x, red)
+    out = out.cpu().numpy()
+    if red in ("sum", "mean"):
+        tol = cases.sum_tolerance(oracle, rowptr, col, val, x) if tol is None else tol
+        fin = np.isfinite(ref) & np.isfinite(tol)
+        assert np.array_equal(np.isnan(out[~fin]), np.isnan(ref[~fin]))
+        err = np.abs(out[fin].astype(np.float64) - ref[fin].astype(np.float64))
+        assert np.all(err <= tol[fin]), f"{red}: max err/tol = {np.max(err / tol[fin])}"
+    else:
+        assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), f"{red}: values not bit-exact"
+        assert np.array_equal(arg.cpu().numpy(), ref_arg), f"{red}: arg indices differ"
+
+
+def _sweep_all(gpu, oracle, rowptr, col, val, x, unit=False, geoms=((8, 64, 16, 64, 4), (5, 24, 8, 2048, 16), (16, 7, 32, 100, 1))):
+    """geoms: (slices, waves_per_gen, rows_per_wave, chunk, min_seg)"""
+    from isplib_amd import cabi
+    from isplib_amd.plan import build_sweep_plan
+    d_rowptr, d_col, d_x = _t(rowptr, gpu), _t(col, gpu), _t(x, gpu)
+    d_val = None if unit else _t(val, gpu)
+    for (s, wpg, rpw, chunk, min_seg) in geoms:
+        plan = build_sweep_plan(d_rowptr, d_col, x.shape[0], s, wpg, rpw, chunk, min_seg)
+        assert plan is not None
+        assert int((plan.task_meta & 0xFFFFFF).sum()) == col.size
+        for red in cases.REDUCES:
+            if red in ("max", "min") and rpw > 16:
+                continue
+            out, arg = cabi.spmm_sweep(d_rowptr, d_col, d_val, plan, d_x, red)
+            again, _ = cabi.spmm_sweep(d_rowptr, d_col, d_val, plan, d_x, red)
+            torch.cuda.synchronize()
+            assert torch.equal(out.view(torch.int32), again.view(torch.int32)), "sweep schedule must be bitwise reproducible"
+            _check(oracle, rowptr, col, val, x, red, out, arg)
+
+
+@pytest.mark.parametrize("k", (4, 16, 32, 64, 100, 128, 256, 600))
+def test_sweep_widths_weighted(gpu, oracle_mod, k):
+    rowptr, col = cases.random_csr(300, 257, 9.0, seed=10 + k, empty_rows=(0, 150, 299))
+    val = cases.weights(col.size, 4)
+    x = cases.dense(257, k, 3)
+    _sweep_all(gpu, oracle_mod, rowptr, col, val, x)
+
+
+@pytest.mark.parametrize("k", (16, 64, 128))
+def test_sweep_unit_weights(gpu, oracle_mod, k):
+    rowptr, col = cases.random_csr(200, 200, 12.0, seed=77)
+    val = cases.weights(col.size, 0, "unit")
+    x = cases.dense(200, k, 3)
+    _sweep_all(gpu, oracle_mod, rowptr, col, val, x, unit=True)
+
+
+@pytest.mark.parametrize("kind", ("integer", "constant", "signed_zero", "nonfinite", "denormal"))
+def test_sweep_ties_and_nonfinite(gpu, oracle_mod, kind):
+    rowptr, col = cases.random_csr(128, 96, 20.0, seed=5, empty_rows=(3,), duplicates=True)
+    val = cases.weights(col.size, 4, "signed_int" if kind != "constant" else "unit")
+    x = cases.dense(96, 64, 3, kind)
+    _sweep_all(gpu, oracle_mod, rowptr, col, val, x)
+
+
+@pytest.mark.parametrize("k", (32, 128))
+def test_sweep_hub_row_is_cut_into_virtual_rows(gpu, oracle_mod, k):
+    """A row of 12,345 edges among short ones: with chunk = 64 / 100 it becomes >100 virtual rows on different waves,
+    folded by sweep_hub_fold_kernel; integer X makes every max/min a tie."""
+    rowptr, col = cases.random_csr(64, 400, 6.0, seed=9, empty_rows=(0, 63), hub=(17, 12345), duplicates=True)
+    val = cases.weights(col.size, 4, "signed_int")
+    x = cases.dense(400, k, 3, "integer")
+    _sweep_all(gpu, oracle_mod, rowptr, col, val, x)
+
+
+def test_sweep_rectangular_and_strided(gpu, oracle_mod):
+    """M != N (the A^T call of the backward) and leading dimensions larger than k."""
+    from isplib_amd import cabi
+    from isplib_amd.plan import build_sweep_plan
+    rowptr, col = cases.random_csr(90, 333, 25.0, seed=3)
+    val = cases.weights(col.size, 4)
+    k, ld = 48, 64
+    xfull = cases.dense(333, ld, 3)
+    x = np.ascontiguousarray(xfull[:, :k])
+    d_rowptr, d_col, d_val = _t(rowptr, gpu), _t(col, gpu), _t(val, gpu)
+    d_x = _t(xfull, gpu)[:, :k]
+    plan = build_sweep_plan(d_rowptr, d_col, 333, 4, 16, 16, 256, 8)
+    zfull = torch.full((90, ld), 7.0, device=gpu)
+    z = zfull[:, :k]
+    cabi.fusedMM_csr_sweep_hip(cabi.MSG_SPMM_SUM, d_rowptr, d_col, d_val, plan, d_x, z, None, plan.workspace("sum", k))
+    torch.cuda.synchronize()
+    _check(oracle_mod, rowptr, col, val, x, "sum", z.contiguous(), None)
+    assert bool((zfull[:, k:] == 7.0).all()), "columns beyond k must not be touched"
+
+
+def test_sweep_epilogue_and_mean(gpu, oracle_mod):
+    from isplib_amd import cabi
+    from isplib_amd.plan import build_sweep_plan
+    rowptr, col = cases.random_csr(150, 150, 15.0, seed=21, empty_rows=(4,), hub=(9, 700))
+    k = 64
+    x = cases.dense(150, k, 3)
+    ones = np.ones(col.size, np.float32)
+    d_rowptr, d_col, d_x = _t(rowptr, gpu), _t(col, gpu), _t(x, gpu)
+    plan = build_sweep_plan(d_rowptr, d_col, 150, 4, 8, 16, 128, 8)
+    rs = cases.dense(150, 1, 8)[:, 0].copy()
+    bias = cases.dense(1, k, 9)[0].copy()
+    out, _ = cabi.spmm_sweep(d_rowptr, d_col, None, plan, d_x, "sum", row_scale=_t(rs, gpu), self_term=d_x, bias=_t(bias, gpu), relu=True)
+    ref, _ = oracle_mod.spmm_fw(rowptr, col, ones, x, "sum")
+    want = np.maximum(rs[:, None] * (ref + x) + bias[None, :], 0.0)
+    tol = cases.sum_tolerance(oracle_mod, rowptr, col, ones, x) * np.abs(rs[:, None]) + 1e-6
+    assert np.all(np.abs(out.cpu().numpy() - want) <= tol)
+
+
+def test_sweep_status_codes(gpu):
+    from isplib_amd import cabi
+    from isplib_amd.plan import build_sweep_plan
+    rowptr, col = cases.random_csr(40, 40, 5.0, seed=1)
+    d_rowptr, d_col = _t(rowptr, gpu), _t(col, gpu)
+    plan = build_sweep_plan(d_rowptr, d_col, 40, 2, 4, 16)
+    x = torch.zeros((40, 6), device=gpu)          # k % 4 != 0
+    z = torch.zeros((40, 6), device=gpu)
+    assert cabi.fusedMM_csr_sweep_hip(cabi.MSG_SPMM_SUM, d_rowptr, d_col, None, plan, x, z, None, check=False) == 1
+    x = torch.zeros((40, 8), device=gpu)
+    z = torch.zeros((41, 8), device=gpu)
+    bad = torch.cat([d_rowptr, d_rowptr[-1:]])    # another row count than the plan's
+    assert cabi.fusedMM_csr_sweep_hip(cabi.MSG_SPMM_SUM, bad, d_col, None, plan, x, z, None, check=False) == 1
+    assert cabi.fusedMM_csr_sweep_hip(0x11101, d_rowptr, d_col, None, plan, x, z[:40], None, check=False) == 128

@@ -359,3 +359,94 @@ def test_degree_skew_adjustment_of_the_slice_rule():
     skewed = torch.cat([torch.zeros(1, dtype=torch.int64), deg.cumsum(0)])
     assert plugin.degree_cv2(skewed) > 2.0 and plugin.skew_adjusted(skewed, 8) == 8
     assert plugin.skew_adjusted(flat, 60) == 64                                     # capped like the rule itself
+
+
+def test_bench_self_launches_one_rank_per_gpu_and_refuses_missing_gpus():
+    """`python bench.py --gpus N` with no launcher (WORLD_SIZE unset) must start N ranks itself, before touching the
+    GPU, and must fail loudly -- never print an n_gpus=1 line -- when fewer than N GPUs are visible."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cmd = bench.launcher_command(4, ["--gpus", "4", "--steps", "3"], 29512)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29512"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    launch_at = src.index("raise SystemExit(self_launch(")
+    assert launch_at < src.index("torch.cuda.is_available()"), "the launcher must run before anything initialises the GPU"
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    if torch.cuda.device_count() < 8:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                           capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode != 0 and "refusing" in r.stderr and '"metric"' not in r.stdout
+    # a launcher that disagrees with --gpus is an error too, not a silent single-rank run
+    env2 = dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True, env=env2, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def _slice_table_np(rowptr, col, n, slices):
+    w = -(-n // slices)
+    m = rowptr.size - 1
+    table = np.zeros((m, slices + 1), np.int64)
+    for i in range(m):
+        c = col[rowptr[i]:rowptr[i + 1]]
+        table[i] = rowptr[i] + np.searchsorted(c, np.arange(slices + 1) * w, side="left")
+        table[i, slices] = rowptr[i + 1]
+    return table
+
+
+@pytest.mark.parametrize("geom", ((8, 8, 8, 512, 4), (5, 3, 16, 64, 16), (16, 2, 32, 100000, 1), (1, 4, 8, 40, 1000)))
+def test_sweep_plan_covers_every_edge_once_in_csr_order(geom):
+    """Host logic of the sweep schedule's plan (isplib_amd/plan.py: sweep_plan_arrays), replayed on the CPU the way
+    the kernel walks it: every stored entry belongs to exactly one task of the wave that owns its (virtual) row, a
+    row's tasks are met in ascending CSR order, a wave's tasks are in (slice, slot) order, hub rows are cut into
+    chunks whose partial rows are contiguous and in CSR order, and the replay reproduces A @ X."""
+    from isplib_amd.plan import sweep_plan_arrays
+    slices, wpg, rpw, chunk, min_seg = geom
+    m, n = 300, 257
+    rowptr, col = cases.random_csr(m, n, 30, 1, empty_rows=(0, 5, 299), hub=(7, 5000))
+    table = _slice_table_np(rowptr, col, n, slices)
+    p = sweep_plan_arrays(torch.from_numpy(rowptr), torch.from_numpy(table), slices, wpg, rpw, chunk, min_seg)
+    nw = p["gens"] * p["waves_per_gen"]
+    wr = p["wave_row"].numpy().reshape(nw, rpw)
+    wp = p["wave_part"].numpy().reshape(nw, rpw)
+    off, tb, tm = p["wave_task_off"].numpy(), p["task_b"].numpy(), p["task_meta"].numpy()
+    x = np.random.default_rng(0).random((n, 3))
+    out, parts = np.zeros((m, 3)), np.zeros((p["n_parts"], 3))
+    cover = np.zeros(col.size, int)
+    width = -(-n // slices)
+    rows_seen = np.zeros(m, int)
+    for w in range(nw):
+        acc = np.zeros((rpw, 3))
+        last_pos = np.full(rpw, -1, np.int64)
+        last_key = -1
+        for t in range(off[w], off[w + 1]):
+            slot, ln, b = int(tm[t]) >> 24, int(tm[t]) & 0xFFFFFF, int(tb[t])
+            r = wr[w, slot]
+            assert r >= 0 and ln > 0 and rowptr[r] <= b and b + ln <= rowptr[r + 1]
+            assert b > last_pos[slot], "a row's tasks must come in ascending CSR order"
+            last_pos[slot] = b
+            if min_seg == 1:                                   # no slice groups: a task's phase is the slice of its first edge
+                key = int(col[b]) // width * rpw + slot
+                assert key > last_key, "a wave's tasks must be in (slice, slot) order"
+                last_key = key
+            cover[b:b + ln] += 1
+            acc[slot] += x[col[b:b + ln]].sum(0)
+        for j in range(rpw):
+            if wr[w, j] < 0:
+                continue
+            if wp[w, j] >= 0:
+                parts[wp[w, j]] = acc[j]
+            else:
+                out[wr[w, j]] = acc[j]
+                rows_seen[wr[w, j]] += 1
+    hr, ho = p["hub_row"].numpy(), p["hub_off"].numpy()
+    for h in range(hr.size):
+        out[hr[h]] = parts[ho[h]:ho[h + 1]].sum(0)
+        rows_seen[hr[h]] += 1
+    assert (cover == 1).all() and (rows_seen == 1).all()
+    ref = np.stack([x[col[rowptr[i]:rowptr[i + 1]]].sum(0) for i in range(m)])
+    assert np.allclose(out, ref, rtol=1e-12, atol=1e-12)
+    assert int((p["task_meta"] & 0xFFFFFF).sum()) == col.size
