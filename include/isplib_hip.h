@@ -329,6 +329,40 @@ int    fusedMM_csr_sweep_hip(int32_t imessage, int64_t m, int64_t n, int64_t k, 
                              void *workspace, size_t workspace_bytes,
                              const isplib_epilogue *epilogue /*host, may be NULL*/, void *stream);
 
+/*
+ * Stream form of the sweep schedule (sum / mean): the plan additionally owns a COPY of the edges in the order the
+ * waves walk them, so a wave never sees a row or slice boundary.  Each of the `streams` (= 64 / lanes per row slot)
+ * slots of a wave owns rows_per_wave / streams rows and a stream of 4-byte words, (local row << 27) | column, that
+ * lists those rows' edges slice by slice; step i of a wave gathers word i of each of its streams in ONE full 1-KiB
+ * buffer load and adds what arrives to the LDS row the word names (ds_add_f32, no return).  U gathers are in flight
+ * per wave at all times; there are no per-segment latency chains, no masked tails and no cross-lane reduction.
+ * No two lanes of an instruction, and no two waves, ever add to the same LDS word, and a wave's LDS operations
+ * execute in order: every sum is formed in one fixed order (bitwise reproducible).  The panel width is
+ * 256 / streams columns (streams = 4: 64 columns); k is swept in such panels.  Weights are part of the plan (`vals`,
+ * in stream order; NULL = unit weights): a caller whose weights change refreshes them through `perm`.
+ * Requirements as fusedMM_csr_sweep_hip, plus n < 2^27.
+ */
+typedef struct isplib_stream_plan {
+   int64_t rows, cols;              /* m, n of the graph the plan was built for */
+   int32_t slices, gens, waves_per_gen, rows_per_wave /* 16 or 32 */, streams /* 2, 4 or 8 */, reserved;
+   int64_t n_steps, n_parts, n_hub;
+   const int32_t *words;            /* [dev] n_steps*streams: (local row << 27) | column; padding = (0 << 27) | n */
+   const float   *vals;             /* [dev] n_steps*streams weights in the same order, or NULL */
+   const int64_t *wave_step_off;    /* [dev] gens*waves_per_gen + 1: first step of a wave */
+   const int32_t *wave_row;         /* [dev] gens*waves_per_gen*rows_per_wave: row of the local row, -1 = unused */
+   const int32_t *wave_part;        /* [dev] same shape: -1 = whole row, else partial row id */
+   const int32_t *hub_row;          /* [dev] n_hub */
+   const int32_t *hub_off;          /* [dev] n_hub + 1 */
+} isplib_stream_plan;
+int    isplib_spmm_stream_resident_waves(int streams, int rows_per_wave);
+size_t isplib_spmm_stream_workspace_bytes(const isplib_stream_plan *plan);
+int    fusedMM_csr_stream_hip(int32_t imessage /* ISPLIB_MSG_SPMM_SUM | _MEAN */, int64_t m, int64_t n, int64_t k,
+                              int64_t nnz, const int64_t *pntrb, const int64_t *pntre,
+                              const isplib_stream_plan *plan /*host*/,
+                              const float *y, int64_t ldy, float *z, int64_t ldz,
+                              void *workspace, size_t workspace_bytes,
+                              const isplib_epilogue *epilogue /*host, may be NULL*/, void *stream);
+
 /* Tuning knobs for experiments (process-wide, not thread-safe; every setting gives the same results):
  *   0  lanes per row slot of the row kernels (0 = by k)      1  0: 64-bit addressing instead of buffer descriptors
  *   2  consecutive tasks per wave of the task kernel (0=auto) 4  column-panel width of the task entries, sum / mean (64)

@@ -52,6 +52,7 @@ EXPORTS = (
     "isplib_suggest_slices", "isplib_graph_create", "isplib_graph_set_slices", "isplib_graph_spmm", "isplib_graph_spmm_backward",
     "isplib_graph_destroy", "isplib_suggest_slices_whole_rows", "isplib_graph_sddmm",
     "fusedMM_csr_sweep_hip", "isplib_spmm_sweep_workspace_bytes", "isplib_spmm_sweep_resident_waves",
+    "fusedMM_csr_stream_hip", "isplib_spmm_stream_workspace_bytes", "isplib_spmm_stream_resident_waves",
 )
 
 _i64, _f32, _vp, _i32 = ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_int32
@@ -73,6 +74,15 @@ class SweepPlanStruct(ctypes.Structure):   # isplib_sweep_plan
                 ("n_parts", ctypes.c_int64), ("n_hub", ctypes.c_int64), ("wave_row", ctypes.c_void_p),
                 ("wave_part", ctypes.c_void_p), ("wave_task_off", ctypes.c_void_p), ("task_b", ctypes.c_void_p),
                 ("task_meta", ctypes.c_void_p), ("hub_row", ctypes.c_void_p), ("hub_off", ctypes.c_void_p)]
+
+
+class StreamPlanStruct(ctypes.Structure):  # isplib_stream_plan
+    _fields_ = [("rows", ctypes.c_int64), ("cols", ctypes.c_int64), ("slices", ctypes.c_int32), ("gens", ctypes.c_int32),
+                ("waves_per_gen", ctypes.c_int32), ("rows_per_wave", ctypes.c_int32), ("streams", ctypes.c_int32),
+                ("reserved", ctypes.c_int32), ("n_steps", ctypes.c_int64), ("n_parts", ctypes.c_int64), ("n_hub", ctypes.c_int64),
+                ("words", ctypes.c_void_p), ("vals", ctypes.c_void_p), ("wave_step_off", ctypes.c_void_p),
+                ("wave_row", ctypes.c_void_p), ("wave_part", ctypes.c_void_p), ("hub_row", ctypes.c_void_p),
+                ("hub_off", ctypes.c_void_p)]
 
 
 _sigs_set = False
@@ -159,6 +169,13 @@ def lib() -> ctypes.CDLL:
         L.isplib_graph_destroy.argtypes = [_vp]
         L.isplib_hip_tune.restype = ctypes.c_int
         L.isplib_hip_tune.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.isplib_spmm_stream_resident_waves.restype = ctypes.c_int
+        L.isplib_spmm_stream_resident_waves.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.isplib_spmm_stream_workspace_bytes.restype = ctypes.c_size_t
+        L.isplib_spmm_stream_workspace_bytes.argtypes = [ctypes.POINTER(StreamPlanStruct)]
+        L.fusedMM_csr_stream_hip.restype = ctypes.c_int
+        L.fusedMM_csr_stream_hip.argtypes = [_i32, _i64, _i64, _i64, _i64, _vp, _vp, ctypes.POINTER(StreamPlanStruct), _vp, _i64,
+                                             _vp, _i64, _vp, ctypes.c_size_t, ctypes.POINTER(Epilogue), _vp]
         L.isplib_spmm_sweep_resident_waves.restype = ctypes.c_int
         L.isplib_spmm_sweep_resident_waves.argtypes = [_i32, _i64, ctypes.c_int]
         L.isplib_spmm_sweep_workspace_bytes.restype = ctypes.c_size_t
@@ -534,6 +551,40 @@ def spmm_sweep(rowptr, col, val, plan, y, reduce: str = "sum", workspace=None, r
                       k if self_term is None else self_term.stride(0), None if bias is None else bias.data_ptr(), int(bool(relu)))
     fusedMM_csr_sweep_hip(MESSAGE[reduce], rowptr, col, val, plan, y, out, arg, workspace, ep)
     return out, arg
+
+
+def fusedMM_csr_stream_hip(imessage: int, rowptr, nnz: int, plan, y, z, workspace=None, epilogue=None, check: bool = True) -> int:
+    """Raw boundary call of the stream-form SpMM (sum / mean); ``plan`` is an isplib_amd.plan.StreamPlan."""
+    assert y.is_cuda and y.dtype == torch.float32 and y.dim() == 2 and y.stride(1) == 1
+    m, n, k = rowptr.numel() - 1, y.size(0), y.size(1)
+    rp = rowptr.data_ptr()
+    ps = plan.struct()
+    with torch.cuda.device(y.device):
+        st = lib().fusedMM_csr_stream_hip(int(imessage), m, n, k, int(nnz), ctypes.c_void_p(rp), ctypes.c_void_p(rp + 8),
+                                          ctypes.byref(ps), _ptr(y), y.stride(0) if n > 1 else max(k, y.stride(0)), _ptr(z),
+                                          z.stride(0) if m > 1 else max(k, z.stride(0)), _ptr(workspace),
+                                          0 if workspace is None else workspace.numel(),
+                                          None if epilogue is None else ctypes.byref(epilogue), _stream(y.device))
+    if check:
+        _check(st, "fusedMM_csr_stream_hip")
+    return st
+
+
+def spmm_stream(rowptr, nnz: int, plan, y, reduce: str = "sum", workspace=None, row_scale=None, self_term=None, bias=None,
+                relu=False):
+    """Allocate the output (+ workspace) and call the stream boundary; returns out."""
+    rowptr = _dev(rowptr, "rowptr", torch.int64)
+    y = y.contiguous()
+    m, k = rowptr.numel() - 1, y.size(1)
+    out = torch.empty((m, k), dtype=torch.float32, device=y.device)
+    if workspace is None:
+        workspace = plan.workspace()
+    ep = None
+    if row_scale is not None or self_term is not None or bias is not None or relu:
+        ep = Epilogue(None if row_scale is None else row_scale.data_ptr(), None if self_term is None else self_term.data_ptr(),
+                      k if self_term is None else self_term.stride(0), None if bias is None else bias.data_ptr(), int(bool(relu)))
+    fusedMM_csr_stream_hip(MESSAGE[reduce], rowptr, nnz, plan, y, out, workspace, ep)
+    return out
 
 
 def sweep_resident_waves(reduce: str, k: int, rows_per_wave: int = 16) -> int:

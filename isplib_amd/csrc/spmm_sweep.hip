@@ -44,6 +44,11 @@ struct SweepArgs {
    const int64_t *task_b;          // [n_tasks] first CSR position
    const int32_t *task_meta;       // [n_tasks] (slot << 24) | edges
    int wave_base, wave_count;      // waves of this launch (one generation): [wave_base, wave_base + wave_count)
+   // stream form (spmm_stream_kernel): the plan's own copy of the edges, in the order the waves walk them
+   const int32_t *words;           // [steps][G] (local row << 27) | column; the null word is (0 << 27) | n
+   const float *vals;              // [steps][G] weights in the same order, or null (unit weights)
+   const int64_t *wave_step_off;   // [waves + 1] first step of a wave
+   unsigned null_word;
    float *part_val;                // [n_parts][k]
    int *part_idx;                  // [n_parts][k] row-relative edge ids (max/min)
    const int32_t *hub_row, *hub_off;
@@ -254,6 +259,122 @@ __global__ __launch_bounds__(256) void sweep_hub_fold_kernel(const SweepArgs a) 
    }
 }
 
+// ---- stream form ------------------------------------------------------------------------------------------------
+// The sweep above still pays one latency chain per (row, slice) segment -- and with L2-sized slices a segment is
+// 15 edges.  Here a wave does not see segments at all.  The plan gives each of the G = 64 / LPR slots of a wave its
+// own STREAM: the edges of the slot's NVMAX / G rows, slice by slice, as 4-byte words (local row << 27 | column) in
+// the plan's own copy of the index array.  Step i of a wave gathers word i of each of its G streams -- one 1-KiB
+// buffer load, always full -- and adds the four floats a lane receives into the LDS row the word names
+// (ds_add_f32 without return: LDS operations of a wave execute in order, and the slots of a wave own disjoint rows,
+// so every sum is formed in one fixed order; no two lanes of an instruction ever meet on an address).  U gathers
+// are in flight per wave at all times, across row and slice boundaries alike; there is no butterfly, no masked
+// tail, no per-segment bookkeeping.  Sum / mean only (a (value, id) pair has no LDS atomic).
+template <int G> __device__ __forceinline__ unsigned pick_lane(unsigned v, int first, int g) {
+   unsigned r = (unsigned)__builtin_amdgcn_readlane((int)v, first);
+#pragma unroll
+   for (int q = 1; q < G; q++) {
+      const unsigned o = (unsigned)__builtin_amdgcn_readlane((int)v, first + q);
+      r = g == q ? o : r;
+   }
+   return r;
+}
+
+template <int LPR, int NVMAX> constexpr int stream_wgs_per_cu() {
+   return 163840 / (4 * (NVMAX * LPR * 4 + 32) * 4) < 8 ? 163840 / (4 * (NVMAX * LPR * 4 + 32) * 4) : 8;
+}
+
+template <int LPR, bool HAS_VAL, int NVMAX>
+__global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, NVMAX>())) void spmm_stream_kernel(const SweepArgs a) {
+   // gathers in flight per wave: 8 where they fit 64 VGPRs (unit weights, 16 or 32 lanes per slot), else 4 (the weights
+   // and, at 8 lanes per slot, the eight-way lane pick need the registers; 8 spills there)
+   constexpr int WAVES = 4, G = 64 / LPR, PANEL = LPR * 4, SPB = 64 / G, U = (HAS_VAL || LPR == 8) ? 4 : 8;
+   constexpr int SKEWN = LPR < 32 ? 32 / LPR : 1;         // slots that share a 32-lane LDS group get disjoint banks
+   constexpr int WAVE_FLOATS = NVMAX * PANEL + 32;        // + room for the bank skew of the last row
+   static_assert(SPB % U == 0, "ring indices must be static");
+   __shared__ __attribute__((aligned(16))) float s_all[WAVES * WAVE_FLOATS];
+   const int lane = threadIdx.x & 63;
+   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+   const int g = lane / LPR, lc = lane % LPR;
+   const int wl = (int)blockIdx.x * WAVES + wave;
+   if (wl >= a.wave_count) return;                       // no barrier anywhere below
+   const int64_t w = (int64_t)a.wave_base + wl;
+   float *my = s_all + wave * WAVE_FLOATS;
+   for (int i = lane * 4; i < WAVE_FLOATS; i += 256)
+      *reinterpret_cast<float4 *>(my + i) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+   __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.y), 0, (int)a.ybytes, 0x00020000);
+   const bool cok = lc * 4 < a.k;
+   const unsigned cbyte = (unsigned)lc * 16u, poison = cok ? 0u : BUF_OOB;
+   // a row of the panel is kept as [component v][lane lc]: the lanes of a slot add to consecutive banks
+   float *lane_base = my + (g % SKEWN) * LPR + lc;
+   const int64_t s0 = a.wave_step_off[w], s1 = a.wave_step_off[w + 1];
+   const int64_t nwords = (s1 - s0) * G;
+   const int32_t *wp = a.words + s0 * G;
+   const float *vp = HAS_VAL ? a.vals + s0 * G : nullptr;
+   const unsigned ldyb = (unsigned)a.ldy * 4u;
+   auto load_batch = [&](int64_t first, unsigned &off, unsigned &row, float &val) {
+      const int64_t i = first + lane;
+      unsigned word = a.null_word;
+      val = 0.0f;
+      if (i < nwords) {
+         word = (unsigned)wp[i];
+         if (HAS_VAL) val = vp[i];
+      }
+      off = (word & 0x7FFFFFFu) * ldyb;
+      row = (word >> 27) * (unsigned)PANEL;
+   };
+   unsigned offA, offB, rowA, rowB;
+   float valA, valB;
+   load_batch(0, offA, rowA, valA);
+   load_batch(64, offB, rowB, valB);
+   v4i_t t[U];
+   unsigned la[U];
+   float vv[U];
+   auto issue = [&](int slot, int step, unsigned off_l, unsigned row_l, float val_l) {
+      const unsigned o = (pick_lane<G>(off_l, step * G, g) + cbyte) | poison;
+      la[slot] = pick_lane<G>(row_l, step * G, g);
+      if (HAS_VAL) vv[slot] = __uint_as_float(pick_lane<G>(__float_as_uint(val_l), step * G, g));
+      t[slot] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)o, 0, 0);
+   };
+#pragma unroll
+   for (int u = 0; u < U; u++) issue(u, u, offA, rowA, valA);
+   const int64_t nb = (nwords + 63) / 64;
+   for (int64_t b = 0; b < nb; b++) {
+#pragma unroll
+      for (int u = 0; u < SPB; u++) {
+         const int slot = u % U;
+         float *dst = lane_base + la[slot];
+#pragma unroll
+         for (int v = 0; v < 4; v++) {
+            const float x = __int_as_float(t[slot][v]);
+            __hip_atomic_fetch_add(dst + v * LPR, HAS_VAL ? vv[slot] * x : x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+         }
+         if (u + U < SPB) issue(slot, u + U, offA, rowA, valA);
+         else issue(slot, u + U - SPB, offB, rowB, valB);
+      }
+      offA = offB; rowA = rowB; valA = valB;
+      load_batch((b + 2) * 64, offB, rowB, valB);
+   }
+   // write-out: slot q owns the local rows [q * NVMAX / G, (q + 1) * NVMAX / G); its LPR lanes hold one row of the panel
+#pragma unroll 1
+   for (int jj = 0; jj < NVMAX / G; jj++) {
+      const int lrow = g * (NVMAX / G) + jj;
+      const int row = a.wave_row[(size_t)w * NVMAX + lrow];
+      if (row < 0 || !cok) continue;
+      const int part = a.wave_part[(size_t)w * NVMAX + lrow];
+      const float *src = lane_base + lrow * PANEL;
+      float v[4] = {src[0], src[LPR], src[2 * LPR], src[3 * LPR]};
+      int bi[4] = {INT_MAX, INT_MAX, INT_MAX, INT_MAX};
+      const int c = lc * 4;
+      if (part >= 0) {
+         store_vec<4>(a.part_val + (size_t)part * (size_t)a.k + c, v);
+         continue;
+      }
+      int64_t arg[4];
+      finish_row<OP_ADD>(a, row, c, v, bi, arg);
+      store_vec<4>(a.z + (size_t)row * (size_t)a.ldz + c, v);
+   }
+}
+
 template <int OP, int LPR, int ADDR>
 static int launch_sweep_nv(const SweepArgs &a, int nvmax, hipStream_t st) {
    const unsigned blocks = (unsigned)((a.wave_count + 3) / 4);
@@ -281,6 +402,23 @@ static int sweep_resident_waves(bool add, int64_t pk, int nvmax, int cus) {
    int wgs = 163840 / lds;
    if (wgs > 8) wgs = 8;
    return cus * wgs * 4;
+}
+
+static int stream_resident_waves(int streams, int nvmax, int cus) {
+   const int lpr = 64 / streams;
+   const int lds = 4 * (nvmax * lpr * 4 + 32) * 4;
+   int wgs = 163840 / lds;
+   if (wgs > 8) wgs = 8;
+   return cus * wgs * 4;
+}
+
+template <int LPR, bool HAS_VAL>
+static int launch_stream(const SweepArgs &a, int nvmax, hipStream_t st) {
+   const unsigned blocks = (unsigned)((a.wave_count + 3) / 4);
+   if (blocks == 0) return ISPLIB_SUCCESS;
+   if (nvmax == 16) hipLaunchKernelGGL((spmm_stream_kernel<LPR, HAS_VAL, 16>), dim3(blocks), dim3(256), 0, st, a);
+   else hipLaunchKernelGGL((spmm_stream_kernel<LPR, HAS_VAL, 32>), dim3(blocks), dim3(256), 0, st, a);
+   return check_launch("spmm_stream_kernel");
 }
 
 int g_sweep_panel = 64;     // tuning knob (isplib_hip_tune(9, w)): column-panel width of the sweep schedule, 32 / 64 / 128
@@ -396,6 +534,94 @@ extern "C" int fusedMM_csr_sweep_hip(int32_t imessage, int64_t m, int64_t n, int
          if (aop == ISPLIB_AOP_ADD) hipLaunchKernelGGL((sweep_hub_fold_kernel<OP_ADD>), dim3((unsigned)blocks), dim3(256), 0, st, p);
          else if (aop == ISPLIB_AOP_MAX) hipLaunchKernelGGL((sweep_hub_fold_kernel<OP_MAX>), dim3((unsigned)blocks), dim3(256), 0, st, p);
          else hipLaunchKernelGGL((sweep_hub_fold_kernel<OP_MIN>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+         const int rc = check_launch("sweep_hub_fold_kernel");
+         if (rc) return rc;
+      }
+   }
+   return ISPLIB_SUCCESS;
+}
+
+// ---- stream form: entry ---------------------------------------------------------------------------------------------
+extern "C" int isplib_spmm_stream_resident_waves(int streams, int rows_per_wave) {
+   clear_error();
+   if ((streams != 2 && streams != 4 && streams != 8) || (rows_per_wave != 16 && rows_per_wave != 32)) return 0;
+   int dev = 0, cus = 0;
+   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+      (void)hipGetLastError();
+      cus = 256;                                          // MI355X
+   }
+   return stream_resident_waves(streams, rows_per_wave, cus);
+}
+
+extern "C" size_t isplib_spmm_stream_workspace_bytes(const isplib_stream_plan *plan) {
+   if (!plan || plan->n_parts <= 0) return 256;
+   const size_t pk = (size_t)(256 / (plan->streams > 0 ? plan->streams : 4));
+   return ((size_t)plan->n_parts * pk * sizeof(float) + 255) & ~(size_t)255;
+}
+
+extern "C" int fusedMM_csr_stream_hip(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t nnz,
+                                      const int64_t *pntrb, const int64_t *pntre, const isplib_stream_plan *plan,
+                                      const float *y, int64_t ldy, float *z, int64_t ldz, void *workspace,
+                                      size_t workspace_bytes, const isplib_epilogue *ep, void *stream) {
+   clear_error();
+   if (imessage != ISPLIB_MSG_SPMM_SUM && imessage != ISPLIB_MSG_SPMM_MEAN)
+      return fail(ISPLIB_NO_OPT_IMPL, "fusedMM_csr_stream_hip: sum and mean only (max / min: fusedMM_csr_tasks_hip)");
+   if (m < 0 || n < 0 || k < 0 || nnz < 0) return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: negative dimension");
+   if (m == 0 || k == 0) return ISPLIB_SUCCESS;
+   if (!plan) return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: plan is required");
+   if (plan->rows != m || plan->cols != n) return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: the plan was built for another shape");
+   if (n >= (1LL << 27)) return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: n must be < 2^27 (column ids share a word with the local row)");
+   if (plan->gens < 1 || plan->waves_per_gen < 1 || (plan->rows_per_wave != 16 && plan->rows_per_wave != 32) ||
+       (plan->streams != 2 && plan->streams != 4 && plan->streams != 8))
+      return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: bad plan geometry (rows_per_wave 16 or 32, streams 2, 4 or 8)");
+   if ((k % 4) != 0 || (ldy % 4) != 0 || (ldz % 4) != 0 || ((uintptr_t)y & 15) != 0 || ((uintptr_t)z & 15) != 0)
+      return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: k, ldy, ldz must be multiples of 4 and y, z 16-byte aligned (use fusedMM_csr_tasks_hip)");
+   if (ldy < k || ldz < k) return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: leading dimension smaller than k");
+   const unsigned long long yb = (unsigned long long)n * (unsigned long long)ldy * 4ull;
+   if (yb > BUF_LIMIT) return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: dense operand larger than 3.5 GiB (use fusedMM_csr_hip)");
+   if (!pntrb || !pntre || !z || !y || !plan->wave_row || !plan->wave_part || !plan->wave_step_off ||
+       (plan->n_steps > 0 && !plan->words) || (plan->n_hub > 0 && (!plan->hub_row || !plan->hub_off)))
+      return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: null operand");
+   if (plan->n_parts > 0) {
+      if (!workspace || workspace_bytes < isplib_spmm_stream_workspace_bytes(plan)) return fail(ISPLIB_NOT_ENOUGH_MEM, "fusedMM_csr_stream_hip: workspace too small");
+      if (((uintptr_t)workspace & 255) != 0) return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: workspace must be 256-byte aligned");
+   }
+   SweepArgs a = {};
+   a.k = k; a.nnz = nnz; a.pntrb = pntrb; a.pntre = pntre;
+   a.y = y; a.ldy = ldy; a.ybytes = (unsigned)yb; a.z = z; a.ldz = ldz; a.z_arg = nullptr;
+   a.mean = imessage == ISPLIB_MSG_SPMM_MEAN ? 1 : 0;
+   a.wave_row = plan->wave_row; a.wave_part = plan->wave_part;
+   a.words = plan->words; a.vals = plan->vals; a.wave_step_off = plan->wave_step_off; a.null_word = (unsigned)n;
+   a.hub_row = plan->hub_row; a.hub_off = plan->hub_off; a.n_hub = plan->n_hub;
+   a.part_val = (float *)workspace; a.part_idx = nullptr;
+   if (ep) {
+      if (ep->self && ep->ld_self < k) return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: ld_self smaller than k");
+      a.ep_row_scale = ep->row_scale; a.ep_self = ep->self; a.ep_ld_self = ep->ld_self; a.ep_bias = ep->bias;
+      a.ep_relu = ep->relu ? 1 : 0;
+   }
+   hipStream_t st = (hipStream_t)stream;
+   const int64_t pw = 256 / plan->streams;                // panel width follows the plan: a slot is 64 / streams lanes x 4 floats
+   for (int64_t c0 = 0; c0 < k; c0 += pw) {
+      SweepArgs p = a;
+      p.k = (k - c0) < pw ? (k - c0) : pw;
+      p.y = y + c0;
+      p.z = z + c0;
+      p.ep_self = a.ep_self ? a.ep_self + c0 : nullptr;
+      p.ep_bias = a.ep_bias ? a.ep_bias + c0 : nullptr;
+      p.ybytes = (unsigned)(yb - (unsigned long long)c0 * 4ull);
+      for (int gen = 0; gen < plan->gens; gen++) {
+         p.wave_base = gen * plan->waves_per_gen;
+         p.wave_count = plan->waves_per_gen;
+         int rc;
+         if (plan->streams == 2) rc = plan->vals ? launch_stream<32, true>(p, plan->rows_per_wave, st) : launch_stream<32, false>(p, plan->rows_per_wave, st);
+         else if (plan->streams == 4) rc = plan->vals ? launch_stream<16, true>(p, plan->rows_per_wave, st) : launch_stream<16, false>(p, plan->rows_per_wave, st);
+         else rc = plan->vals ? launch_stream<8, true>(p, plan->rows_per_wave, st) : launch_stream<8, false>(p, plan->rows_per_wave, st);
+         if (rc) return rc;
+      }
+      if (plan->n_hub > 0) {
+         int64_t blocks = (plan->n_hub * (p.k / 4) + 255) / 256;
+         if (blocks > 4096) blocks = 4096;
+         hipLaunchKernelGGL((sweep_hub_fold_kernel<OP_ADD>), dim3((unsigned)blocks), dim3(256), 0, st, p);
          const int rc = check_launch("sweep_hub_fold_kernel");
          if (rc) return rc;
       }

@@ -208,3 +208,139 @@ def build_sweep_plan(rowptr: torch.Tensor, col: torch.Tensor, ncols: int, slices
     if col32 is None:
         col32 = cabi.pack_indices(col)
     return SweepPlan(col32=col32, **arrays)
+
+
+@dataclass
+class StreamPlan:
+    """Plan of the stream form of the sweep schedule (``fusedMM_csr_stream_hip``, include/isplib_hip.h:
+    isplib_stream_plan).  Owns a copy of the edges in the order the waves walk them."""
+    rows: int
+    cols: int
+    slices: int
+    gens: int
+    waves_per_gen: int
+    rows_per_wave: int
+    streams: int
+    n_steps: int
+    n_parts: int
+    n_hub: int
+    words: torch.Tensor          # int32 [n_steps*streams]
+    vals: Optional[torch.Tensor]  # float32, same shape, or None (unit weights)
+    perm: torch.Tensor           # int32/int64 [n_steps*streams]: CSR position of the word, -1 = padding
+    wave_step_off: torch.Tensor  # int64 [gens*waves_per_gen + 1]
+    wave_row: torch.Tensor       # int32 [gens*waves_per_gen*rows_per_wave]
+    wave_part: torch.Tensor      # int32, same shape
+    hub_row: torch.Tensor        # int32 [n_hub]
+    hub_off: torch.Tensor        # int32 [n_hub + 1]
+    chunk: int
+
+    def struct(self) -> "cabi.StreamPlanStruct":
+        p = lambda t: t.data_ptr() if t is not None and t.numel() else None  # noqa: E731
+        return cabi.StreamPlanStruct(self.rows, self.cols, self.slices, self.gens, self.waves_per_gen, self.rows_per_wave,
+                                     self.streams, 0, self.n_steps, self.n_parts, self.n_hub, p(self.words), p(self.vals),
+                                     p(self.wave_step_off), p(self.wave_row), p(self.wave_part), p(self.hub_row), p(self.hub_off))
+
+    def workspace(self) -> torch.Tensor:
+        import ctypes
+        ps = self.struct()
+        nbytes = cabi.lib().isplib_spmm_stream_workspace_bytes(ctypes.byref(ps))
+        return torch.empty(nbytes, dtype=torch.uint8, device=self.words.device)
+
+    def set_values(self, val: Optional[torch.Tensor]) -> None:
+        """Weights in stream order (None = unit weights): one gather through `perm`, for callers whose weights change."""
+        if val is None:
+            self.vals = None
+            return
+        ok = self.perm >= 0
+        out = torch.zeros(self.perm.numel(), dtype=torch.float32, device=self.perm.device)
+        out[ok] = val.detach().to(torch.float32)[self.perm[ok].to(torch.int64)]
+        self.vals = out
+
+
+def stream_plan_arrays(rowptr: torch.Tensor, col: torch.Tensor, ncols: int, slices: int, waves_per_gen: int,
+                       rows_per_wave: int = 16, streams: int = 4, chunk: int = 2048) -> dict:
+    """The arrays of a stream plan; plain torch ops on the device of `col` (once per graph and geometry).
+
+      * rows over `chunk` edges are cut evenly into virtual rows;
+      * virtual rows are dealt longest first, back and forth, to the gens*waves_per_gen*streams STREAMS (a stream =
+        one slot of one wave, rows_per_wave / streams rows): equal rows and, within a fraction of a percent, equal
+        edges per stream; `streams` neighbouring streams form a wave and advance together;
+      * a stream lists its rows' edges slice by slice (then row by row, then in CSR order) as words
+        (local row << 27) | column; streams of a wave are interleaved step by step and padded to the longest."""
+    assert 1 <= slices <= 4096 and rows_per_wave in (16, 32) and streams in (2, 4, 8) and waves_per_gen >= 1
+    assert ncols < (1 << 27), "column ids share a 32-bit word with the local row"
+    m = rowptr.numel() - 1
+    dev = col.device
+    i64 = dict(dtype=torch.int64, device=dev)
+    nnz = col.numel()
+    deg = rowptr[1:] - rowptr[:-1]
+    nchunk = ((deg + chunk - 1) // chunk).clamp(min=1)
+    csize = (deg + nchunk - 1) // nchunk
+    nv = int(nchunk.sum())
+    vrow = torch.repeat_interleave(torch.arange(m, **i64), nchunk)
+    first = torch.cumsum(nchunk, 0) - nchunk
+    ci = torch.arange(nv, **i64) - first[vrow]
+    vb = rowptr[vrow] + ci * csize[vrow]
+    ve = torch.minimum(vb + csize[vrow], rowptr[vrow + 1])
+    vb = torch.minimum(vb, ve)
+    vlen = ve - vb
+    per = rows_per_wave // streams                              # rows of a stream
+    gens = max(1, -(-nv // (waves_per_gen * rows_per_wave)))
+    nw = gens * waves_per_gen
+    ns = nw * streams
+    order = torch.sort(vlen, descending=True, stable=True).indices
+    rank = torch.empty(nv, **i64)
+    rank[order] = torch.arange(nv, **i64)
+    rnd, pos = rank // ns, rank % ns
+    sid = torch.where(rnd % 2 == 0, pos, ns - 1 - pos)           # stream of the virtual row
+    wave, slot = sid // streams, sid % streams
+    lrow = slot * per + rnd                                      # local row inside the wave
+    is_hub = nchunk[vrow] > 1
+    part = torch.where(is_hub, torch.cumsum(is_hub.to(torch.int64), 0) - 1, torch.full((nv,), -1, **i64))
+    wave_row = torch.full((nw * rows_per_wave,), -1, dtype=torch.int32, device=dev)
+    wave_part = torch.full((nw * rows_per_wave,), -1, dtype=torch.int32, device=dev)
+    at = wave * rows_per_wave + lrow
+    wave_row[at] = vrow.to(torch.int32)
+    wave_part[at] = part.to(torch.int32)
+    hub_rows = torch.nonzero(nchunk > 1).flatten()
+    hub_off = torch.zeros(hub_rows.numel() + 1, dtype=torch.int32, device=dev)
+    if hub_rows.numel():
+        hub_off[1:] = torch.cumsum(nchunk[hub_rows], 0).to(torch.int32)
+    # the edges, stream by stream: (stream, slice, row of the stream) then CSR order (stable sort)
+    width = -(-ncols // slices)
+    ev = torch.repeat_interleave(torch.arange(nv, **i64), vlen)                  # edge -> virtual row (CSR order)
+    key = (sid[ev] * slices + col // width) * per + rnd[ev]
+    perm = torch.sort(key, stable=True).indices
+    del key
+    e_sid = sid[ev][perm]
+    lens = torch.bincount(e_sid, minlength=ns)
+    start = torch.cumsum(lens, 0) - lens
+    p = torch.arange(nnz, **i64) - start[e_sid]                                  # position inside the stream
+    steps = lens.view(nw, streams).max(dim=1).values
+    wave_step_off = torch.zeros(nw + 1, **i64)
+    wave_step_off[1:] = torch.cumsum(steps, 0)
+    n_steps = int(wave_step_off[-1])
+    idx = (wave_step_off[e_sid // streams] + p) * streams + e_sid % streams
+    del p, start
+    words = torch.full((n_steps * streams,), int(ncols), dtype=torch.int32, device=dev)
+    words[idx] = ((lrow[ev][perm] << 27) | col[perm]).to(torch.int32)
+    perm_out = torch.full((n_steps * streams,), -1, dtype=torch.int32 if nnz < 2 ** 31 else torch.int64, device=dev)
+    perm_out[idx] = perm.to(perm_out.dtype)
+    return dict(rows=m, cols=int(ncols), slices=slices, gens=gens, waves_per_gen=waves_per_gen, rows_per_wave=rows_per_wave,
+                streams=streams, n_steps=n_steps, n_parts=int(is_hub.sum()), n_hub=int(hub_rows.numel()), words=words, vals=None,
+                perm=perm_out, wave_step_off=wave_step_off, wave_row=wave_row, wave_part=wave_part,
+                hub_row=hub_rows.to(torch.int32), hub_off=hub_off, chunk=chunk)
+
+
+def build_stream_plan(rowptr: torch.Tensor, col: torch.Tensor, val: Optional[torch.Tensor], ncols: int, slices: int,
+                      waves_per_gen: Optional[int] = None, rows_per_wave: int = 16, streams: int = 4,
+                      chunk: int = 2048) -> Optional[StreamPlan]:
+    """Stream plan of a graph on the device.  None when the rows are not column-sorted (a row's edges would then not
+    be met in ascending CSR order inside a slice -- the order every other schedule and the oracle use) or n >= 2^27."""
+    if ncols >= (1 << 27):
+        return None
+    if waves_per_gen is None:
+        waves_per_gen = int(cabi.lib().isplib_spmm_stream_resident_waves(streams, rows_per_wave))
+    plan = StreamPlan(**stream_plan_arrays(rowptr, col, ncols, slices, waves_per_gen, rows_per_wave, streams, chunk))
+    plan.set_values(val)
+    return plan

@@ -5,7 +5,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from isplib_amd import cabi, synth
-from isplib_amd.plan import build_sweep_plan, build_task_plan
+from isplib_amd.plan import build_stream_plan, build_sweep_plan, build_task_plan
 
 dev = torch.device("cuda:0")
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 128
@@ -38,7 +38,11 @@ msg = cabi.MESSAGE[red]
 out = torch.empty((n, k), device=dev)
 arg = torch.empty((n, k), dtype=torch.int64, device=dev) if red in ("max", "min") else None
 s_def = int(cabi.lib().isplib_suggest_slices(n, n, nnz, k, int(red in ("max", "min"))))
-if s_def > 0:
+only = os.environ.get("ONLY_SWEEP") == "1"
+ref = None
+if only:
+    pass
+elif s_def > 0:
     tp = build_task_plan(rowptr, col, n, s_def, col32=col32)
     tw = tp.workspace(red, k)
     t = timeit(lambda: cabi.fusedMM_csr_tasks_hip(msg, rowptr, col, None, tp, x, out, arg, tw))
@@ -51,8 +55,28 @@ else:
     print(f"plain: {t:.3f} ms  {nnz / t / 1e6:.2f} Gedges/s", flush=True)
     ref = out.clone()
 
+# stream form: STREAMS=slices:rows_per_wave:streams:chunk,...
+sgeoms = os.environ.get("STREAMS", "16:16:4:2048,32:16:4:2048,64:16:4:2048,32:32:4:2048" if red in ("sum", "mean") else "")
+for sg in filter(None, sgeoms.split(",")):
+    S, rpw, streams, chunk = (int(v) for v in sg.split(":"))
+    wpg = int(os.environ.get("WPG", cabi.lib().isplib_spmm_stream_resident_waves(streams, rpw)))
+    torch.cuda.synchronize()
+    plan = build_stream_plan(rowptr, col, None, n, S, wpg, rpw, streams, chunk)
+    ws = plan.workspace()
+    steps = plan.wave_step_off[1:] - plan.wave_step_off[:-1]
+    cabi.fusedMM_csr_stream_hip(msg, rowptr, nnz, plan, x, out, ws)
+    torch.cuda.synchronize()
+    err = (out - ref).abs().max().item() if ref is not None else float("nan")
+    t = timeit(lambda: cabi.fusedMM_csr_stream_hip(msg, rowptr, nnz, plan, x, out, ws))
+    print(f"stream S={S:3d} rows/wave={rpw:2d} streams={streams} chunk={chunk} gens={plan.gens} waves/gen={wpg} steps={plan.n_steps} "
+          f"(padding {plan.n_steps * streams / nnz - 1:.3%}) hub parts={plan.n_parts} steps max/mean={steps.max().item() / steps.double().mean().item():.3f}: "
+          f"{t:.3f} ms  {nnz / t / 1e6:.2f} Gedges/s  maxdiff vs tasks {err:.2e}", flush=True)
+    del plan, ws
+
 geoms = os.environ.get("GEOMS")
-if geoms:
+if geoms == "none":
+    geoms = []
+elif geoms:
     geoms = [tuple(int(v) for v in g.split(":")) for g in geoms.split(",")]
 else:
     geoms = [(s, rpw, 2048, ms) for s in (8, 16, 32) for rpw in (16,) for ms in (16,)] + [(16, 32, 2048, 16), (16, 16, 2048, 8), (16, 16, 1024, 32), (24, 16, 2048, 16)]
@@ -70,7 +94,7 @@ for (S, rpw, chunk, min_seg) in geoms:
     loads.index_add_(0, torch.repeat_interleave(torch.arange(loads.numel(), device=dev), cnt), lens)
     cabi.fusedMM_csr_sweep_hip(msg, rowptr, col, None, plan, x, out, arg, ws)
     torch.cuda.synchronize()
-    err = (out - ref).abs().max().item()
+    err = (out - ref).abs().max().item() if ref is not None else float("nan")
     t = timeit(lambda: cabi.fusedMM_csr_sweep_hip(msg, rowptr, col, None, plan, x, out, arg, ws))
     print(f"sweep S={S:3d} rows/wave={rpw:2d} chunk={chunk} min_seg={min_seg:2d} gens={plan.gens} waves/gen={wpg} tasks={plan.n_tasks} "
           f"(avg {nnz / max(plan.n_tasks, 1):.1f} edges) hub parts={plan.n_parts} load max/mean={loads.max().item() / loads.double().mean().item():.3f}: "

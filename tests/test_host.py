@@ -422,13 +422,16 @@ def test_sweep_plan_covers_every_edge_once_in_csr_order(geom):
         acc = np.zeros((rpw, 3))
         last_pos = np.full(rpw, -1, np.int64)
         last_key = -1
+        slot_edges = np.zeros(rpw, np.int64)
+        for t in range(off[w], off[w + 1]):
+            slot_edges[int(tm[t]) >> 24] += int(tm[t]) & 0xFFFFFF
         for t in range(off[w], off[w + 1]):
             slot, ln, b = int(tm[t]) >> 24, int(tm[t]) & 0xFFFFFF, int(tb[t])
             r = wr[w, slot]
             assert r >= 0 and ln > 0 and rowptr[r] <= b and b + ln <= rowptr[r + 1]
             assert b > last_pos[slot], "a row's tasks must come in ascending CSR order"
             last_pos[slot] = b
-            if min_seg == 1:                                   # no slice groups: a task's phase is the slice of its first edge
+            if min_seg == 1 and slot_edges[slot] >= slices:    # no slice groups: a task's phase is the slice of its first edge
                 key = int(col[b]) // width * rpw + slot
                 assert key > last_key, "a wave's tasks must be in (slice, slot) order"
                 last_key = key
