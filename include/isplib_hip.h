@@ -340,7 +340,7 @@ int    fusedMM_csr_sweep_hip(int32_t imessage, int64_t m, int64_t n, int64_t k, 
  * execute in order: every sum is formed in one fixed order (bitwise reproducible).  The panel width is
  * 256 / streams columns (streams = 4: 64 columns); k is swept in such panels.  Weights are part of the plan (`vals`,
  * in stream order; NULL = unit weights): a caller whose weights change refreshes them through `perm`.
- * Requirements as fusedMM_csr_sweep_hip, plus n < 2^27.
+ * Requirements as fusedMM_csr_sweep_hip, plus n < 2^24 and ldy < 2^22 (24-bit address arithmetic per edge).
  */
 typedef struct isplib_stream_plan {
    int64_t rows, cols;              /* m, n of the graph the plan was built for */

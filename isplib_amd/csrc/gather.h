@@ -209,20 +209,6 @@ __device__ __forceinline__ void buf_step(const __amdgpu_buffer_rsrc_t rsrc, unsi
    }
 }
 
-// the last, partial step of a batch: depth UU when more than half of it is used, else the next smaller depth
-template <int OP, bool HAS_VAL, int LPR, int NCH, int UU>
-__device__ __forceinline__ void buf_tail(const __amdgpu_buffer_rsrc_t rsrc, unsigned off_l, float v_l, int s, int cnt,
-                                         int rel0, int g, const unsigned (&cbyte)[NCH], const unsigned (&poison)[NCH],
-                                         const bool (&cok)[NCH], float (&acc)[NCH][4], int (&bi)[NCH][4]) {
-   constexpr int G = 64 / LPR;
-   if constexpr (UU <= 1) {
-      buf_step<OP, HAS_VAL, LPR, NCH, 1>(rsrc, off_l, v_l, s, cnt, rel0, g, cbyte, poison, cok, acc, bi);
-   } else {
-      if (cnt - s > G * (UU / 2)) buf_step<OP, HAS_VAL, LPR, NCH, UU>(rsrc, off_l, v_l, s, cnt, rel0, g, cbyte, poison, cok, acc, bi);
-      else buf_tail<OP, HAS_VAL, LPR, NCH, UU / 2>(rsrc, off_l, v_l, s, cnt, rel0, g, cbyte, poison, cok, acc, bi);
-   }
-}
-
 // metadata of the 64 edges [p0, p0 + 64) n [.., re): byte offset of the dense row (past the descriptor when masked), weight
 template <bool HAS_VAL, class Args>
 __device__ __forceinline__ void load_edge_batch(const Args &a, int64_t p0, int64_t re, unsigned ldyb, unsigned &off_l, float &v_l) {
@@ -242,6 +228,7 @@ __device__ __forceinline__ void wave_edges_buf(const Args &a, const __amdgpu_buf
                                                float (&acc)[NCH][4], int (&bi)[NCH][4], unsigned pre_off = 0u,
                                                float pre_val = 0.0f) {
    constexpr int G = 64 / LPR;
+   constexpr int UT = U >= 4 ? 2 : 1;   // tail granularity: fewer all-masked gathers on short segments
    const int lane = threadIdx.x & 63;
    const int g = lane / LPR;
    const unsigned ldyb = (unsigned)a.ldy * 4u;
@@ -262,10 +249,10 @@ __device__ __forceinline__ void wave_edges_buf(const Args &a, const __amdgpu_buf
       int s = 0;
       for (; s + G * U <= cnt; s += G * U)
          buf_step<OP, HAS_VAL, LPR, NCH, U>(rsrc, off_l, v_l, s, cnt, rel0, g, cbyte, poison, cok, acc, bi);
-      // The remainder (< G*U edges): at most two steps of half the depth (U/2 gathers in flight each), lanes past the
-      // end reading through the descriptor's range check (0, no memory traffic).  Steps of two gathers cost a
-      // 26-edge segment four dependent round trips to the L2; a cascade U, U/2, U/4, ... of single steps spills.
-      constexpr int UT = U >= 4 ? U / 2 : (U >= 2 ? U / 2 : 1);
+      // The remainder (< G*U edges) in steps of two gathers.  Deeper tail steps were tried in round 2 (U/2 gathers per
+      // step: fewer dependent round trips for a short segment) and lost: lanes past the end of a task still cost
+      // their slot in the address pipeline although the range check returns 0 without memory traffic (sweep
+      // schedule, 26-edge tasks: 3.83 -> 5.09 ms; task list unchanged).
       for (; s < cnt; s += G * UT)
          buf_step<OP, HAS_VAL, LPR, NCH, UT>(rsrc, off_l, v_l, s, cnt, rel0, g, cbyte, poison, cok, acc, bi);
    }

@@ -264,32 +264,22 @@ __global__ __launch_bounds__(256) void sweep_hub_fold_kernel(const SweepArgs a) 
 // 15 edges.  Here a wave does not see segments at all.  The plan gives each of the G = 64 / LPR slots of a wave its
 // own STREAM: the edges of the slot's NVMAX / G rows, slice by slice, as 4-byte words (local row << 27 | column) in
 // the plan's own copy of the index array.  Step i of a wave gathers word i of each of its G streams -- one 1-KiB
-// buffer load, always full -- and adds the four floats a lane receives into the LDS row the word names
-// (ds_add_f32 without return: LDS operations of a wave execute in order, and the slots of a wave own disjoint rows,
-// so every sum is formed in one fixed order; no two lanes of an instruction ever meet on an address).  U gathers
-// are in flight per wave at all times, across row and slice boundaries alike; there is no butterfly, no masked
-// tail, no per-segment bookkeeping.  Sum / mean only (a (value, id) pair has no LDS atomic).
-template <int G> __device__ __forceinline__ unsigned pick_lane(unsigned v, int first, int g) {
-   unsigned r = (unsigned)__builtin_amdgcn_readlane((int)v, first);
-#pragma unroll
-   for (int q = 1; q < G; q++) {
-      const unsigned o = (unsigned)__builtin_amdgcn_readlane((int)v, first + q);
-      r = g == q ? o : r;
-   }
-   return r;
-}
-
+// buffer load, always full -- and every lane adds the four floats it receives to the running sum of the row its
+// slot is on (registers), which moves to and from the slot's LDS row when the stream changes rows.  The slots of a
+// wave own disjoint rows and a wave's LDS operations execute in order, so every sum is formed in one fixed order.
+// U gathers are in flight per wave at all times, across row and slice boundaries alike; there is no butterfly, no
+// masked tail, no per-segment bookkeeping.  Sum / mean only.
 template <int LPR, int NVMAX> constexpr int stream_wgs_per_cu() {
-   return 163840 / (4 * (NVMAX * LPR * 4 + 32) * 4) < 8 ? 163840 / (4 * (NVMAX * LPR * 4 + 32) * 4) : 8;
+   return 163840 / (4 * NVMAX * LPR * 4 * 4) < 8 ? 163840 / (4 * NVMAX * LPR * 4 * 4) : 8;
 }
 
 template <int LPR, bool HAS_VAL, int NVMAX>
 __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, NVMAX>())) void spmm_stream_kernel(const SweepArgs a) {
-   // gathers in flight per wave: 8 where they fit 64 VGPRs (unit weights, 16 or 32 lanes per slot), else 4 (the weights
-   // and, at 8 lanes per slot, the eight-way lane pick need the registers; 8 spills there)
-   constexpr int WAVES = 4, G = 64 / LPR, PANEL = LPR * 4, SPB = 64 / G, U = (HAS_VAL || LPR == 8) ? 4 : 8;
-   constexpr int SKEWN = LPR < 32 ? 32 / LPR : 1;         // slots that share a 32-lane LDS group get disjoint banks
-   constexpr int WAVE_FLOATS = NVMAX * PANEL + 32;        // + room for the bank skew of the last row
+   // gathers in flight per wave: 4 (x 32 waves per CU = 128 KB in flight per CU); 8 need ~80 VGPRs with the running
+   // sum and the row bookkeeping, i.e. fewer resident waves
+   constexpr int WAVES = 4, G = 64 / LPR, PANEL = LPR * 4, SPB = 64 / G, U = 4;
+   constexpr int PER = NVMAX / G;                         // rows of a slot
+   constexpr int WAVE_FLOATS = NVMAX * PANEL;
    static_assert(SPB % U == 0, "ring indices must be static");
    __shared__ __attribute__((aligned(16))) float s_all[WAVES * WAVE_FLOATS];
    const int lane = threadIdx.x & 63;
@@ -304,65 +294,93 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, NVMAX>())) void spmm_s
    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.y), 0, (int)a.ybytes, 0x00020000);
    const bool cok = lc * 4 < a.k;
    const unsigned cbyte = (unsigned)lc * 16u, poison = cok ? 0u : BUF_OOB;
-   // a row of the panel is kept as [component v][lane lc]: the lanes of a slot add to consecutive banks
-   float *lane_base = my + (g % SKEWN) * LPR + lc;
+   float *lane_base = my + lc * 4;                        // a lane's four columns of a row are contiguous
    const int64_t s0 = a.wave_step_off[w], s1 = a.wave_step_off[w + 1];
    const int64_t nwords = (s1 - s0) * G;
    const int32_t *wp = a.words + s0 * G;
    const float *vp = HAS_VAL ? a.vals + s0 * G : nullptr;
    const unsigned ldyb = (unsigned)a.ldy * 4u;
-   auto load_batch = [&](int64_t first, unsigned &off, unsigned &row, float &val) {
+   // lane i of a batch holds word i = (step i / G, slot i % G); past the end of the wave: the padding word of the slot
+   // (column n: the gather reads 0 through the range check; the row stays inside the slot's own rows)
+   const unsigned pad_word = ((unsigned)((lane % G) * PER) << 27) | a.null_word;
+   auto load_batch = [&](int64_t first, unsigned &word, float &val) {
       const int64_t i = first + lane;
-      unsigned word = a.null_word;
+      word = pad_word;
       val = 0.0f;
       if (i < nwords) {
          word = (unsigned)wp[i];
          if (HAS_VAL) val = vp[i];
       }
-      off = (word & 0x7FFFFFFu) * ldyb;
-      row = (word >> 27) * (unsigned)PANEL;
    };
-   unsigned offA, offB, rowA, rowB;
+   unsigned wordA, wordB;
    float valA, valB;
-   load_batch(0, offA, rowA, valA);
-   load_batch(64, offB, rowB, valB);
+   load_batch(0, wordA, valA);
+   load_batch(64, wordB, valB);
    v4i_t t[U];
    unsigned la[U];
    float vv[U];
-   auto issue = [&](int slot, int step, unsigned off_l, unsigned row_l, float val_l) {
-      const unsigned o = (pick_lane<G>(off_l, step * G, g) + cbyte) | poison;
-      la[slot] = pick_lane<G>(row_l, step * G, g);
-      if (HAS_VAL) vv[slot] = __uint_as_float(pick_lane<G>(__float_as_uint(val_l), step * G, g));
+   // one ds_bpermute hands a slot its word of the step (the LDS pipe is otherwise idle here; picking it with
+   // v_readlane + v_cndmask cost 16 vector instructions per step and bounded the kernel at 16 TB/s from the L2);
+   // column * row pitch is a 24-bit multiply (n < 2^24, pitch < 2^24, product < 2^32: checked by the entry)
+   auto issue = [&](int slot, int step, unsigned word_l, float val_l) {
+      const unsigned word = (unsigned)__shfl((int)word_l, step * G + g);
+      const unsigned o = (__umul24(word & 0x7FFFFFFu, ldyb) + cbyte) | poison;
+      la[slot] = (word >> 27) * (unsigned)PANEL;
+      if (HAS_VAL) vv[slot] = __shfl(val_l, step * G + g);
       t[slot] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)o, 0, 0);
    };
 #pragma unroll
-   for (int u = 0; u < U; u++) issue(u, u, offA, rowA, valA);
+   for (int u = 0; u < U; u++) issue(u, u, wordA, valA);
+   // The row a slot is working on keeps its running sum in registers; it moves to the slot's LDS row when the stream
+   // turns to another row (every ~deg / slices edges) and is picked up again from there when the stream comes back
+   // in the next slice.  Plain read-add-write by the only lanes that ever touch that LDS row: LDS float atomics
+   // (one ds_add_f32 per gathered float) ran 25x slower than the gathers they were meant to keep up with.
+   unsigned cur = (unsigned)(g * PER * PANEL);
+   float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+   auto flush = [&]() {
+      float4 *p = reinterpret_cast<float4 *>(lane_base + cur);
+      float4 o = *p;
+      o.x += acc[0]; o.y += acc[1]; o.z += acc[2]; o.w += acc[3];
+      *p = o;
+   };
    const int64_t nb = (nwords + 63) / 64;
    for (int64_t b = 0; b < nb; b++) {
-#pragma unroll
-      for (int u = 0; u < SPB; u++) {
-         const int slot = u % U;
-         float *dst = lane_base + la[slot];
-#pragma unroll
-         for (int v = 0; v < 4; v++) {
-            const float x = __int_as_float(t[slot][v]);
-            __hip_atomic_fetch_add(dst + v * LPR, HAS_VAL ? vv[slot] * x : x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-         }
-         if (u + U < SPB) issue(slot, u + U, offA, rowA, valA);
-         else issue(slot, u + U - SPB, offB, rowB, valB);
-      }
-      offA = offB; rowA = rowB; valA = valB;
-      load_batch((b + 2) * 64, offB, rowB, valB);
-   }
-   // write-out: slot q owns the local rows [q * NVMAX / G, (q + 1) * NVMAX / G); its LPR lanes hold one row of the panel
+      // groups of U steps: the group's U gathers were issued one group earlier and are consumed in order, each
+      // consumed ring slot is refilled with the same step of the next group (from the next batch after the last group)
 #pragma unroll 1
-   for (int jj = 0; jj < NVMAX / G; jj++) {
-      const int lrow = g * (NVMAX / G) + jj;
+      for (int grp = 0; grp < SPB / U; grp++) {
+         const bool last = grp == SPB / U - 1;
+         const unsigned src_w = last ? wordB : wordA;
+         const float src_v = last ? valB : valA;
+         const int istep = last ? 0 : (grp + 1) * U;
+#pragma unroll
+         for (int u = 0; u < U; u++) {
+            if (la[u] != cur) {                          // per lane: the slots of a wave change rows at different steps
+               flush();
+               cur = la[u];
+               acc[0] = acc[1] = acc[2] = acc[3] = 0.0f;
+            }
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+               const float x = __int_as_float(t[u][v]);
+               acc[v] = HAS_VAL ? fmaf(vv[u], x, acc[v]) : acc[v] + x;
+            }
+            issue(u, istep + u, src_w, src_v);
+         }
+      }
+      wordA = wordB; valA = valB;
+      load_batch((b + 2) * 64, wordB, valB);
+   }
+   flush();
+   // write-out: slot q owns the local rows [q * PER, (q + 1) * PER); its LPR lanes hold one row of the panel
+#pragma unroll 1
+   for (int jj = 0; jj < PER; jj++) {
+      const int lrow = g * PER + jj;
       const int row = a.wave_row[(size_t)w * NVMAX + lrow];
       if (row < 0 || !cok) continue;
       const int part = a.wave_part[(size_t)w * NVMAX + lrow];
-      const float *src = lane_base + lrow * PANEL;
-      float v[4] = {src[0], src[LPR], src[2 * LPR], src[3 * LPR]};
+      const float4 t4 = *reinterpret_cast<const float4 *>(lane_base + lrow * PANEL);
+      float v[4] = {t4.x, t4.y, t4.z, t4.w};
       int bi[4] = {INT_MAX, INT_MAX, INT_MAX, INT_MAX};
       const int c = lc * 4;
       if (part >= 0) {
@@ -406,7 +424,7 @@ static int sweep_resident_waves(bool add, int64_t pk, int nvmax, int cus) {
 
 static int stream_resident_waves(int streams, int nvmax, int cus) {
    const int lpr = 64 / streams;
-   const int lds = 4 * (nvmax * lpr * 4 + 32) * 4;
+   const int lds = 4 * nvmax * lpr * 4 * 4;
    int wgs = 163840 / lds;
    if (wgs > 8) wgs = 8;
    return cus * wgs * 4;
@@ -570,7 +588,7 @@ extern "C" int fusedMM_csr_stream_hip(int32_t imessage, int64_t m, int64_t n, in
    if (m == 0 || k == 0) return ISPLIB_SUCCESS;
    if (!plan) return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: plan is required");
    if (plan->rows != m || plan->cols != n) return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: the plan was built for another shape");
-   if (n >= (1LL << 27)) return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: n must be < 2^27 (column ids share a word with the local row)");
+   if (n >= (1LL << 24) || ldy >= (1LL << 22)) return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: n must be < 2^24 and ldy < 2^22 (24-bit address arithmetic)");
    if (plan->gens < 1 || plan->waves_per_gen < 1 || (plan->rows_per_wave != 16 && plan->rows_per_wave != 32) ||
        (plan->streams != 2 && plan->streams != 4 && plan->streams != 8))
       return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: bad plan geometry (rows_per_wave 16 or 32, streams 2, 4 or 8)");

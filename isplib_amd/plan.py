@@ -268,7 +268,7 @@ def stream_plan_arrays(rowptr: torch.Tensor, col: torch.Tensor, ncols: int, slic
       * a stream lists its rows' edges slice by slice (then row by row, then in CSR order) as words
         (local row << 27) | column; streams of a wave are interleaved step by step and padded to the longest."""
     assert 1 <= slices <= 4096 and rows_per_wave in (16, 32) and streams in (2, 4, 8) and waves_per_gen >= 1
-    assert ncols < (1 << 27), "column ids share a 32-bit word with the local row"
+    assert ncols < (1 << 24), "column ids share a 32-bit word with the local row and are multiplied in 24 bits"
     m = rowptr.numel() - 1
     dev = col.device
     i64 = dict(dtype=torch.int64, device=dev)
@@ -322,7 +322,9 @@ def stream_plan_arrays(rowptr: torch.Tensor, col: torch.Tensor, ncols: int, slic
     n_steps = int(wave_step_off[-1])
     idx = (wave_step_off[e_sid // streams] + p) * streams + e_sid % streams
     del p, start
-    words = torch.full((n_steps * streams,), int(ncols), dtype=torch.int32, device=dev)
+    # padding: column n (reads 0 through the range check), row = the first row of the word's own stream
+    pad = ((torch.arange(streams, **i64) * per) << 27) | int(ncols)
+    words = pad.to(torch.int32).repeat(n_steps)
     words[idx] = ((lrow[ev][perm] << 27) | col[perm]).to(torch.int32)
     perm_out = torch.full((n_steps * streams,), -1, dtype=torch.int32 if nnz < 2 ** 31 else torch.int64, device=dev)
     perm_out[idx] = perm.to(perm_out.dtype)
@@ -336,8 +338,8 @@ def build_stream_plan(rowptr: torch.Tensor, col: torch.Tensor, val: Optional[tor
                       waves_per_gen: Optional[int] = None, rows_per_wave: int = 16, streams: int = 4,
                       chunk: int = 2048) -> Optional[StreamPlan]:
     """Stream plan of a graph on the device.  None when the rows are not column-sorted (a row's edges would then not
-    be met in ascending CSR order inside a slice -- the order every other schedule and the oracle use) or n >= 2^27."""
-    if ncols >= (1 << 27):
+    be met in ascending CSR order inside a slice -- the order every other schedule and the oracle use) or n >= 2^24."""
+    if ncols >= (1 << 24):
         return None
     if waves_per_gen is None:
         waves_per_gen = int(cabi.lib().isplib_spmm_stream_resident_waves(streams, rows_per_wave))

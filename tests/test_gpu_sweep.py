@@ -134,3 +134,119 @@ def test_sweep_status_codes(gpu):
     bad = torch.cat([d_rowptr, d_rowptr[-1:]])    # another row count than the plan's
     assert cabi.fusedMM_csr_sweep_hip(cabi.MSG_SPMM_SUM, bad, d_col, None, plan, x, z, None, check=False) == 1
     assert cabi.fusedMM_csr_sweep_hip(0x11101, d_rowptr, d_col, None, plan, x, z[:40], None, check=False) == 128
+
+
+# ---- stream form (fusedMM_csr_stream_hip): sum / mean, the plan owns the edges in walking order ---------------------
+
+def _stream_all(gpu, oracle, rowptr, col, val, x, unit=False, geoms=((8, 64, 16, 4, 64), (5, 24, 32, 8, 2048), (16, 7, 16, 2, 100), (3, 9, 32, 4, 300))):
+    """geoms: (slices, waves_per_gen, rows_per_wave, streams, chunk)"""
+    from isplib_amd import cabi
+    from isplib_amd.plan import build_stream_plan
+    d_rowptr, d_col, d_x = _t(rowptr, gpu), _t(col, gpu), _t(x, gpu)
+    d_val = None if unit else _t(val, gpu)
+    for (s, wpg, rpw, streams, chunk) in geoms:
+        plan = build_stream_plan(d_rowptr, d_col, d_val, x.shape[0], s, wpg, rpw, streams, chunk)
+        assert plan is not None and int((plan.perm >= 0).sum()) == col.size
+        for red in ("sum", "mean"):
+            out = cabi.spmm_stream(d_rowptr, col.size, plan, d_x, red)
+            again = cabi.spmm_stream(d_rowptr, col.size, plan, d_x, red)
+            torch.cuda.synchronize()
+            assert torch.equal(out.view(torch.int32), again.view(torch.int32)), "stream schedule must be bitwise reproducible"
+            _check(oracle, rowptr, col, val, x, red, out, None)
+
+
+@pytest.mark.parametrize("k", (4, 16, 32, 64, 100, 128, 256, 600))
+def test_stream_widths_weighted(gpu, oracle_mod, k):
+    rowptr, col = cases.random_csr(300, 257, 9.0, seed=10 + k, empty_rows=(0, 150, 299))
+    val = cases.weights(col.size, 4)
+    x = cases.dense(257, k, 3)
+    _stream_all(gpu, oracle_mod, rowptr, col, val, x)
+
+
+@pytest.mark.parametrize("k", (16, 64, 128))
+def test_stream_unit_weights(gpu, oracle_mod, k):
+    rowptr, col = cases.random_csr(200, 200, 12.0, seed=77)
+    val = cases.weights(col.size, 0, "unit")
+    x = cases.dense(200, k, 3)
+    _stream_all(gpu, oracle_mod, rowptr, col, val, x, unit=True)
+
+
+@pytest.mark.parametrize("kind", ("integer", "signed_zero", "nonfinite", "denormal"))
+def test_stream_special_values(gpu, oracle_mod, kind):
+    """Integer operands make the sums exact (any order must give the oracle's bits); NaN / Inf propagate through the
+    LDS adds; subnormal products and sums are not flushed."""
+    from isplib_amd import cabi
+    from isplib_amd.plan import build_stream_plan
+    rowptr, col = cases.random_csr(128, 96, 20.0, seed=5, empty_rows=(3,), duplicates=True)
+    val = cases.weights(col.size, 4, "signed_int")
+    x = cases.dense(96, 64, 3, kind)
+    _stream_all(gpu, oracle_mod, rowptr, col, val, x)
+    if kind in ("integer", "signed_zero", "denormal"):
+        plan = build_stream_plan(_t(rowptr, gpu), _t(col, gpu), _t(val, gpu), 96, 4, 16, 16, 4, 64)
+        out = cabi.spmm_stream(_t(rowptr, gpu), col.size, plan, _t(x, gpu), "sum").cpu().numpy()
+        ref, _ = oracle_mod.spmm_fw(rowptr, col, val, x, "sum")
+        if kind == "denormal":
+            assert np.any((np.abs(ref) > 0) & (np.abs(ref) < np.finfo(np.float32).tiny)), "case must produce subnormal sums"
+            assert np.all(np.abs(out.astype(np.float64) - ref.astype(np.float64)) <= 1e-5 * np.abs(ref) + 1e-44 * 64)
+        else:
+            assert np.array_equal(out, ref)
+
+
+@pytest.mark.parametrize("k", (32, 128))
+def test_stream_hub_row_is_cut_into_virtual_rows(gpu, oracle_mod, k):
+    rowptr, col = cases.random_csr(64, 400, 6.0, seed=9, empty_rows=(0, 63), hub=(17, 12345), duplicates=True)
+    val = cases.weights(col.size, 4, "signed_int")
+    x = cases.dense(400, k, 3, "integer")
+    _stream_all(gpu, oracle_mod, rowptr, col, val, x)
+
+
+def test_stream_rectangular_strided_epilogue_and_new_weights(gpu, oracle_mod):
+    from isplib_amd import cabi
+    from isplib_amd.plan import build_stream_plan
+    rowptr, col = cases.random_csr(90, 333, 25.0, seed=3, hub=(5, 900))
+    val = cases.weights(col.size, 4)
+    k, ld = 48, 64
+    xfull = cases.dense(333, ld, 3)
+    x = np.ascontiguousarray(xfull[:, :k])
+    d_rowptr, d_col = _t(rowptr, gpu), _t(col, gpu)
+    d_x = _t(xfull, gpu)[:, :k]
+    plan = build_stream_plan(d_rowptr, d_col, _t(val, gpu), 333, 4, 16, 16, 4, 256)
+    zfull = torch.full((90, ld), 7.0, device=gpu)
+    z = zfull[:, :k]
+    cabi.fusedMM_csr_stream_hip(cabi.MSG_SPMM_SUM, d_rowptr, col.size, plan, d_x, z, plan.workspace())
+    torch.cuda.synchronize()
+    _check(oracle_mod, rowptr, col, val, x, "sum", z.contiguous(), None)
+    assert bool((zfull[:, k:] == 7.0).all()), "columns beyond k must not be touched"
+    # weights replaced: one gather through the plan's permutation, same plan
+    val2 = cases.weights(col.size, 99)
+    plan.set_values(_t(val2, gpu))
+    out = cabi.spmm_stream(d_rowptr, col.size, plan, _t(x, gpu), "mean")
+    _check(oracle_mod, rowptr, col, val2, x, "mean", out, None)
+    # epilogue on a square unit-weight graph
+    rowptr, col = cases.random_csr(150, 150, 15.0, seed=21, empty_rows=(4,), hub=(9, 700))
+    x = cases.dense(150, 64, 3)
+    ones = np.ones(col.size, np.float32)
+    d_rowptr, d_col, d_x = _t(rowptr, gpu), _t(col, gpu), _t(x, gpu)
+    plan = build_stream_plan(d_rowptr, d_col, None, 150, 4, 8, 16, 4, 128)
+    rs = cases.dense(150, 1, 8)[:, 0].copy()
+    bias = cases.dense(1, 64, 9)[0].copy()
+    out = cabi.spmm_stream(d_rowptr, col.size, plan, d_x, "sum", row_scale=_t(rs, gpu), self_term=d_x, bias=_t(bias, gpu), relu=True)
+    ref, _ = oracle_mod.spmm_fw(rowptr, col, ones, x, "sum")
+    want = np.maximum(rs[:, None] * (ref + x) + bias[None, :], 0.0)
+    tol = cases.sum_tolerance(oracle_mod, rowptr, col, ones, x) * np.abs(rs[:, None]) + 1e-6
+    assert np.all(np.abs(out.cpu().numpy() - want) <= tol)
+
+
+def test_stream_status_codes(gpu):
+    from isplib_amd import cabi
+    from isplib_amd.plan import build_stream_plan
+    rowptr, col = cases.random_csr(40, 40, 5.0, seed=1)
+    d_rowptr, d_col = _t(rowptr, gpu), _t(col, gpu)
+    plan = build_stream_plan(d_rowptr, d_col, None, 40, 2, 4, 16, 4)
+    x, z = torch.zeros((40, 8), device=gpu), torch.zeros((40, 8), device=gpu)
+    assert cabi.fusedMM_csr_stream_hip(cabi.MSG_SPMM_MAX, d_rowptr, col.size, plan, x, z, check=False) == 128      # sum / mean only
+    x6, z6 = torch.zeros((40, 6), device=gpu), torch.zeros((40, 6), device=gpu)
+    assert cabi.fusedMM_csr_stream_hip(cabi.MSG_SPMM_SUM, d_rowptr, col.size, plan, x6, z6, check=False) == 1       # k % 4
+    x41 = torch.zeros((41, 8), device=gpu)
+    assert cabi.fusedMM_csr_stream_hip(cabi.MSG_SPMM_SUM, d_rowptr, col.size, plan, x41, z, check=False) == 1       # other n than the plan's
+    assert cabi.fusedMM_csr_stream_hip(cabi.MSG_SPMM_SUM, d_rowptr, col.size, plan, x, z, check=False) == 0
