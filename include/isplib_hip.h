@@ -332,21 +332,25 @@ int    fusedMM_csr_sweep_hip(int32_t imessage, int64_t m, int64_t n, int64_t k, 
 /*
  * Stream form of the sweep schedule (sum / mean): the plan additionally owns a COPY of the edges in the order the
  * waves walk them, so a wave never sees a row or slice boundary.  Each of the `streams` (= 64 / lanes per row slot)
- * slots of a wave owns rows_per_wave / streams rows and a stream of 4-byte words, (local row << 27) | column, that
+ * slots of a wave owns rows_per_wave / streams rows and a stream of 4-byte words, (local row << 24) | column, that
  * lists those rows' edges slice by slice; step i of a wave gathers word i of each of its streams in ONE full 1-KiB
- * buffer load and adds what arrives to the LDS row the word names (ds_add_f32, no return).  U gathers are in flight
- * per wave at all times; there are no per-segment latency chains, no masked tails and no cross-lane reduction.
- * No two lanes of an instruction, and no two waves, ever add to the same LDS word, and a wave's LDS operations
- * execute in order: every sum is formed in one fixed order (bitwise reproducible).  The panel width is
- * 256 / streams columns (streams = 4: 64 columns); k is swept in such panels.  Weights are part of the plan (`vals`,
- * in stream order; NULL = unit weights): a caller whose weights change refreshes them through `perm`.
+ * buffer load, and every lane adds what arrives to the running sum of the row its slot is on (registers), which
+ * moves to and from the slot's LDS row when the stream changes rows.  16 or 32 gathers are in flight per wave at all
+ * times; there are no per-segment latency chains, no masked tails, no cross-lane reduction, no partial rows, no fold.
+ * The slots of a wave own disjoint rows and a wave's LDS operations execute in order: every sum is formed in one
+ * fixed order (bitwise reproducible).  The panel width is 256 / streams columns (streams = 4: 64 columns); k is
+ * swept in such panels.  Weights are part of the plan (`vals`, in stream order; NULL = unit weights): a caller whose
+ * weights change refreshes them through the plan's permutation.  A launch holds few, deep waves (2 or 3 per SIMD):
+ * isplib_spmm_stream_geometry reports the rows per wave the kernel of a slot width is built for and the waves the
+ * device holds at once (what waves_per_gen should be: persistent waves only stay on the same slices -- and the slices
+ * in the L2 -- when they all start together).
  * Requirements as fusedMM_csr_sweep_hip, plus n < 2^24 and ldy < 2^22 (24-bit address arithmetic per edge).
  */
 typedef struct isplib_stream_plan {
    int64_t rows, cols;              /* m, n of the graph the plan was built for */
-   int32_t slices, gens, waves_per_gen, rows_per_wave /* 16 or 32 */, streams /* 2, 4 or 8 */, reserved;
+   int32_t slices, gens, waves_per_gen, rows_per_wave, streams /* 2, 4 or 8 */, reserved;
    int64_t n_steps, n_parts, n_hub;
-   const int32_t *words;            /* [dev] n_steps*streams: (local row << 27) | column; padding = (0 << 27) | n */
+   const int32_t *words;            /* [dev] n_steps*streams: (local row << 24) | column; padding = (own row << 24) | n */
    const float   *vals;             /* [dev] n_steps*streams weights in the same order, or NULL */
    const int64_t *wave_step_off;    /* [dev] gens*waves_per_gen + 1: first step of a wave */
    const int32_t *wave_row;         /* [dev] gens*waves_per_gen*rows_per_wave: row of the local row, -1 = unused */
@@ -354,7 +358,7 @@ typedef struct isplib_stream_plan {
    const int32_t *hub_row;          /* [dev] n_hub */
    const int32_t *hub_off;          /* [dev] n_hub + 1 */
 } isplib_stream_plan;
-int    isplib_spmm_stream_resident_waves(int streams, int rows_per_wave);
+int    isplib_spmm_stream_geometry(int streams, int *rows_per_wave /*out*/, int *waves_resident /*out*/);
 size_t isplib_spmm_stream_workspace_bytes(const isplib_stream_plan *plan);
 int    fusedMM_csr_stream_hip(int32_t imessage /* ISPLIB_MSG_SPMM_SUM | _MEAN */, int64_t m, int64_t n, int64_t k,
                               int64_t nnz, const int64_t *pntrb, const int64_t *pntre,

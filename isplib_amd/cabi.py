@@ -52,7 +52,7 @@ EXPORTS = (
     "isplib_suggest_slices", "isplib_graph_create", "isplib_graph_set_slices", "isplib_graph_spmm", "isplib_graph_spmm_backward",
     "isplib_graph_destroy", "isplib_suggest_slices_whole_rows", "isplib_graph_sddmm",
     "fusedMM_csr_sweep_hip", "isplib_spmm_sweep_workspace_bytes", "isplib_spmm_sweep_resident_waves",
-    "fusedMM_csr_stream_hip", "isplib_spmm_stream_workspace_bytes", "isplib_spmm_stream_resident_waves",
+    "fusedMM_csr_stream_hip", "isplib_spmm_stream_workspace_bytes", "isplib_spmm_stream_geometry",
 )
 
 _i64, _f32, _vp, _i32 = ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_int32
@@ -81,8 +81,8 @@ class StreamPlanStruct(ctypes.Structure):  # isplib_stream_plan
                 ("waves_per_gen", ctypes.c_int32), ("rows_per_wave", ctypes.c_int32), ("streams", ctypes.c_int32),
                 ("reserved", ctypes.c_int32), ("n_steps", ctypes.c_int64), ("n_parts", ctypes.c_int64), ("n_hub", ctypes.c_int64),
                 ("words", ctypes.c_void_p), ("vals", ctypes.c_void_p), ("wave_step_off", ctypes.c_void_p),
-                ("wave_row", ctypes.c_void_p), ("wave_part", ctypes.c_void_p), ("hub_row", ctypes.c_void_p),
-                ("hub_off", ctypes.c_void_p)]
+                ("wave_row", ctypes.c_void_p), ("wave_part", ctypes.c_void_p),
+                ("hub_row", ctypes.c_void_p), ("hub_off", ctypes.c_void_p)]
 
 
 _sigs_set = False
@@ -169,8 +169,8 @@ def lib() -> ctypes.CDLL:
         L.isplib_graph_destroy.argtypes = [_vp]
         L.isplib_hip_tune.restype = ctypes.c_int
         L.isplib_hip_tune.argtypes = [ctypes.c_int, ctypes.c_int]
-        L.isplib_spmm_stream_resident_waves.restype = ctypes.c_int
-        L.isplib_spmm_stream_resident_waves.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.isplib_spmm_stream_geometry.restype = ctypes.c_int
+        L.isplib_spmm_stream_geometry.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
         L.isplib_spmm_stream_workspace_bytes.restype = ctypes.c_size_t
         L.isplib_spmm_stream_workspace_bytes.argtypes = [ctypes.POINTER(StreamPlanStruct)]
         L.fusedMM_csr_stream_hip.restype = ctypes.c_int
@@ -585,6 +585,13 @@ def spmm_stream(rowptr, nnz: int, plan, y, reduce: str = "sum", workspace=None, 
                       k if self_term is None else self_term.stride(0), None if bias is None else bias.data_ptr(), int(bool(relu)))
     fusedMM_csr_stream_hip(MESSAGE[reduce], rowptr, nnz, plan, y, out, workspace, ep)
     return out
+
+
+def stream_geometry(streams: int = 4):
+    """(rows per wave, resident waves) of the stream kernel for `streams` slots per wave (isplib_spmm_stream_geometry)."""
+    rpw, res = ctypes.c_int(0), ctypes.c_int(0)
+    _check(lib().isplib_spmm_stream_geometry(int(streams), ctypes.byref(rpw), ctypes.byref(res)), "isplib_spmm_stream_geometry")
+    return rpw.value, res.value
 
 
 def sweep_resident_waves(reduce: str, k: int, rows_per_wave: int = 16) -> int:

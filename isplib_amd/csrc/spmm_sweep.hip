@@ -24,6 +24,17 @@
 #include "common.h"
 #include "gather.h"
 
+// geometry of the 64-column stream kernel (compile-time: rows per wave, 64-word batch registers per lane, workgroups per CU)
+#ifndef ISPLIB_STREAM_NV4
+#define ISPLIB_STREAM_NV4 64
+#endif
+#ifndef ISPLIB_STREAM_NBW4
+#define ISPLIB_STREAM_NBW4 2
+#endif
+#ifndef ISPLIB_STREAM_WGS4
+#define ISPLIB_STREAM_WGS4 2
+#endif
+
 namespace isplib {
 
 struct SweepArgs {
@@ -269,18 +280,20 @@ __global__ __launch_bounds__(256) void sweep_hub_fold_kernel(const SweepArgs a) 
 // wave own disjoint rows and a wave's LDS operations execute in order, so every sum is formed in one fixed order.
 // U gathers are in flight per wave at all times, across row and slice boundaries alike; there is no butterfly, no
 // masked tail, no per-segment bookkeeping.  Sum / mean only.
-template <int LPR, int NVMAX> constexpr int stream_wgs_per_cu() {
-   return 163840 / (4 * NVMAX * LPR * 4 * 4) < 8 ? 163840 / (4 * NVMAX * LPR * 4 * 4) : 8;
+// Geometry of the stream kernel.  Persistent waves only stay on the same column slices while FEW of them share a SIMD:
+// a SIMD's memory instructions go to its oldest ready wave first, so with 8 waves per SIMD the waves of a CU finish
+// one after the other (L2 hit rate 48 % at 32 slices; 67-75 % with 4; the compulsory misses only with 2).  The bytes
+// in flight that keep a CU's address pipeline busy (~256 KB) therefore come from depth, not from occupancy:
+// WGS workgroups (of 4 waves, one per SIMD) per CU, each wave with U = 64 * NBW / G gathers of 1 KiB in flight.
+template <int LPR, int NVMAX, int WGS> constexpr int stream_wgs_per_cu() {
+   return 163840 / (4 * NVMAX * LPR * 4 * 4) < WGS ? 163840 / (4 * NVMAX * LPR * 4 * 4) : WGS;
 }
 
-template <int LPR, bool HAS_VAL, int NVMAX>
-__global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, NVMAX>())) void spmm_stream_kernel(const SweepArgs a) {
-   // gathers in flight per wave: 4 (x 32 waves per CU = 128 KB in flight per CU); 8 need ~80 VGPRs with the running
-   // sum and the row bookkeeping, i.e. fewer resident waves
-   constexpr int WAVES = 4, G = 64 / LPR, PANEL = LPR * 4, SPB = 64 / G, U = 4;
+template <int LPR, bool HAS_VAL, int NVMAX, int NBW, int WGS>
+__global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, NVMAX, WGS>())) void spmm_stream_kernel(const SweepArgs a) {
+   constexpr int WAVES = 4, G = 64 / LPR, PANEL = LPR * 4, U = 64 * NBW / G;     // a batch = NBW x 64 words = U steps
    constexpr int PER = NVMAX / G;                         // rows of a slot
    constexpr int WAVE_FLOATS = NVMAX * PANEL;
-   static_assert(SPB % U == 0, "ring indices must be static");
    __shared__ __attribute__((aligned(16))) float s_all[WAVES * WAVE_FLOATS];
    const int lane = threadIdx.x & 63;
    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -300,37 +313,41 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, NVMAX>())) void spmm_s
    const int32_t *wp = a.words + s0 * G;
    const float *vp = HAS_VAL ? a.vals + s0 * G : nullptr;
    const unsigned ldyb = (unsigned)a.ldy * 4u;
-   // lane i of a batch holds word i = (step i / G, slot i % G); past the end of the wave: the padding word of the slot
-   // (column n: the gather reads 0 through the range check; the row stays inside the slot's own rows)
-   const unsigned pad_word = ((unsigned)((lane % G) * PER) << 27) | a.null_word;
-   auto load_batch = [&](int64_t first, unsigned &word, float &val) {
-      const int64_t i = first + lane;
-      word = pad_word;
-      val = 0.0f;
-      if (i < nwords) {
-         word = (unsigned)wp[i];
-         if (HAS_VAL) val = vp[i];
+   // lane i of batch register q holds word q*64 + i = (step (q*64 + i) / G, slot i % G); past the end of the wave: the
+   // padding word of the slot (column n: the gather reads 0 through the range check; the row is one of the slot's own)
+   const unsigned pad_word = ((unsigned)((lane % G) * PER) << 24) | a.null_word;
+   auto load_batch = [&](int64_t first, unsigned (&word)[NBW], float (&val)[NBW]) {
+#pragma unroll
+      for (int q = 0; q < NBW; q++) {
+         const int64_t i = first + q * 64 + lane;
+         word[q] = pad_word;
+         val[q] = 0.0f;
+         if (i < nwords) {
+            word[q] = (unsigned)wp[i];
+            if (HAS_VAL) val[q] = vp[i];
+         }
       }
    };
-   unsigned wordA, wordB;
-   float valA, valB;
-   load_batch(0, wordA, valA);
-   load_batch(64, wordB, valB);
+   unsigned w1[NBW], w2[NBW];                             // the words of the next batch and of the one after it
+   float v1[NBW], v2[NBW];
    v4i_t t[U];
    unsigned la[U];
    float vv[U];
-   // one ds_bpermute hands a slot its word of the step (the LDS pipe is otherwise idle here; picking it with
-   // v_readlane + v_cndmask cost 16 vector instructions per step and bounded the kernel at 16 TB/s from the L2);
-   // column * row pitch is a 24-bit multiply (n < 2^24, pitch < 2^24, product < 2^32: checked by the entry)
-   auto issue = [&](int slot, int step, unsigned word_l, float val_l) {
-      const unsigned word = (unsigned)__shfl((int)word_l, step * G + g);
-      const unsigned o = (__umul24(word & 0x7FFFFFFu, ldyb) + cbyte) | poison;
-      la[slot] = (word >> 27) * (unsigned)PANEL;
-      if (HAS_VAL) vv[slot] = __shfl(val_l, step * G + g);
-      t[slot] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)o, 0, 0);
+   // one ds_bpermute hands a slot its word of the step (the LDS pipe is otherwise idle; picking it with v_readlane +
+   // v_cndmask cost 16 vector instructions per step); column * row pitch is a 24-bit multiply (n < 2^24, pitch < 2^24,
+   // product < 2^32: checked by the entry)
+   auto issue = [&](int u, const unsigned (&word_l)[NBW], const float (&val_l)[NBW]) {
+      const unsigned word = (unsigned)__shfl((int)word_l[(u * G) / 64], (u * G) % 64 + g);
+      const unsigned o = (__umul24(word & 0xFFFFFFu, ldyb) + cbyte) | poison;
+      la[u] = (word >> 24) * (unsigned)PANEL;
+      if (HAS_VAL) vv[u] = __shfl(val_l[(u * G) / 64], (u * G) % 64 + g);
+      t[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)o, 0, 0);
    };
+   load_batch(0, w1, v1);
 #pragma unroll
-   for (int u = 0; u < U; u++) issue(u, u, wordA, valA);
+   for (int u = 0; u < U; u++) issue(u, w1, v1);
+   load_batch(64 * NBW, w1, v1);
+   load_batch(128 * NBW, w2, v2);
    // The row a slot is working on keeps its running sum in registers; it moves to the slot's LDS row when the stream
    // turns to another row (every ~deg / slices edges) and is picked up again from there when the stream comes back
    // in the next slice.  Plain read-add-write by the only lanes that ever touch that LDS row: LDS float atomics
@@ -343,33 +360,26 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, NVMAX>())) void spmm_s
       o.x += acc[0]; o.y += acc[1]; o.z += acc[2]; o.w += acc[3];
       *p = o;
    };
-   const int64_t nb = (nwords + 63) / 64;
+   const int64_t nb = (nwords + 64 * NBW - 1) / (64 * NBW);
    for (int64_t b = 0; b < nb; b++) {
-      // groups of U steps: the group's U gathers were issued one group earlier and are consumed in order, each
-      // consumed ring slot is refilled with the same step of the next group (from the next batch after the last group)
-#pragma unroll 1
-      for (int grp = 0; grp < SPB / U; grp++) {
-         const bool last = grp == SPB / U - 1;
-         const unsigned src_w = last ? wordB : wordA;
-         const float src_v = last ? valB : valA;
-         const int istep = last ? 0 : (grp + 1) * U;
+      // the U gathers of batch b are in flight; each one consumed is replaced by the same step of batch b + 1
 #pragma unroll
-         for (int u = 0; u < U; u++) {
-            if (la[u] != cur) {                          // per lane: the slots of a wave change rows at different steps
-               flush();
-               cur = la[u];
-               acc[0] = acc[1] = acc[2] = acc[3] = 0.0f;
-            }
-#pragma unroll
-            for (int v = 0; v < 4; v++) {
-               const float x = __int_as_float(t[u][v]);
-               acc[v] = HAS_VAL ? fmaf(vv[u], x, acc[v]) : acc[v] + x;
-            }
-            issue(u, istep + u, src_w, src_v);
+      for (int u = 0; u < U; u++) {
+         if (la[u] != cur) {                             // per lane: the slots of a wave change rows at different steps
+            flush();
+            cur = la[u];
+            acc[0] = acc[1] = acc[2] = acc[3] = 0.0f;
          }
+#pragma unroll
+         for (int v = 0; v < 4; v++) {
+            const float x = __int_as_float(t[u][v]);
+            acc[v] = HAS_VAL ? fmaf(vv[u], x, acc[v]) : acc[v] + x;
+         }
+         issue(u, w1, v1);
       }
-      wordA = wordB; valA = valB;
-      load_batch((b + 2) * 64, wordB, valB);
+#pragma unroll
+      for (int q = 0; q < NBW; q++) { w1[q] = w2[q]; v1[q] = v2[q]; }
+      load_batch((b + 3) * 64 * NBW, w2, v2);
    }
    flush();
    // write-out: slot q owns the local rows [q * PER, (q + 1) * PER); its LPR lanes hold one row of the panel
@@ -422,20 +432,31 @@ static int sweep_resident_waves(bool add, int64_t pk, int nvmax, int cus) {
    return cus * wgs * 4;
 }
 
-static int stream_resident_waves(int streams, int nvmax, int cus) {
+// the one geometry per slot width (lanes per row slot = 64 / streams) that the entry launches: rows per wave, batch
+// registers and workgroups per CU (measured on the Reddit shape, K = 128 in 64-column panels)
+struct StreamGeom { int nvmax, nbw, wgs; };
+static StreamGeom stream_geom(int streams) {
+   if (streams == 2) return {32, 1, 2};     // 128-column panels: U = 32 gathers of 1 KiB per wave
+   if (streams == 4) return {ISPLIB_STREAM_NV4, ISPLIB_STREAM_NBW4, ISPLIB_STREAM_WGS4};
+   return {64, 2, 3};                       // 32-column panels: U = 16
+}
+
+static int stream_resident_waves(int streams, int cus) {
+   const StreamGeom ge = stream_geom(streams);
    const int lpr = 64 / streams;
-   const int lds = 4 * nvmax * lpr * 4 * 4;
+   const int lds = 4 * ge.nvmax * lpr * 4 * 4;
    int wgs = 163840 / lds;
-   if (wgs > 8) wgs = 8;
+   if (wgs > ge.wgs) wgs = ge.wgs;
    return cus * wgs * 4;
 }
 
 template <int LPR, bool HAS_VAL>
-static int launch_stream(const SweepArgs &a, int nvmax, hipStream_t st) {
+static int launch_stream(const SweepArgs &a, hipStream_t st) {
    const unsigned blocks = (unsigned)((a.wave_count + 3) / 4);
    if (blocks == 0) return ISPLIB_SUCCESS;
-   if (nvmax == 16) hipLaunchKernelGGL((spmm_stream_kernel<LPR, HAS_VAL, 16>), dim3(blocks), dim3(256), 0, st, a);
-   else hipLaunchKernelGGL((spmm_stream_kernel<LPR, HAS_VAL, 32>), dim3(blocks), dim3(256), 0, st, a);
+   if constexpr (LPR == 32) hipLaunchKernelGGL((spmm_stream_kernel<32, HAS_VAL, 32, 1, 2>), dim3(blocks), dim3(256), 0, st, a);
+   else if constexpr (LPR == 16) hipLaunchKernelGGL((spmm_stream_kernel<16, HAS_VAL, ISPLIB_STREAM_NV4, ISPLIB_STREAM_NBW4, ISPLIB_STREAM_WGS4>), dim3(blocks), dim3(256), 0, st, a);
+   else hipLaunchKernelGGL((spmm_stream_kernel<8, HAS_VAL, 64, 2, 3>), dim3(blocks), dim3(256), 0, st, a);
    return check_launch("spmm_stream_kernel");
 }
 
@@ -560,15 +581,17 @@ extern "C" int fusedMM_csr_sweep_hip(int32_t imessage, int64_t m, int64_t n, int
 }
 
 // ---- stream form: entry ---------------------------------------------------------------------------------------------
-extern "C" int isplib_spmm_stream_resident_waves(int streams, int rows_per_wave) {
+extern "C" int isplib_spmm_stream_geometry(int streams, int *rows_per_wave, int *waves_resident) {
    clear_error();
-   if ((streams != 2 && streams != 4 && streams != 8) || (rows_per_wave != 16 && rows_per_wave != 32)) return 0;
+   if (streams != 2 && streams != 4 && streams != 8) return fail(ISPLIB_FAIL, "isplib_spmm_stream_geometry: streams must be 2, 4 or 8");
    int dev = 0, cus = 0;
    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
       (void)hipGetLastError();
       cus = 256;                                          // MI355X
    }
-   return stream_resident_waves(streams, rows_per_wave, cus);
+   if (rows_per_wave) *rows_per_wave = stream_geom(streams).nvmax;
+   if (waves_resident) *waves_resident = stream_resident_waves(streams, cus);
+   return ISPLIB_SUCCESS;
 }
 
 extern "C" size_t isplib_spmm_stream_workspace_bytes(const isplib_stream_plan *plan) {
@@ -589,9 +612,10 @@ extern "C" int fusedMM_csr_stream_hip(int32_t imessage, int64_t m, int64_t n, in
    if (!plan) return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: plan is required");
    if (plan->rows != m || plan->cols != n) return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: the plan was built for another shape");
    if (n >= (1LL << 24) || ldy >= (1LL << 22)) return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: n must be < 2^24 and ldy < 2^22 (24-bit address arithmetic)");
-   if (plan->gens < 1 || plan->waves_per_gen < 1 || (plan->rows_per_wave != 16 && plan->rows_per_wave != 32) ||
-       (plan->streams != 2 && plan->streams != 4 && plan->streams != 8))
-      return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: bad plan geometry (rows_per_wave 16 or 32, streams 2, 4 or 8)");
+   if (plan->streams != 2 && plan->streams != 4 && plan->streams != 8)
+      return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: bad plan geometry (streams 2, 4 or 8)");
+   if (plan->gens < 1 || plan->waves_per_gen < 1 || plan->rows_per_wave != stream_geom(plan->streams).nvmax)
+      return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: bad plan geometry (rows_per_wave must be what isplib_spmm_stream_geometry reports)");
    if ((k % 4) != 0 || (ldy % 4) != 0 || (ldz % 4) != 0 || ((uintptr_t)y & 15) != 0 || ((uintptr_t)z & 15) != 0)
       return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: k, ldy, ldz must be multiples of 4 and y, z 16-byte aligned (use fusedMM_csr_tasks_hip)");
    if (ldy < k || ldz < k) return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: leading dimension smaller than k");
@@ -631,9 +655,9 @@ extern "C" int fusedMM_csr_stream_hip(int32_t imessage, int64_t m, int64_t n, in
          p.wave_base = gen * plan->waves_per_gen;
          p.wave_count = plan->waves_per_gen;
          int rc;
-         if (plan->streams == 2) rc = plan->vals ? launch_stream<32, true>(p, plan->rows_per_wave, st) : launch_stream<32, false>(p, plan->rows_per_wave, st);
-         else if (plan->streams == 4) rc = plan->vals ? launch_stream<16, true>(p, plan->rows_per_wave, st) : launch_stream<16, false>(p, plan->rows_per_wave, st);
-         else rc = plan->vals ? launch_stream<8, true>(p, plan->rows_per_wave, st) : launch_stream<8, false>(p, plan->rows_per_wave, st);
+         if (plan->streams == 2) rc = plan->vals ? launch_stream<32, true>(p, st) : launch_stream<32, false>(p, st);
+         else if (plan->streams == 4) rc = plan->vals ? launch_stream<16, true>(p, st) : launch_stream<16, false>(p, st);
+         else rc = plan->vals ? launch_stream<8, true>(p, st) : launch_stream<8, false>(p, st);
          if (rc) return rc;
       }
       if (plan->n_hub > 0) {

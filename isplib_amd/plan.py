@@ -261,13 +261,16 @@ def stream_plan_arrays(rowptr: torch.Tensor, col: torch.Tensor, ncols: int, slic
                        rows_per_wave: int = 16, streams: int = 4, chunk: int = 2048) -> dict:
     """The arrays of a stream plan; plain torch ops on the device of `col` (once per graph and geometry).
 
-      * rows over `chunk` edges are cut evenly into virtual rows;
+      * rows over `chunk` edges are dealt edge by edge, round robin, to ceil(deg / chunk) virtual rows: every
+        virtual row then spans ALL column slices like an ordinary row does (contiguous pieces of a column-sorted
+        row would each sit in a few slices, and a wave holding such pieces falls out of step with the others);
       * virtual rows are dealt longest first, back and forth, to the gens*waves_per_gen*streams STREAMS (a stream =
         one slot of one wave, rows_per_wave / streams rows): equal rows and, within a fraction of a percent, equal
         edges per stream; `streams` neighbouring streams form a wave and advance together;
       * a stream lists its rows' edges slice by slice (then row by row, then in CSR order) as words
-        (local row << 27) | column; streams of a wave are interleaved step by step and padded to the longest."""
-    assert 1 <= slices <= 4096 and rows_per_wave in (16, 32) and streams in (2, 4, 8) and waves_per_gen >= 1
+        (local row << 24) | column; streams of a wave are interleaved step by step and padded to the longest."""
+    assert 1 <= slices <= 4096 and streams in (2, 4, 8) and waves_per_gen >= 1
+    assert rows_per_wave % streams == 0 and rows_per_wave <= 128
     assert ncols < (1 << 24), "column ids share a 32-bit word with the local row and are multiplied in 24 bits"
     m = rowptr.numel() - 1
     dev = col.device
@@ -275,15 +278,14 @@ def stream_plan_arrays(rowptr: torch.Tensor, col: torch.Tensor, ncols: int, slic
     nnz = col.numel()
     deg = rowptr[1:] - rowptr[:-1]
     nchunk = ((deg + chunk - 1) // chunk).clamp(min=1)
-    csize = (deg + nchunk - 1) // nchunk
     nv = int(nchunk.sum())
-    vrow = torch.repeat_interleave(torch.arange(m, **i64), nchunk)
-    first = torch.cumsum(nchunk, 0) - nchunk
-    ci = torch.arange(nv, **i64) - first[vrow]
-    vb = rowptr[vrow] + ci * csize[vrow]
-    ve = torch.minimum(vb + csize[vrow], rowptr[vrow + 1])
-    vb = torch.minimum(vb, ve)
-    vlen = ve - vb
+    vrow = torch.repeat_interleave(torch.arange(m, **i64), nchunk)              # virtual row -> row
+    first = torch.cumsum(nchunk, 0) - nchunk                                    # first virtual row of a row
+    ci = torch.arange(nv, **i64) - first[vrow]                                  # chunk number inside the row
+    vlen = (deg[vrow] - ci + nchunk[vrow] - 1) // nchunk[vrow]                  # edges ci, ci + nchunk, ci + 2 nchunk, ...
+    erow = torch.repeat_interleave(torch.arange(m, **i64), deg)                 # edge -> row
+    ev = first[erow] + (torch.arange(nnz, **i64) - rowptr[erow]) % nchunk[erow]  # edge -> virtual row
+    del erow
     per = rows_per_wave // streams                              # rows of a stream
     gens = max(1, -(-nv // (waves_per_gen * rows_per_wave)))
     nw = gens * waves_per_gen
@@ -308,7 +310,6 @@ def stream_plan_arrays(rowptr: torch.Tensor, col: torch.Tensor, ncols: int, slic
         hub_off[1:] = torch.cumsum(nchunk[hub_rows], 0).to(torch.int32)
     # the edges, stream by stream: (stream, slice, row of the stream) then CSR order (stable sort)
     width = -(-ncols // slices)
-    ev = torch.repeat_interleave(torch.arange(nv, **i64), vlen)                  # edge -> virtual row (CSR order)
     key = (sid[ev] * slices + col // width) * per + rnd[ev]
     perm = torch.sort(key, stable=True).indices
     del key
@@ -323,9 +324,9 @@ def stream_plan_arrays(rowptr: torch.Tensor, col: torch.Tensor, ncols: int, slic
     idx = (wave_step_off[e_sid // streams] + p) * streams + e_sid % streams
     del p, start
     # padding: column n (reads 0 through the range check), row = the first row of the word's own stream
-    pad = ((torch.arange(streams, **i64) * per) << 27) | int(ncols)
+    pad = ((torch.arange(streams, **i64) * per) << 24) | int(ncols)
     words = pad.to(torch.int32).repeat(n_steps)
-    words[idx] = ((lrow[ev][perm] << 27) | col[perm]).to(torch.int32)
+    words[idx] = ((lrow[ev][perm] << 24) | col[perm]).to(torch.int32)
     perm_out = torch.full((n_steps * streams,), -1, dtype=torch.int32 if nnz < 2 ** 31 else torch.int64, device=dev)
     perm_out[idx] = perm.to(perm_out.dtype)
     return dict(rows=m, cols=int(ncols), slices=slices, gens=gens, waves_per_gen=waves_per_gen, rows_per_wave=rows_per_wave,
@@ -335,14 +336,16 @@ def stream_plan_arrays(rowptr: torch.Tensor, col: torch.Tensor, ncols: int, slic
 
 
 def build_stream_plan(rowptr: torch.Tensor, col: torch.Tensor, val: Optional[torch.Tensor], ncols: int, slices: int,
-                      waves_per_gen: Optional[int] = None, rows_per_wave: int = 16, streams: int = 4,
-                      chunk: int = 2048) -> Optional[StreamPlan]:
-    """Stream plan of a graph on the device.  None when the rows are not column-sorted (a row's edges would then not
-    be met in ascending CSR order inside a slice -- the order every other schedule and the oracle use) or n >= 2^24."""
+                      waves_per_gen: Optional[int] = None, rows_per_wave: Optional[int] = None, streams: int = 4,
+                      chunk: int = 512) -> Optional[StreamPlan]:
+    """Stream plan of a graph on the device.  rows_per_wave / waves_per_gen default to what the kernel of this slot
+    width is built for (isplib_spmm_stream_geometry).  None when n >= 2^24.  (Rows need not be column-sorted: the
+    stream order -- slice, row, CSR position -- is the plan's own.)"""
     if ncols >= (1 << 24):
         return None
-    if waves_per_gen is None:
-        waves_per_gen = int(cabi.lib().isplib_spmm_stream_resident_waves(streams, rows_per_wave))
+    rpw, resident = cabi.stream_geometry(streams)
+    rows_per_wave = rpw if rows_per_wave is None else rows_per_wave
+    waves_per_gen = resident if waves_per_gen is None else waves_per_gen
     plan = StreamPlan(**stream_plan_arrays(rowptr, col, ncols, slices, waves_per_gen, rows_per_wave, streams, chunk))
     plan.set_values(val)
     return plan

@@ -55,11 +55,12 @@ else:
     print(f"plain: {t:.3f} ms  {nnz / t / 1e6:.2f} Gedges/s", flush=True)
     ref = out.clone()
 
-# stream form: STREAMS=slices:rows_per_wave:streams:chunk,...
-sgeoms = os.environ.get("STREAMS", "16:16:4:2048,32:16:4:2048,64:16:4:2048,32:32:4:2048" if red in ("sum", "mean") else "")
+# stream form: STREAMS=slices:streams:chunk,...   (rows per wave and waves per generation: the kernel's own geometry)
+sgeoms = os.environ.get("STREAMS", "32:4:512,64:4:512,128:4:512" if red in ("sum", "mean") else "")
 for sg in filter(None, sgeoms.split(",")):
-    S, rpw, streams, chunk = (int(v) for v in sg.split(":"))
-    wpg = int(os.environ.get("WPG", cabi.lib().isplib_spmm_stream_resident_waves(streams, rpw)))
+    S, streams, chunk = (int(v) for v in sg.split(":"))
+    rpw, wpg = cabi.stream_geometry(streams)
+    wpg = int(os.environ.get("WPG", wpg))
     torch.cuda.synchronize()
     plan = build_stream_plan(rowptr, col, None, n, S, wpg, rpw, streams, chunk)
     ws = plan.workspace()
@@ -72,6 +73,7 @@ for sg in filter(None, sgeoms.split(",")):
           f"(padding {plan.n_steps * streams / nnz - 1:.3%}) hub parts={plan.n_parts} steps max/mean={steps.max().item() / steps.double().mean().item():.3f}: "
           f"{t:.3f} ms  {nnz / t / 1e6:.2f} Gedges/s  maxdiff vs tasks {err:.2e}", flush=True)
     del plan, ws
+
 
 geoms = os.environ.get("GEOMS")
 if geoms == "none":

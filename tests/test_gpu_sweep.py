@@ -138,14 +138,14 @@ def test_sweep_status_codes(gpu):
 
 # ---- stream form (fusedMM_csr_stream_hip): sum / mean, the plan owns the edges in walking order ---------------------
 
-def _stream_all(gpu, oracle, rowptr, col, val, x, unit=False, geoms=((8, 64, 16, 4, 64), (5, 24, 32, 8, 2048), (16, 7, 16, 2, 100), (3, 9, 32, 4, 300))):
-    """geoms: (slices, waves_per_gen, rows_per_wave, streams, chunk)"""
+def _stream_all(gpu, oracle, rowptr, col, val, x, unit=False, geoms=((8, 16, 4, 64), (5, 6, 8, 2048), (16, 7, 2, 100), (3, 3, 4, 300))):
+    """geoms: (slices, waves_per_gen, streams, chunk); rows per wave are the kernel's (isplib_spmm_stream_geometry)"""
     from isplib_amd import cabi
     from isplib_amd.plan import build_stream_plan
     d_rowptr, d_col, d_x = _t(rowptr, gpu), _t(col, gpu), _t(x, gpu)
     d_val = None if unit else _t(val, gpu)
-    for (s, wpg, rpw, streams, chunk) in geoms:
-        plan = build_stream_plan(d_rowptr, d_col, d_val, x.shape[0], s, wpg, rpw, streams, chunk)
+    for (s, wpg, streams, chunk) in geoms:
+        plan = build_stream_plan(d_rowptr, d_col, d_val, x.shape[0], s, wpg, None, streams, chunk)
         assert plan is not None and int((plan.perm >= 0).sum()) == col.size
         for red in ("sum", "mean"):
             out = cabi.spmm_stream(d_rowptr, col.size, plan, d_x, red)
@@ -182,7 +182,7 @@ def test_stream_special_values(gpu, oracle_mod, kind):
     x = cases.dense(96, 64, 3, kind)
     _stream_all(gpu, oracle_mod, rowptr, col, val, x)
     if kind in ("integer", "signed_zero", "denormal"):
-        plan = build_stream_plan(_t(rowptr, gpu), _t(col, gpu), _t(val, gpu), 96, 4, 16, 16, 4, 64)
+        plan = build_stream_plan(_t(rowptr, gpu), _t(col, gpu), _t(val, gpu), 96, 4, 16, None, 4, 64)
         out = cabi.spmm_stream(_t(rowptr, gpu), col.size, plan, _t(x, gpu), "sum").cpu().numpy()
         ref, _ = oracle_mod.spmm_fw(rowptr, col, val, x, "sum")
         if kind == "denormal":
@@ -210,7 +210,7 @@ def test_stream_rectangular_strided_epilogue_and_new_weights(gpu, oracle_mod):
     x = np.ascontiguousarray(xfull[:, :k])
     d_rowptr, d_col = _t(rowptr, gpu), _t(col, gpu)
     d_x = _t(xfull, gpu)[:, :k]
-    plan = build_stream_plan(d_rowptr, d_col, _t(val, gpu), 333, 4, 16, 16, 4, 256)
+    plan = build_stream_plan(d_rowptr, d_col, _t(val, gpu), 333, 4, 16, None, 4, 256)
     zfull = torch.full((90, ld), 7.0, device=gpu)
     z = zfull[:, :k]
     cabi.fusedMM_csr_stream_hip(cabi.MSG_SPMM_SUM, d_rowptr, col.size, plan, d_x, z, plan.workspace())
@@ -227,7 +227,7 @@ def test_stream_rectangular_strided_epilogue_and_new_weights(gpu, oracle_mod):
     x = cases.dense(150, 64, 3)
     ones = np.ones(col.size, np.float32)
     d_rowptr, d_col, d_x = _t(rowptr, gpu), _t(col, gpu), _t(x, gpu)
-    plan = build_stream_plan(d_rowptr, d_col, None, 150, 4, 8, 16, 4, 128)
+    plan = build_stream_plan(d_rowptr, d_col, None, 150, 4, 8, None, 4, 128)
     rs = cases.dense(150, 1, 8)[:, 0].copy()
     bias = cases.dense(1, 64, 9)[0].copy()
     out = cabi.spmm_stream(d_rowptr, col.size, plan, d_x, "sum", row_scale=_t(rs, gpu), self_term=d_x, bias=_t(bias, gpu), relu=True)
@@ -242,7 +242,7 @@ def test_stream_status_codes(gpu):
     from isplib_amd.plan import build_stream_plan
     rowptr, col = cases.random_csr(40, 40, 5.0, seed=1)
     d_rowptr, d_col = _t(rowptr, gpu), _t(col, gpu)
-    plan = build_stream_plan(d_rowptr, d_col, None, 40, 2, 4, 16, 4)
+    plan = build_stream_plan(d_rowptr, d_col, None, 40, 2, 4, None, 4)
     x, z = torch.zeros((40, 8), device=gpu), torch.zeros((40, 8), device=gpu)
     assert cabi.fusedMM_csr_stream_hip(cabi.MSG_SPMM_MAX, d_rowptr, col.size, plan, x, z, check=False) == 128      # sum / mean only
     x6, z6 = torch.zeros((40, 6), device=gpu), torch.zeros((40, 6), device=gpu)

@@ -453,3 +453,60 @@ def test_sweep_plan_covers_every_edge_once_in_csr_order(geom):
     ref = np.stack([x[col[rowptr[i]:rowptr[i + 1]]].sum(0) for i in range(m)])
     assert np.allclose(out, ref, rtol=1e-12, atol=1e-12)
     assert int((p["task_meta"] & 0xFFFFFF).sum()) == col.size
+
+
+@pytest.mark.parametrize("geom", ((8, 8, 16, 4, 512), (5, 3, 32, 8, 64), (3, 2, 16, 2, 100000)))
+def test_stream_plan_lists_every_edge_once_slice_by_slice(geom):
+    """Host logic of the stream plan (isplib_amd/plan.py: stream_plan_arrays), replayed on the CPU the way
+    spmm_stream_kernel walks it: every stored entry appears in exactly one stream, in the stream of the slot that owns
+    its (virtual) row; a stream visits the column slices in ascending order and inside a slice its rows one after the
+    other, each in ascending CSR order; hub rows are dealt round robin to virtual rows, whose partial rows are
+    contiguous; padding words name column n and a row of the stream's own slot; the replay reproduces A @ X."""
+    from isplib_amd.plan import stream_plan_arrays
+    slices, wpg, rpw, streams, chunk = geom
+    m, n = 300, 257
+    rowptr, col = cases.random_csr(m, n, 30, 1, empty_rows=(0, 5, 299), hub=(7, 5000))
+    p = stream_plan_arrays(torch.from_numpy(rowptr), torch.from_numpy(col), n, slices, wpg, rpw, streams, chunk)
+    nw = p["gens"] * wpg
+    words = p["words"].numpy().astype(np.int64) & 0xFFFFFFFF
+    perm = p["perm"].numpy()
+    off = p["wave_step_off"].numpy()
+    wr, wp = p["wave_row"].numpy().reshape(nw, rpw), p["wave_part"].numpy().reshape(nw, rpw)
+    per, width = rpw // streams, -(-n // slices)
+    x = np.random.default_rng(0).random((n, 3))
+    out, parts, seen = np.zeros((m, 3)), np.zeros((p["n_parts"], 3)), np.zeros(col.size, int)
+    for w in range(nw):
+        acc = np.zeros((rpw, 3))
+        last = [(-1, -1, -1)] * streams                         # (slice, local row, CSR position) of the stream's previous word
+        for st in range(off[w], off[w + 1]):
+            for g in range(streams):
+                wd = words[st * streams + g]
+                c, lr = wd & 0xFFFFFF, wd >> 24
+                assert lr // per == g, "a word names a row of its own slot"
+                if c == n:
+                    assert perm[st * streams + g] == -1
+                    continue
+                e = perm[st * streams + g]
+                r = wr[w, lr]
+                assert col[e] == c and rowptr[r] <= e < rowptr[r + 1]
+                key = (c // width, lr, e)
+                assert key > last[g], "streams go slice by slice, row by row, in CSR order"
+                last[g] = key
+                seen[e] += 1
+                acc[lr] += x[c]
+        for j in range(rpw):
+            if wr[w, j] < 0:
+                continue
+            if wp[w, j] >= 0:
+                parts[wp[w, j]] = acc[j]
+            else:
+                out[wr[w, j]] = acc[j]
+    hr, ho = p["hub_row"].numpy(), p["hub_off"].numpy()
+    for h in range(hr.size):
+        out[hr[h]] = parts[ho[h]:ho[h + 1]].sum(0)
+    assert (seen == 1).all()
+    ref = np.stack([x[col[rowptr[i]:rowptr[i + 1]]].sum(0) for i in range(m)])
+    assert np.allclose(out, ref, rtol=1e-12, atol=1e-12)
+    if chunk < 5000:                                            # the hub row's pieces all span the whole column range
+        hub_slots = [(w, j) for w in range(nw) for j in range(rpw) if wr[w, j] == 7]
+        assert len(hub_slots) == -(-5000 // chunk)
