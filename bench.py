@@ -46,8 +46,10 @@ def parse():
     p.add_argument("--weighted", action="store_true", help="U(0,1) edge weights instead of unit weights")
     p.add_argument("--slices", type=int, default=-1,
                    help="column slices (0 = plain row kernel; -1 = isplib_amd.plugin.suggest_slices)")
-    p.add_argument("--schedule", default="tasks", choices=["sliced", "tasks"],
-                   help="sliced: (row, slice) segment per wave; tasks: explicit task list (isplib_amd/plan.py)")
+    p.add_argument("--schedule", default="auto", choices=["auto", "stream", "sliced", "tasks"],
+                   help="stream: rows resident in LDS, the plan's own edge stream (sum / mean); tasks: explicit task list; "
+                        "sliced: (row, slice) segment per wave; auto: stream where isplib_suggest_stream says so, else tasks")
+    p.add_argument("--stream-geom", default="", help="debug: streams:slices:chunk for the stream schedule instead of the rule")
     p.add_argument("--chunk", type=int, default=1024, help="tasks: edges per task")
     p.add_argument("--short", type=int, default=128, help="tasks: rows shorter than this are not sliced")
     p.add_argument("--tune", default="", help="debug: comma list of key=value for isplib_hip_tune")
@@ -233,6 +235,21 @@ def main():
             raise SystemExit("synthetic graph rows are not column-sorted?")
         work = cabi.sliced_workspace(a.reduce, m_local, k, a.slices, dev)
 
+    # stream schedule (sum / mean): the default wherever the rule expects it to win
+    splan = swork = None
+    if a.schedule in ("auto", "stream") and a.reduce in ("sum", "mean"):
+        from isplib_amd.plan import build_stream_plan
+        geom = tuple(int(v) for v in a.stream_geom.split(":")) if a.stream_geom else \
+            cabi.suggest_stream(m_local, x_in.size(0), l_col.numel(), k)
+        if geom is not None:
+            splan = build_stream_plan(l_rowptr, l_col, l_val, x_in.size(0), geom[1], None, None, geom[0], geom[2])
+            swork = None if splan is None else splan.workspace()
+        if splan is None and a.schedule == "stream":
+            raise SystemExit("--schedule stream: the stream schedule does not apply to this shape (isplib_suggest_stream)")
+    if a.schedule in ("auto", "stream"):
+        a.schedule = "tasks"            # what everything the stream schedule does not serve falls back to
+    use_stream = splan is not None
+
     tplan = twork = None
     if a.schedule == "tasks" and a.slices > 0:
         from isplib_amd.plan import build_task_plan
@@ -246,7 +263,11 @@ def main():
         twork = tplan.workspace(a.reduce, k)
     use_tasks = tplan is not None and not multi      # N > 1: decided by a short measurement below
 
-    def spmm(rp, cl, vl, tb, xin, o, ar, tp=None):
+    def spmm(rp, cl, vl, tb, xin, o, ar, tp=None, sp=None):
+        sp = splan if (sp is None and tp is None and rp is l_rowptr and use_stream) else sp
+        if sp is not None:
+            cabi.fusedMM_csr_stream_hip(msg, rp, cl.numel(), sp, xin, o, swork if sp is splan else swork_t)
+            return
         tp = tplan if (tp is None and rp is l_rowptr and use_tasks) else tp
         if tp is not None:
             cabi.fusedMM_csr_tasks_hip(msg, rp, cl, vl, tp, xin, o, ar, twork)
@@ -308,8 +329,14 @@ def main():
             out.copy_(keep)
             return mag
 
+        def gather_then_stream():
+            gather()
+            cabi.fusedMM_csr_stream_hip(msg, l_rowptr, l_col.numel(), splan, x_in, out, swork)
+
         base = gather_then_tasks if tplan is not None else gather_then_sliced
         candidates = {"gather+spmm": base}
+        if splan is not None and checked("gather+stream", gather_then_stream, base, exact=False):
+            candidates["gather+stream"] = gather_then_stream
         if os.environ.get("ISPLIB_OVERLAP", "1") != "0":
             if plan is not None:
                 fn = lambda: part.spmm_overlapped(x_shard, x_in, out, plan, a.reduce, arg)  # noqa: E731
@@ -341,7 +368,8 @@ def main():
         times = {name: timed(fn) for name, fn in candidates.items()}
         chosen = min(times, key=times.get)
         use_tasks = tplan is not None and chosen != "overlapped sliced"
-        if chosen != "gather+spmm":
+        use_stream = chosen == "gather+stream"
+        if chosen not in ("gather+spmm", "gather+stream"):
             step_fn = candidates[chosen]
         if rank == 0:
             print(f"[bench] N={world}: " + ", ".join(f"{n_} {t_:.3f} ms/step" for n_, t_ in times.items()) + f" -> {chosen}",
@@ -413,21 +441,25 @@ def main():
 
     # backward of SpMM-sum = the same kernel on A^T (csrc/fusedmm.cpp:285); reported beside the metric
     bwd = None
+    swork_t = None
     if not multi and not a.no_backward and a.reduce == "sum":
         colptr, _, row_t, val_t = cabi.csr2csc(rowptr, col, val, n, want_perm=False, want_val=val is not None)
         dy = synth.features(n, k, seed=5, device=dev)
         dx = torch.empty((n, k), dtype=torch.float32, device=dev)
         table_t = cabi.spmm_slices(colptr, row_t, n, a.slices)[0] if a.slices > 0 else None
-        tplan_t = None
-        if tplan is not None:
+        tplan_t = splan_t = None
+        if use_stream:
+            splan_t = build_stream_plan(colptr, row_t, val_t, n, splan.slices, None, None, splan.streams, splan.chunk)
+            swork_t = splan_t.workspace()
+        elif tplan is not None:
             tplan_t = build_task_plan(colptr, row_t, n, a.slices, a.chunk, a.short)
             twork = tplan_t.workspace(a.reduce, k) if tplan_t.n_tasks > tplan.n_tasks else twork
         for _ in range(2):
-            spmm(colptr, row_t, val_t, table_t, dy, dx, None, tplan_t)
+            spmm(colptr, row_t, val_t, table_t, dy, dx, None, tplan_t, splan_t)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         for _ in range(5):
-            spmm(colptr, row_t, val_t, table_t, dy, dx, None, tplan_t)
+            spmm(colptr, row_t, val_t, table_t, dy, dx, None, tplan_t, splan_t)
         e.record()
         torch.cuda.synchronize()
         bms = s.elapsed_time(e) / 5
@@ -446,10 +478,24 @@ def main():
         if os.path.exists(tpath) and not multi and a.scale == 1.0 and not a.weighted and a.generator == "chunglu" \
                 and (a.chunk, a.short) == (1024, 128):
             try:
-                rec = json.load(open(tpath)).get(f"{a.workload}-{a.reduce}-k{k}-s{a.slices}" + ("-tasks" if tplan is not None else ""))
+                rec = json.load(open(tpath)).get(f"{a.workload}-{a.reduce}-k{k}-" + (f"stream{splan.slices}" if use_stream else
+                                                 f"s{a.slices}" + ("-tasks" if tplan is not None else "")))
                 traffic = rec["hbm_bytes_per_launch"] if rec else None
             except Exception:
                 traffic = None
+        if use_stream:
+            pw = 256 // splan.streams
+            kernel_label = (f"spmm_stream_kernel x {splan.gens} generation(s) + sweep_hub_fold_kernel, "
+                            f"{-(-k // pw)} pass(es) of {pw} columns per launch")
+        elif use_tasks:
+            kernel_label = "spmm_task_kernel + combine_tasks_kernel"
+            if x_in.size(0) * k * 4 / max(a.slices, 1) > 9216 * 1024:          # else a whole-row plan: one pass
+                if k >= 96 and k % 32 == 0:
+                    kernel_label += f", {-(-k // 64)} passes of 64 columns per launch"
+                elif k >= 192:
+                    kernel_label += f", {-(-k // 128)} passes of 128 columns per launch"
+        else:
+            kernel_label = "spmm_csr_kernel" + (f"<sliced x{sliced_slices}> + combine_slices_kernel" if a.slices > 0 else "")
         res = {
             "metric": "edges_aggregated_per_sec", "value": nnz / (elapsed / a.steps), "unit": "edges/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
@@ -459,7 +505,10 @@ def main():
                 "workload": f"{a.workload}-like graph ({a.generator}, N={n}, nnz={nnz}), SpMM-{a.reduce} forward, K={k}, fp32"
                             + (", U(0,1) weights" if a.weighted else ", unit weights")
                             + ("" if a.scale == 1.0 else f", SCALED x{a.scale} (debug)"),
-                "schedule": (f"task list: {a.slices} column slices, {tplan.n_tasks} tasks of <= {a.chunk} edges, rows < {a.short} unsliced"
+                "schedule": (f"stream: {splan.streams} streams x {splan.rows_per_wave // splan.streams} rows per wave, {splan.slices} column slices, "
+                             f"{splan.gens} generation(s) of {splan.waves_per_gen} waves, rows > {splan.chunk} edges dealt to {splan.n_parts} virtual rows"
+                             if use_stream else
+                             f"task list: {a.slices} column slices, {tplan.n_tasks} tasks of <= {a.chunk} edges, rows < {a.short} unsliced"
                              if use_tasks else
                              f"{sliced_slices} column slices, XCD-affine" if a.slices > 0 else "row-per-wave, unsliced"),
                 "partition": "none" if not multi else f"1-D rows by nnz, {world} ranks, one all-gather(X) per step"
@@ -469,11 +518,7 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                 "traffic_source": None if traffic is None else "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, gfx950-corrected)",
-                "kernel": (("spmm_task_kernel + combine_tasks_kernel" + (
-                    "" if x_in.size(0) * k * 4 / max(a.slices, 1) <= 9216 * 1024 else      # whole-row plan: one pass
-                    f", {-(-k // 64)} passes of 64 columns per launch" if k >= 96 and k % 32 == 0 else
-                    f", {-(-k // 128)} passes of 128 columns per launch" if k >= 192 else "")) if use_tasks else
-                           "spmm_csr_kernel" + (f"<sliced x{sliced_slices}> + combine_slices_kernel" if a.slices > 0 else "")),
+                "kernel": kernel_label,
                 "kernel_avg_ms": kern_avg_ms, "kernel_median_ms": sorted(kern_ms)[len(kern_ms) // 2], "kernel_min_ms": min(kern_ms),
                 "kernel_cold_cache_ms": cold_ms, "peak_measured_copy": copy_gbps,
                 "frac_of_measured_copy": None if not copy_gbps else achieved / copy_gbps,

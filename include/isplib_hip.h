@@ -359,6 +359,9 @@ typedef struct isplib_stream_plan {
    const int32_t *hub_off;          /* [dev] n_hub + 1 */
 } isplib_stream_plan;
 int    isplib_spmm_stream_geometry(int streams, int *rows_per_wave /*out*/, int *waves_resident /*out*/);
+/* the measured rule: nonzero when the stream schedule is expected to beat the task list for an m x n, nnz-entry SpMM
+ * over k columns (sum / mean), with the plan parameters to build it with (streams, column slices, hub-row chunk) */
+int    isplib_suggest_stream(int64_t m, int64_t n, int64_t nnz, int64_t k, int *streams, int *slices, int *chunk);
 size_t isplib_spmm_stream_workspace_bytes(const isplib_stream_plan *plan);
 int    fusedMM_csr_stream_hip(int32_t imessage /* ISPLIB_MSG_SPMM_SUM | _MEAN */, int64_t m, int64_t n, int64_t k,
                               int64_t nnz, const int64_t *pntrb, const int64_t *pntre,

@@ -52,7 +52,7 @@ EXPORTS = (
     "isplib_suggest_slices", "isplib_graph_create", "isplib_graph_set_slices", "isplib_graph_spmm", "isplib_graph_spmm_backward",
     "isplib_graph_destroy", "isplib_suggest_slices_whole_rows", "isplib_graph_sddmm",
     "fusedMM_csr_sweep_hip", "isplib_spmm_sweep_workspace_bytes", "isplib_spmm_sweep_resident_waves",
-    "fusedMM_csr_stream_hip", "isplib_spmm_stream_workspace_bytes", "isplib_spmm_stream_geometry",
+    "fusedMM_csr_stream_hip", "isplib_spmm_stream_workspace_bytes", "isplib_spmm_stream_geometry", "isplib_suggest_stream",
 )
 
 _i64, _f32, _vp, _i32 = ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_int32
@@ -169,6 +169,8 @@ def lib() -> ctypes.CDLL:
         L.isplib_graph_destroy.argtypes = [_vp]
         L.isplib_hip_tune.restype = ctypes.c_int
         L.isplib_hip_tune.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.isplib_suggest_stream.restype = ctypes.c_int
+        L.isplib_suggest_stream.argtypes = [_i64, _i64, _i64, _i64, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
         L.isplib_spmm_stream_geometry.restype = ctypes.c_int
         L.isplib_spmm_stream_geometry.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
         L.isplib_spmm_stream_workspace_bytes.restype = ctypes.c_size_t
@@ -585,6 +587,14 @@ def spmm_stream(rowptr, nnz: int, plan, y, reduce: str = "sum", workspace=None, 
                       k if self_term is None else self_term.stride(0), None if bias is None else bias.data_ptr(), int(bool(relu)))
     fusedMM_csr_stream_hip(MESSAGE[reduce], rowptr, nnz, plan, y, out, workspace, ep)
     return out
+
+
+def suggest_stream(m: int, n: int, nnz: int, k: int):
+    """(streams, slices, chunk) when the stream schedule is expected to win for this shape, else None (isplib_suggest_stream)."""
+    st, sl, ch = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    if not lib().isplib_suggest_stream(int(m), int(n), int(nnz), int(k), ctypes.byref(st), ctypes.byref(sl), ctypes.byref(ch)):
+        return None
+    return st.value, sl.value, ch.value
 
 
 def stream_geometry(streams: int = 4):

@@ -594,6 +594,33 @@ extern "C" int isplib_spmm_stream_geometry(int streams, int *rows_per_wave, int 
    return ISPLIB_SUCCESS;
 }
 
+extern "C" int isplib_suggest_stream(int64_t m, int64_t n, int64_t nnz, int64_t k, int *streams, int *slices, int *chunk) {
+   // When does the stream schedule pay, and with which plan?  Measured on MI355X:
+   //   * slots of 16 lanes (64-column panels) from k = 33, of 8 lanes (32-column panels) below;
+   //   * a column slice of ~1.9 MB of the panel (Reddit shape: 32 slices at 64 columns, 16 at 32);
+   //   * every generation of waves sweeps the whole dense operand once per XCD, so the rows a generation holds must
+   //     reuse each row of it often: edges per generation and XCD >= 8 x rows of y (Reddit shape: 31; the
+   //     ogbn-products shape, mean degree 50 over 2.4 M rows: 0.3 -- such graphs stay on the plain kernel);
+   //   * rows longer than ~0.3 of a stream's share of the edges are dealt to several virtual rows (chunk).
+   clear_error();
+   if (m <= 0 || n <= 0 || nnz <= 0 || k < 4 || (k % 4) != 0 || n >= (1LL << 24) || nnz < (1LL << 22)) return 0;
+   const int st = k <= 32 ? 8 : 4;
+   int rpw = 0, resident = 0;
+   if (isplib_spmm_stream_geometry(st, &rpw, &resident) != ISPLIB_SUCCESS || rpw <= 0 || resident <= 0) return 0;
+   const int64_t per_gen = (int64_t)rpw * resident;
+   const int64_t gens = (m + per_gen - 1) / per_gen;
+   if ((double)nnz / (double)gens / 8.0 < 8.0 * (double)n) return 0;
+   const double panel_bytes = 1024.0 / st;
+   int sl = (int)((double)n * panel_bytes / 1.9e6 + 0.5);
+   sl = sl < 1 ? 1 : (sl > 512 ? 512 : sl);
+   int64_t ch = (int64_t)((double)nnz / ((double)gens * resident * st) / 3.4);
+   ch = ch < 256 ? 256 : (ch > (1 << 20) ? (1 << 20) : ch);
+   if (streams) *streams = st;
+   if (slices) *slices = sl;
+   if (chunk) *chunk = (int)ch;
+   return 1;
+}
+
 extern "C" size_t isplib_spmm_stream_workspace_bytes(const isplib_stream_plan *plan) {
    if (!plan || plan->n_parts <= 0) return 256;
    const size_t pk = (size_t)(256 / (plan->streams > 0 ? plan->streams : 4));

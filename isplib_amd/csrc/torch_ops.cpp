@@ -97,6 +97,9 @@ struct OpTimer {
 using Plan = std::vector<Tensor>;
 // task plan = {task_row, task_b, task_len, seg_off, lane_off (host)} + optionally the 32-bit copy of col
 static inline bool is_task_plan(const Plan &p) { return p.size() == 5 || p.size() == 6; }
+// stream plan (sum / mean; isplib_stream_plan) = {words, vals (empty = unit weights), wave_step_off, wave_row, wave_part,
+// hub_row, hub_off, meta (host int64: rows, cols, slices, gens, waves_per_gen, rows_per_wave, streams, n_steps, n_parts, n_hub)}
+static inline bool is_stream_plan(const Plan &p) { return p.size() == 8; }
 // what the reference-schema operators pass: "no plan was given, choose for me" (one undefined tensor), as opposed
 // to the empty plan of the *_planned operators, which means "the plain kernel, please"
 static inline Plan auto_plan() { return Plan{Tensor()}; }
@@ -210,6 +213,39 @@ std::tuple<Tensor, Tensor> spmm_fw(const Tensor &rowptr_, const Tensor &col_, co
    if (reduction == R_MAX || reduction == R_MIN) arg = at::empty({M, K}, rowptr.options());
    const int64_t *rp = rowptr.data_ptr<int64_t>();
    const bool tasks_fit = K >= 4 && (double)N * (double)K * 4.0 <= 3.5 * 1073741824.0;
+   if (is_stream_plan(plan) && M > 0 && K > 0) {
+      // the plan carries the edges (and the weights) in its own order: `col` / `value` are not read
+      TORCH_CHECK(reduction == R_SUM || reduction == R_MEAN, "isplib: a stream plan serves sum and mean only");
+      const Tensor &words = plan[0], &vals = plan[1], &step_off = plan[2], &wave_row = plan[3], &wave_part = plan[4],
+                   &hub_row = plan[5], &hub_off = plan[6], &meta = plan[7];
+      TORCH_CHECK(!meta.is_cuda() && meta.scalar_type() == at::kLong && meta.numel() == 10, "isplib: stream plan meta must be 10 host int64");
+      TORCH_CHECK(words.is_cuda() && words.scalar_type() == at::kInt && step_off.scalar_type() == at::kLong &&
+                      wave_row.scalar_type() == at::kInt && wave_part.scalar_type() == at::kInt &&
+                      hub_row.scalar_type() == at::kInt && hub_off.scalar_type() == at::kInt &&
+                      (vals.numel() == 0 || (vals.scalar_type() == at::kFloat && vals.numel() == words.numel())),
+                  "isplib: malformed stream plan");
+      const int64_t *mt = meta.data_ptr<int64_t>();
+      isplib_stream_plan sp;
+      sp.rows = mt[0]; sp.cols = mt[1]; sp.slices = (int32_t)mt[2]; sp.gens = (int32_t)mt[3]; sp.waves_per_gen = (int32_t)mt[4];
+      sp.rows_per_wave = (int32_t)mt[5]; sp.streams = (int32_t)mt[6]; sp.reserved = 0; sp.n_steps = mt[7]; sp.n_parts = mt[8]; sp.n_hub = mt[9];
+      TORCH_CHECK(words.numel() == sp.n_steps * sp.streams && step_off.numel() == (int64_t)sp.gens * sp.waves_per_gen + 1 &&
+                      wave_row.numel() == (int64_t)sp.gens * sp.waves_per_gen * sp.rows_per_wave && wave_part.numel() == wave_row.numel() &&
+                      hub_row.numel() == sp.n_hub && hub_off.numel() == sp.n_hub + 1,
+                  "isplib: stream plan arrays do not match its meta");
+      sp.words = words.data_ptr<int32_t>();
+      sp.vals = vals.numel() ? vals.data_ptr<float>() : nullptr;
+      sp.wave_step_off = step_off.data_ptr<int64_t>();
+      sp.wave_row = wave_row.data_ptr<int32_t>();
+      sp.wave_part = wave_part.data_ptr<int32_t>();
+      sp.hub_row = sp.n_hub ? hub_row.data_ptr<int32_t>() : nullptr;
+      sp.hub_off = hub_off.data_ptr<int32_t>();
+      const size_t ws = isplib_spmm_stream_workspace_bytes(&sp);
+      Tensor work = at::empty({(int64_t)ws}, mat.options().dtype(at::kByte));
+      const int st = fusedMM_csr_stream_hip(msg, M, N, K, nnz, rp, rp + 1, &sp, mat.data_ptr<float>(), K, out.data_ptr<float>(), K,
+                                            work.data_ptr(), ws, nullptr, current_stream(mat));
+      check_status(st, "fusedMM_csr_stream_hip");
+      return std::make_tuple(out, arg);
+   }
    if (is_task_plan(plan) && tasks_fit && M > 0 && K > 0) {
       const Tensor &task_row = plan[0], &task_b = plan[1], &task_len = plan[2], &seg_off = plan[3], &lane = plan[4];
       TORCH_CHECK(task_row.is_cuda() && task_row.scalar_type() == at::kInt && task_len.scalar_type() == at::kInt &&

@@ -290,11 +290,19 @@ def stream_plan_arrays(rowptr: torch.Tensor, col: torch.Tensor, ncols: int, slic
     gens = max(1, -(-nv // (waves_per_gen * rows_per_wave)))
     nw = gens * waves_per_gen
     ns = nw * streams
+    # deal the virtual rows to the streams in rounds of one row per stream, longest rows first; in every round the
+    # longest row goes to the stream that holds the fewest edges so far (a plain back-and-forth deal leaves 5 % between
+    # the longest and the mean stream when hub pieces of 2048 edges meet streams of 7000)
     order = torch.sort(vlen, descending=True, stable=True).indices
-    rank = torch.empty(nv, **i64)
-    rank[order] = torch.arange(nv, **i64)
-    rnd, pos = rank // ns, rank % ns
-    sid = torch.where(rnd % 2 == 0, pos, ns - 1 - pos)           # stream of the virtual row
+    sid = torch.empty(nv, **i64)
+    rnd = torch.empty(nv, **i64)
+    loads = torch.zeros(ns, **i64)
+    for r in range(-(-nv // ns)):
+        items = order[r * ns:(r + 1) * ns]
+        to = torch.sort(loads, stable=True).indices[:items.numel()]
+        sid[items] = to
+        rnd[items] = r
+        loads[to] += vlen[items]
     wave, slot = sid // streams, sid % streams
     lrow = slot * per + rnd                                      # local row inside the wave
     is_hub = nchunk[vrow] > 1

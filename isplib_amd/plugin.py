@@ -19,6 +19,10 @@ Differences from the reference, each a defect there:
     ``(out, arg)`` tuple of :143,145 (the tuple stays available at the op level);
   * an unknown ``reduce`` raises ValueError instead of returning None (:154-155);
   * the patched ``torch.sparse.mm`` still serves ordinary torch sparse tensors.
+
+Environment: ISPLIB_SLICES=<n> forces the task list with n column slices (0: plain kernel); ISPLIB_STREAM=0 keeps
+sum / mean off the stream schedule; ISPLIB_STREAM_GEOM=streams:slices:chunk forces it with that plan geometry;
+ISPLIB_TUNE_FILE names a tuning table to load at import; ISPLIB_DEBUG=1 prints per-operator device times.
 """
 from __future__ import annotations
 
@@ -173,6 +177,20 @@ def choose_slices(storage: SparseStorage, rows: int, k: int, minmax: bool = Fals
     return s
 
 
+def choose_stream(storage: SparseStorage, m: int, n: int, k: int):
+    """(streams, slices, chunk) when sum / mean of this shape should run on the stream schedule, else None.
+    ISPLIB_STREAM=0 disables it, ISPLIB_SLICES (the task list's override) disables it too: explicit schedules win."""
+    if os.environ.get("ISPLIB_STREAM", "1") == "0" or os.environ.get("ISPLIB_SLICES") is not None:
+        return None
+    if k < 4 or k % 4 != 0 or n >= (1 << 24):
+        return None
+    forced = os.environ.get("ISPLIB_STREAM_GEOM")          # "streams:slices:chunk": tests and experiments
+    if forced:
+        return tuple(int(v) for v in forced.split(":"))
+    from . import cabi
+    return cabi.suggest_stream(m, n, storage._col.numel(), k)
+
+
 def spmm_autotuned(src, other: torch.Tensor, reduce: str = "sum") -> torch.Tensor:
     """``torch_sparse.matmul(src, other, reduce)`` on the HIP path (isplib/__init__.py:48-157)."""
     if reduce not in ("sum", "add", "mean", "max", "min"):
@@ -190,15 +208,24 @@ def spmm_autotuned(src, other: torch.Tensor, reduce: str = "sum") -> torch.Tenso
     needs_grad = torch.is_grad_enabled() and mat.requires_grad       # :69-73
     ops = torch.ops.isplib
     k = mat.size(-1)
-    n_sl = choose_slices(s, mat.size(0), k, reduce in ("max", "min"))
-    plan = s.plan(n_sl)                                              # per-graph, built once on the device
+    m_rows = rowptr.numel() - 1
+    # sum / mean on graphs with work for the whole chip: the stream schedule (rows resident in LDS, the plan's own copy
+    # of the edges; include/isplib_hip.h: fusedMM_csr_stream_hip) -- measured 15-18 % ahead of the task list
+    geom = choose_stream(s, m_rows, mat.size(0), k) if reduce in ("sum", "add", "mean") else None
+    plan = s.stream_plan(False, geom) if geom is not None else None
+    if plan is None:
+        n_sl = choose_slices(s, mat.size(0), k, reduce in ("max", "min"))
+        plan = s.plan(n_sl)                                          # per-graph, built once on the device
     if reduce in ("sum", "add", "mean"):
         colptr = val_t = row_t = None
         plan_t = []
         if needs_grad:                                               # :76-80 / :83-99 (built once per graph)
             colptr, row_t = s.colptr(), s.row_t()
             val_t = s.mean_val_t() if reduce == "mean" else s.val_t()   # mean: intended pairing
-            plan_t = s.plan_t(choose_slices(s, rowptr.numel() - 1, k))
+            geom_t = choose_stream(s, mat.size(0), m_rows, k)
+            plan_t = s.stream_plan(True, geom_t, "mean" if reduce == "mean" else "sum") if geom_t is not None else None
+            if plan_t is None:
+                plan_t = s.plan_t(choose_slices(s, m_rows, k))
         if reduce == "mean":
             out = ops.fusedmm_spmm_mean_planned(rowptr, col, value, colptr, mat, row_t, val_t, plan, plan_t)
         else:

@@ -46,6 +46,10 @@ class SparseStorage:
         # task plans of A and A^T per slice count ([] when the rows are not column-sorted: plain kernel)
         self._plans = {}
         self._plans_t = {}
+        # stream plans (sum / mean) of A and A^T per (transposed, streams, slices, chunk); their weight vectors in stream
+        # order per (transposed, streams, slices, chunk, kind) with the state of `value` they were gathered from
+        self._streams = {}
+        self._stream_vals = {}
         self._tuned = {}          # (dense rows, k, minmax) -> slice count measured by iSpLibPlugin.autotune
 
     def sparse_sizes(self) -> Tuple[int, int]:
@@ -135,6 +139,44 @@ class SparseStorage:
             cache[n_slices] = [] if p is None else [p.task_row, p.task_b, p.task_len, p.seg_off,
                                                     torch.tensor(p.lane_off, dtype=torch.int64), p.col32]
         return cache[n_slices]
+
+    def stream_plan(self, transposed: bool, geom, kind: str = "sum"):
+        """Operands of the stream schedule for the `_planned` operators: [words, vals, wave_step_off, wave_row, wave_part,
+        hub_row, hub_off, meta_cpu] for A (or A^T), `geom` = (streams, slices, chunk) from ``cabi.suggest_stream``.
+        `kind`: which weights ride in the plan -- "sum": value (A) / value[csr2csc] (A^T); "mean" (A^T only): the mean
+        backward's value[csr2csc] / max(deg, 1).  The structure is built once per graph and geometry; the weights are
+        re-gathered through the plan's permutation whenever `value` was replaced or written in place."""
+        from .plan import build_stream_plan
+        key = (bool(transposed),) + tuple(int(v) for v in geom)
+        plan = self._streams.get(key)
+        if plan is None:
+            if transposed:
+                plan = build_stream_plan(self.colptr(), self.row_t(), None, self._sparse_sizes[0], geom[1], None, None, geom[0], geom[2])
+            else:
+                plan = build_stream_plan(self._rowptr, self._col, None, self._sparse_sizes[1], geom[1], None, None, geom[0], geom[2])
+            self._streams[key] = plan
+            if plan is not None:
+                plan.meta = torch.tensor([plan.rows, plan.cols, plan.slices, plan.gens, plan.waves_per_gen, plan.rows_per_wave,
+                                          plan.streams, plan.n_steps, plan.n_parts, plan.n_hub], dtype=torch.int64)
+        if plan is None:
+            return None
+        vals = torch.empty(0, dtype=torch.float32, device=plan.words.device)
+        if self._value is not None or (transposed and kind == "mean"):
+            vkey = key + (kind,)
+            state = self._value_state()
+            hit = self._stream_vals.get(vkey)
+            if hit is None or hit[0] != state:
+                if transposed:
+                    src = self.mean_val_t() if kind == "mean" else self.val_t()
+                else:
+                    src = self._value
+                ok = plan.perm >= 0
+                vals = torch.zeros(plan.perm.numel(), dtype=torch.float32, device=plan.perm.device)
+                vals[ok] = src.detach().to(torch.float32)[plan.perm[ok].to(torch.int64)]
+                self._stream_vals[vkey] = (state, vals)
+            else:
+                vals = hit[1]
+        return [plan.words, vals, plan.wave_step_off, plan.wave_row, plan.wave_part, plan.hub_row, plan.hub_off, plan.meta]
 
     def gcn_dinv(self) -> torch.Tensor:
         """(deg + 1)^-1/2 per row: the D^-1/2 of GCN's normalisation with self loops, unit weights."""

@@ -205,10 +205,22 @@ def reddit_sweep(reddit):
     return build_sweep_plan(rowptr, col, n, 16, cabi.sweep_resident_waves("sum", 64, 16), 16)
 
 
+@pytest.fixture(scope="module")
+def reddit_stream(reddit):
+    """The plug-in's / bench.py's default plan for sum and mean on this shape (isplib_suggest_stream), unit weights."""
+    from isplib_amd import cabi
+    from isplib_amd.plan import build_stream_plan
+    rowptr, col, n, _ = reddit
+    geom = cabi.suggest_stream(n, n, col.numel(), 128)
+    assert geom is not None and geom[0] == 4
+    return build_stream_plan(rowptr, col, None, n, geom[1], None, None, geom[0], geom[2])
+
+
 @pytest.mark.parametrize("red", ("mean", "min"))
-def test_config3_reddit_k64_default_plan_and_torch_arbiter(gpu, reddit, reddit_sweep, oracle_mod, red):
-    """mean / min, K=64, weighted, through the DEFAULT schedule (isplib_suggest_slices -> 8 slices, task list) and the
-    sweep schedule; checked against the oracle AND against torch.sparse.mm on the CPU."""
+def test_config3_reddit_k64_default_plan_and_torch_arbiter(gpu, reddit, reddit_sweep, reddit_stream, oracle_mod, red):
+    """mean / min, K=64, weighted, through the default schedules (mean: the stream plan of isplib_suggest_stream; min: the
+    task list with isplib_suggest_slices -> 8 slices) and the others that serve them (task list / sweep); checked
+    against the oracle AND against torch.sparse.mm on the CPU."""
     from isplib_amd import cabi, synth
     from isplib_amd.plan import build_task_plan
     rowptr, col, n, _ = reddit
@@ -220,12 +232,19 @@ def test_config3_reddit_k64_default_plan_and_torch_arbiter(gpu, reddit, reddit_s
     w = synth.edge_weights(col.numel(), device=gpu)
     tasks, targ = cabi.spmm_tasks(rowptr, col, w, plan, x, red)
     sweep, sarg = cabi.spmm_sweep(rowptr, col, w, reddit_sweep, x, red)
+    stream = None
+    if red == "mean":
+        reddit_stream.set_values(w)
+        stream = cabi.spmm_stream(rowptr, col.numel(), reddit_stream, x, red)
+        again = cabi.spmm_stream(rowptr, col.numel(), reddit_stream, x, red)
+        assert torch.equal(stream, again), "stream schedule must be bitwise reproducible"
+        reddit_stream.set_values(None)
     rp, cl, ww, xx = _host(rowptr, col, w, x)
     ref, ref_arg = oracle_mod.spmm_fw(rp, cl, ww, xx, red)
     third = _torch_cpu_spmm(rp, cl, ww, xx, red)
     if red == "mean":
         mag, _ = oracle_mod.spmm_fw(rp, cl, ww, np.abs(xx), "mean")
-        for name, got in (("tasks", tasks), ("sweep", sweep)):
+        for name, got in (("stream", stream), ("tasks", tasks), ("sweep", sweep)):
             got = got.cpu().numpy()
             assert np.all(np.abs(got - ref) <= 1e-5 * mag + 1e-30), name
             assert np.all(np.abs(got - third) <= 2e-5 * mag + 1e-30), f"{name} vs torch.sparse.mm"
@@ -237,9 +256,10 @@ def test_config3_reddit_k64_default_plan_and_torch_arbiter(gpu, reddit, reddit_s
             assert np.array_equal(got.cpu().numpy(), third), f"{name} vs torch.sparse.mm amin"
 
 
-def test_config2_sum_k128_sweep_and_torch_arbiter(gpu, reddit, reddit_sweep, oracle_mod):
-    """The headline workload through the sweep schedule: bitwise reproducible, within the bound of the oracle, and
-    within twice the bound of torch.sparse.mm on the CPU (two fp32 summation orders)."""
+def test_config2_sum_k128_stream_sweep_and_torch_arbiter(gpu, reddit, reddit_sweep, reddit_stream, oracle_mod):
+    """The headline workload through the stream schedule (bench.py's default) and the sweep schedule: bitwise
+    reproducible, within the bound of the oracle, and within twice the bound of torch.sparse.mm on the CPU (two fp32
+    summation orders)."""
     from isplib_amd import cabi, synth
     rowptr, col, n, _ = reddit
     k = 128
@@ -247,16 +267,21 @@ def test_config2_sum_k128_sweep_and_torch_arbiter(gpu, reddit, reddit_sweep, ora
     out, _ = cabi.spmm_sweep(rowptr, col, None, reddit_sweep, x, "sum")
     again, _ = cabi.spmm_sweep(rowptr, col, None, reddit_sweep, x, "sum")
     assert torch.equal(out, again)
+    st = cabi.spmm_stream(rowptr, col.numel(), reddit_stream, x, "sum")
+    again = cabi.spmm_stream(rowptr, col.numel(), reddit_stream, x, "sum")
+    assert torch.equal(st, again)
     rp, cl, xx = _host(rowptr, col, x)
     ones = np.ones(cl.size, np.float32)
     ref, _ = oracle_mod.spmm_fw(rp, cl, ones, xx, "sum")
     mag, _ = oracle_mod.spmm_fw(rp, cl, ones, np.abs(xx), "sum")
-    got = out.cpu().numpy()
-    assert np.all(np.abs(got - ref) <= 1e-5 * mag + 1e-30)
     third = _torch_cpu_spmm(rp, cl, ones, xx, "sum")
-    assert np.all(np.abs(got - third) <= 2e-5 * mag + 1e-30)
-    q = _quantiles("reddit sum K=128 sweep vs oracle", got, ref)
-    assert q[0] < 1e-5
+    for name, t in (("sweep", out), ("stream", st)):
+        got = t.cpu().numpy()
+        assert np.all(np.abs(got - ref) <= 1e-5 * mag + 1e-30), name
+        assert np.all(np.abs(got - third) <= 2e-5 * mag + 1e-30), name
+        q = _quantiles(f"reddit sum K=128 {name} vs oracle", got, ref)
+        assert q[0] < 1e-5
+    out = st
     deg = (rowptr[1:] - rowptr[:-1]).double()
     expect = (deg[:, None] * x.double()).sum(0)
     slack = 1e-8 * (deg[:, None] * x.double().abs()).sum(0)

@@ -614,3 +614,30 @@ def test_backward_sees_edge_weights_updated_in_place(gpu, oracle_mod):
             isplib_amd.matmul(adj, xs, red).backward(_t(g, gpu))
             _close(xs.grad, bw(rowptr, col, cur, 70, g), rtol=1e-5, atol=2e-5)
             value.copy_(_t(val1, gpu))              # what optimizer.step() does to a trainable weight vector
+
+
+@pytest.mark.parametrize("geom", ("4:3:64", "8:2:100000", "2:5:300"))
+def test_plugin_runs_sum_and_mean_on_the_stream_schedule(gpu, oracle_mod, monkeypatch, geom):
+    """The plug-in's default for sum / mean on large graphs, forced onto a small one (ISPLIB_STREAM_GEOM): forward through
+    a stream plan of A, backward through a stream plan of A^T whose weights are value[csr2csc] (sum) or the mean
+    backward's value[csr2csc] / max(deg, 1); trainable weights stepped in place are picked up by both plans."""
+    import isplib_amd
+    monkeypatch.setenv("ISPLIB_STREAM_GEOM", geom)
+    rowptr, col = cases.random_csr(150, 110, 30.0, seed=41, empty_rows=(5,), hub=(9, 900))
+    x, g = cases.dense(110, 64, 3), cases.dense(150, 64, 5)
+    val0, val1 = cases.weights(col.size, 4), cases.weights(col.size, 99)
+    tol = cases.sum_tolerance(oracle_mod, rowptr, col, np.maximum(val0, val1), x)
+    for weighted in (True, False):
+        for red, bw in (("sum", oracle_mod.spmm_sum_bw), ("mean", oracle_mod.spmm_mean_bw)):
+            value = _t(val0, gpu) if weighted else None
+            adj = isplib_amd.SparseTensor.from_csr(_t(rowptr, gpu), _t(col, gpu), value, (150, 110))
+            for cur in ((val0, val1) if weighted else (np.ones(col.size, np.float32),)):
+                xs = _t(x, gpu).requires_grad_(True)
+                out = isplib_amd.matmul(adj, xs, red)
+                out.backward(_t(g, gpu))
+                ref, _ = oracle_mod.spmm_fw(rowptr, col, cur, x, red)
+                assert np.all(np.abs(out.detach().cpu().numpy() - ref) <= tol), (red, weighted)
+                _close(xs.grad, bw(rowptr, col, cur, 110, g), rtol=1e-5, atol=2e-5)
+                if weighted:
+                    value.copy_(_t(val1, gpu))
+            assert any(k[0] is False for k in adj.storage._streams) and any(k[0] is True for k in adj.storage._streams), "stream plans were not used"
