@@ -59,24 +59,21 @@ def parse():
 
 
 def cpu_baseline(rowptr, col, x, nnz):
-    """Oracle on the host cores: whole workload, 1 pass to gauge, then more within ~15 s of wall clock (at most 9); median."""
+    """The oracle's SpMM-sum on the host cores (oracle/fusedmm_oracle.c: oracle_spmm_sum_timed): the same inner loop as
+    the parity oracle, run the way a careful OpenMP host would -- one contiguous nnz-balanced row block per thread,
+    index / value / output streams first-touched by the thread that streams them, the gathered operand spread over
+    all memory controllers.  Whole workload, 5 passes (about 5-10 s of CPU work), median.  For context: the oracle's
+    plain `schedule(dynamic,16)` entry on NumPy's single-node arrays, and torch.sparse.mm on a CSR tensor (MKL)."""
+    import numpy as np
     import oracle
     oracle.build()
     rp, cl, xx = rowptr.cpu().numpy(), col.cpu().numpy(), x.cpu().numpy()
-    import numpy as np
     val = np.ones(cl.size, np.float32)   # the reference materialises unit weights (isplib/__init__.py:51-57)
-    times = []
+    secs, _ = oracle.spmm_sum_timed(rp, cl, val, xx, reps=5)
+    t = float(np.median(secs))
     t0 = time.perf_counter()
     oracle.spmm_fw(rp, cl, val, xx, "sum")
-    times.append(time.perf_counter() - t0)
-    budget = 15.0 - times[0]
-    while len(times) < 9 and budget > times[0]:
-        t0 = time.perf_counter()
-        oracle.spmm_fw(rp, cl, val, xx, "sum")
-        times.append(time.perf_counter() - t0)
-        budget -= times[-1]
-    t = statistics.median(times) if len(times) > 1 else times[0]
-    # context only (SURVEY.md 8d): torch.sparse.mm on a CSR tensor on the same host cores
+    plain_ms = (time.perf_counter() - t0) * 1e3
     torch_ms = None
     try:
         csr = torch.sparse_csr_tensor(torch.from_numpy(rp), torch.from_numpy(cl), torch.from_numpy(val), size=(rp.size - 1, xx.shape[0]))
@@ -90,10 +87,13 @@ def cpu_baseline(rowptr, col, x, nnz):
         torch_ms = min(tt) * 1e3
     except Exception:  # noqa: BLE001 - context figure only
         pass
-    return {"value": nnz / t, "unit": "edges/s", "cores": oracle.num_threads(), "kind": "port", "torch_sparse_mm_ms": torch_ms,
-            "sample": f"whole workload, {len(times)} pass(es), median {t * 1e3:.1f} ms/pass; "
-                      "oracle/fusedmm_oracle.c (restated FusedMM-semantics kernel, -O3 -march=native -fopenmp)",
-            "ms_per_step": t * 1e3, "host_cpus": os.cpu_count()}
+    k = xx.shape[1]
+    return {"value": nnz / t, "unit": "edges/s", "cores": oracle.num_threads(), "kind": "port",
+            "sample": f"whole workload, 5 passes, median {t * 1e3:.1f} ms/pass (min {secs.min() * 1e3:.1f}); oracle/fusedmm_oracle.c "
+                      "oracle_spmm_sum_timed (restated FusedMM-semantics kernel, -O3 -march=native -fopenmp, static nnz-balanced "
+                      "row blocks, NUMA first touch)",
+            "ms_per_step": t * 1e3, "gathered_GBps": nnz * (12 + 4 * k) / t / 1e9, "host_cpus": os.cpu_count(),
+            "oracle_dynamic16_single_node_ms": plain_ms, "torch_sparse_mm_ms": torch_ms}
 
 
 def launcher_command(gpus: int, argv, port: int):
@@ -248,7 +248,7 @@ def main():
             raise SystemExit("--schedule stream: the stream schedule does not apply to this shape (isplib_suggest_stream)")
     if a.schedule in ("auto", "stream"):
         a.schedule = "tasks"            # what everything the stream schedule does not serve falls back to
-    use_stream = splan is not None
+    use_stream = splan is not None and not multi     # N > 1: decided by a short measurement below
 
     tplan = twork = None
     if a.schedule == "tasks" and a.slices > 0:
@@ -280,6 +280,8 @@ def main():
     #   gather+spmm      : one all-gather, then the SpMM (task list when a plan exists)
     #   overlapped sliced: local column slices aggregated while the all-gather is in flight
     #   pipelined xC     : X travels in C column panels; panel c is aggregated while panels c+1.. travel
+    #   direct xB        : P-1 per-peer send / receive pairs in B groups, a group's shards aggregated as it lands
+    #   gather+stream    : one all-gather, then the stream schedule
     # Every candidate is first checked against gather+spmm of the same kernel family (bit for bit, except that
     # panelled sums are held to the parity tests' 1e-5 bound: their summation order differs), then all
     # are timed for a few steps (max over ranks) and the fastest is kept: which one wins depends on how
@@ -342,6 +344,13 @@ def main():
                 fn = lambda: part.spmm_overlapped(x_shard, x_in, out, plan, a.reduce, arg)  # noqa: E731
                 if checked("overlapped sliced", fn, gather_then_sliced):
                     candidates["overlapped sliced"] = fn
+            if plan is not None and world > 1:
+                for nb in sorted({1, 2, world - 1}):
+                    if nb > world - 1:
+                        continue
+                    fn = (lambda b: lambda: part.spmm_direct(x_shard, x_in, out, plan, a.reduce, arg, batches=b))(nb)
+                    if checked(f"direct x{nb}", fn, gather_then_sliced):
+                        candidates[f"direct x{nb}"] = fn
             if tplan is not None:
                 for panels in (2, 4):
                     if k // panels < 16:
@@ -369,6 +378,8 @@ def main():
         chosen = min(times, key=times.get)
         use_tasks = tplan is not None and chosen != "overlapped sliced"
         use_stream = chosen == "gather+stream"
+        if chosen.startswith("direct"):
+            use_tasks = False
         if chosen not in ("gather+spmm", "gather+stream"):
             step_fn = candidates[chosen]
         if rank == 0:
@@ -480,7 +491,7 @@ def main():
             try:
                 rec = json.load(open(tpath)).get(f"{a.workload}-{a.reduce}-k{k}-" + (f"stream{splan.slices}" if use_stream else
                                                  f"s{a.slices}" + ("-tasks" if tplan is not None else "")))
-                traffic = rec["hbm_bytes_per_launch"] if rec else None
+                traffic = rec.get("fabric_bytes_per_launch", rec.get("hbm_bytes_per_launch")) if rec else None
             except Exception:
                 traffic = None
         if use_stream:
@@ -517,7 +528,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                "traffic_source": None if traffic is None else "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, gfx950-corrected)",
+                "traffic_source": None if traffic is None else "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled (gfx950), per launch; these are the bytes leaving the XCD L2s, Infinity-Cache hits included",
                 "kernel": kernel_label,
                 "kernel_avg_ms": kern_avg_ms, "kernel_median_ms": sorted(kern_ms)[len(kern_ms) // 2], "kernel_min_ms": min(kern_ms),
                 "kernel_cold_cache_ms": cold_ms, "peak_measured_copy": copy_gbps,

@@ -154,6 +154,54 @@ class RowPartition:
         return out
 
 
+    # ---- direct form: per-peer send / receive instead of one all-gather; shards are consumed as they land ----
+
+    def post_direct(self, x_shard: torch.Tensor, buf: torch.Tensor, batches: int = 2):
+        """Posts the P-1 send / receive pairs of one exchange of X in `batches` groups by ring distance (group b:
+        distances [bounds[b], bounds[b+1]): send to rank + d, receive the shard of rank - d into its place in `buf`).
+        Returns [(d0, d1, requests)] in the order the groups complete.  The own shard is not copied."""
+        P, r = self.world, self.rank
+        works = []
+        if P > 1:
+            batches = max(1, min(int(batches), P - 1))
+            bounds = [1 + (P - 1) * b // batches for b in range(batches + 1)]
+            for b in range(batches):
+                ops = []
+                for d in range(bounds[b], bounds[b + 1]):
+                    src = (r - d) % P
+                    ops.append(dist.P2POp(dist.isend, x_shard, (r + d) % P, group=self.group))
+                    ops.append(dist.P2POp(dist.irecv, buf[src * self.max_rows:(src + 1) * self.max_rows], src, group=self.group))
+                works.append((bounds[b], bounds[b + 1], dist.batch_isend_irecv(ops)))
+        return works
+
+    def spmm_direct(self, x_shard: torch.Tensor, buf: torch.Tensor, out: torch.Tensor, plan, reduce: str = "sum",
+                    arg: Optional[torch.Tensor] = None, batches: int = 2):
+        """The exchange of X as P-1 point-to-point transfers (over the xGMI full mesh every peer's shard
+        has its own link, so nothing has to travel a ring), issued in `batches` groups by ring distance: the transfers
+        of one group run concurrently (one RCCL group call: all its links busy), the groups one after the other, and
+        the column slices that lie in a group's shards are aggregated as soon as that group has landed -- own shard
+        first, straight from `x_shard`, while the first group is still on the links.  Same slices and the same fold
+        order as `fusedMM_csr_sliced_hip` over the gathered buffer: bitwise equal to it for every reduction.
+        `plan` = self.plan(k, reduce) (slice count a multiple of world).  batches = P-1 gives per-peer completion."""
+        from . import cabi
+        s, table, work = plan
+        k = x_shard.size(1)
+        msg = cabi.MESSAGE[reduce]
+        P, r = self.world, self.rank
+        q = s // P
+        common = (msg, self.rowptr, self.col_padded, self.val, table, s)
+        works = self.post_direct(x_shard, buf, batches)
+        # own shard: column ids are in the padded layout, so shift the base onto the shard
+        y_local = x_shard.data_ptr() - r * self.max_rows * x_shard.stride(0) * 4
+        cabi.fusedMM_csr_sliced_phase_hip(*common, r * q, q, P == 1, y_local, self.ncols_padded, k, x_shard.stride(0), out, arg, work)
+        for i, (d0, d1, reqs) in enumerate(works):
+            for req in reqs:
+                req.wait()
+            first = ((r - (d1 - 1)) % P) * q                 # shards r-d1+1 .. r-d0, ascending modulo P
+            cabi.fusedMM_csr_sliced_phase_hip(*common, first, (d1 - d0) * q, i == len(works) - 1, buf.data_ptr(), self.ncols_padded,
+                                              k, buf.stride(0), out, arg, work)
+        return out
+
     # ---- pipelined form: K is cut into panels, panel c+1 travels while panel c is aggregated -------
 
     def task_plan(self, slices: int, chunk: int = 1024, short_row: int = 128):
@@ -247,21 +295,22 @@ class DistGraph:
 def _spmm_auto(self, x_local: torch.Tensor) -> torch.Tensor:
     """Sum-SpMM of this partition on unpadded local rows [x_rows, K]: pads into the shard pitch, then
     ISPLIB_DIST_SCHEDULE = tasks (default: one all-gather, task-list SpMM) | overlap (local column slices
-    during the all-gather) | pipelined (two column panels, panel 2 travels while panel 1 is aggregated).
+    during the all-gather) | pipelined (two column panels, panel 2 travels while panel 1 is aggregated) | direct
+    (per-peer send / receive in ISPLIB_DIRECT_BATCHES groups, shards aggregated as they land).
     Whatever the schedule, a graph for which the slice rule says 0 runs gather + the plain kernel."""
     import os
     from . import cabi
     from .plugin import suggest_slices
     k = x_local.size(1)
     mode = os.environ.get("ISPLIB_DIST_SCHEDULE", "tasks")
-    if mode not in ("tasks", "overlap", "pipelined"):
-        raise ValueError(f"ISPLIB_DIST_SCHEDULE={mode!r}: expected tasks | overlap | pipelined")
+    if mode not in ("tasks", "overlap", "pipelined", "direct"):
+        raise ValueError(f"ISPLIB_DIST_SCHEDULE={mode!r}: expected tasks | overlap | pipelined | direct")
     cache = self.__dict__.setdefault("_auto", {})
     key = (k, mode)
     if key not in cache:
         s = suggest_slices(self.rows, self.ncols_padded, self.nnz, k)
         ops = None
-        if s > 0 and mode == "overlap":
+        if s > 0 and mode in ("overlap", "direct"):
             forced = os.environ.get("ISPLIB_SLICES")        # one-pass sliced kernel: its own (whole-row) slice rule
             ops = self.plan(k, "sum", slices=int(forced) if forced else None)
         elif s > 0 and mode == "pipelined" and k >= 32:
@@ -278,6 +327,8 @@ def _spmm_auto(self, x_local: torch.Tensor) -> torch.Tensor:
     out = torch.empty((self.rows, k), dtype=torch.float32, device=x_local.device)
     if ops is not None and mode == "overlap":
         return self.spmm_overlapped(shard, buf, out, ops, "sum")
+    if ops is not None and mode == "direct":
+        return self.spmm_direct(shard, buf, out, ops, "sum", batches=int(os.environ.get("ISPLIB_DIRECT_BATCHES", "2")))
     if ops is not None and mode == "pipelined" and k >= 32:
         return self.spmm_pipelined(shard, out, ops, "sum")
     self.all_gather(shard, buf)

@@ -144,6 +144,25 @@ def spmm_fw(rowptr, col, value, mat, reduce="sum"):
     return out, arg
 
 
+def spmm_sum_timed(rowptr, col, value, mat, reps=5):
+    """bench.py's CPU baseline: SpMM-sum with NUMA-aware placement and a static nnz-balanced row partition
+    (fusedmm_oracle.c: oracle_spmm_sum_timed).  Returns (seconds per pass [reps], out)."""
+    rowptr = np.ascontiguousarray(rowptr, np.int64)
+    col = np.ascontiguousarray(col, np.int64)
+    value = np.ascontiguousarray(value, np.float32)
+    mat = np.ascontiguousarray(mat, np.float32)
+    m, (n, k) = rowptr.size - 1, mat.shape
+    secs = np.zeros(reps, np.float64)
+    out = np.empty((m, k), np.float32)
+    fn = lib().oracle_spmm_sum_timed
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_int64] * 4 + [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    st = fn(m, n, k, col.size, _p(value), _p(col), _p(rowptr), _p(mat), int(reps), _p(secs), _p(out))
+    if st != 0:
+        raise RuntimeError(f"oracle_spmm_sum_timed returned status {st}")
+    return secs, out
+
+
 def csr_transpose(rowptr, col, ncols):
     """row, rowcount, colptr, csr2csc as torch_sparse's SparseStorage builds them
     (stable sort of the CSR entries by column) -- the operands the reference

@@ -305,6 +305,88 @@ int oracle_sddmm_csr(const INDEXTYPE m, const INDEXTYPE k,
    return ORC_SUCCESS;
 }
 
+/*
+ * Timed CPU baseline of the SpMM-sum (bench.py's cpu_baseline leg ONLY; same row_add as fusedMM_csr above, so the
+ * same results): what a careful OpenMP host would do on a many-socket machine.
+ *   - every thread owns one contiguous block of rows holding 1/T of the stored entries (static, nnz-balanced:
+ *     `dynamic,16` over a power-law degree sequence leaves the last threads with the hub rows);
+ *   - private copies of the index / value streams and of the output are allocated here and FIRST TOUCHED by the
+ *     thread that will stream them (NumPy's arrays were touched by one thread: every page on one NUMA node);
+ *   - the gathered operand y is read by everyone: it is first touched in interleaved 1/T pieces, so its pages are
+ *     spread over all memory controllers instead of one node's.
+ * reps passes are timed individually (seconds[0..reps)); z_out (m x k, may be NULL) receives the result.
+ */
+#include <stdlib.h>
+#include <string.h>
+int oracle_spmm_sum_timed(const INDEXTYPE m, const INDEXTYPE n, const INDEXTYPE k, const INDEXTYPE nnz,
+                          const VALUETYPE *val, const INDEXTYPE *indx, const INDEXTYPE *rowptr,
+                          const VALUETYPE *y, const int reps, double *seconds, VALUETYPE *z_out)
+{
+#ifdef _OPENMP
+   const int T = omp_get_max_threads();
+#else
+   const int T = 1;
+#endif
+   INDEXTYPE *cut = (INDEXTYPE *)malloc(((size_t)T + 1) * sizeof(INDEXTYPE));
+   VALUETYPE *lval = 0, *ly = 0, *lz = 0;
+   INDEXTYPE *lidx = 0;
+   if (!cut || posix_memalign((void **)&lval, 4096, ((size_t)nnz + 1) * sizeof(VALUETYPE)) ||
+       posix_memalign((void **)&lidx, 4096, ((size_t)nnz + 1) * sizeof(INDEXTYPE)) ||
+       posix_memalign((void **)&ly, 4096, ((size_t)n * k + 1) * sizeof(VALUETYPE)) ||
+       posix_memalign((void **)&lz, 4096, ((size_t)m * k + 1) * sizeof(VALUETYPE))) {
+      free(cut); free(lval); free(lidx); free(ly); free(lz);
+      return ORC_FAIL;
+   }
+   cut[0] = 0;
+   for (int t = 1; t <= T; t++) {           /* first row whose prefix reaches t/T of the entries */
+      const INDEXTYPE want = (INDEXTYPE)((double)nnz * t / T);
+      INDEXTYPE lo = cut[t - 1], hi = m;
+      while (lo < hi) { const INDEXTYPE mid = lo + (hi - lo) / 2; if (rowptr[mid] < want) lo = mid + 1; else hi = mid; }
+      cut[t] = t == T ? m : lo;
+   }
+#pragma omp parallel num_threads(T)
+   {
+#ifdef _OPENMP
+      const int t = omp_get_thread_num();
+#else
+      const int t = 0;
+#endif
+      const INDEXTYPE r0 = cut[t], r1 = cut[t + 1];
+      const INDEXTYPE e0 = rowptr[r0], e1 = rowptr[r1];
+      memcpy(lval + e0, val + e0, (size_t)(e1 - e0) * sizeof(VALUETYPE));
+      memcpy(lidx + e0, indx + e0, (size_t)(e1 - e0) * sizeof(INDEXTYPE));
+      memset(lz + r0 * k, 0, (size_t)(r1 - r0) * k * sizeof(VALUETYPE));
+      const INDEXTYPE y0 = n * t / T, y1 = n * (t + 1) / T;
+      memcpy(ly + y0 * k, y + y0 * k, (size_t)(y1 - y0) * k * sizeof(VALUETYPE));
+   }
+   for (int rep = 0; rep < reps; rep++) {
+#ifdef _OPENMP
+      const double t0 = omp_get_wtime();
+#endif
+#pragma omp parallel num_threads(T)
+      {
+#ifdef _OPENMP
+         const int t = omp_get_thread_num();
+#else
+         const int t = 0;
+#endif
+         for (INDEXTYPE i = cut[t]; i < cut[t + 1]; i++) {
+            VALUETYPE *zi = lz + i * k;
+            for (INDEXTYPE kk = 0; kk < k; kk++) zi[kk] = (VALUETYPE)0;       /* the launcher's zeros (csrc/fusedmm.cpp:152) */
+            row_add(lval, lidx, rowptr[i], rowptr[i + 1], k, ly, k, zi);
+         }
+      }
+#ifdef _OPENMP
+      seconds[rep] = omp_get_wtime() - t0;
+#else
+      seconds[rep] = 0.0;
+#endif
+   }
+   if (z_out) memcpy(z_out, lz, (size_t)m * k * sizeof(VALUETYPE));
+   free(cut); free(lval); free(lidx); free(ly); free(lz);
+   return ORC_SUCCESS;
+}
+
 int oracle_num_threads(void)
 {
 #ifdef _OPENMP

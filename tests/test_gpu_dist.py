@@ -31,7 +31,7 @@ val = cases.weights(col.size, 4)
 x, g = cases.dense(n, k, 3), cases.dense(n, k, 5)
 t = lambda a: torch.from_numpy(a).to(dev)
 # plain gather-then-SpMM, then the three schedules of a sliced graph (ISPLIB_DIST_SCHEDULE)
-for slices, mode in (("0", "tasks"), ("8", "tasks"), ("8", "overlap"), ("6", "pipelined")):
+for slices, mode in (("0", "tasks"), ("8", "tasks"), ("8", "overlap"), ("6", "pipelined"), ("8", "direct")):
     os.environ["ISPLIB_DIST_SCHEDULE"] = mode
     os.environ["ISPLIB_SLICES"] = slices            # the one-pass sliced kernel of `overlap` has its own rule: force it
     import isplib_amd.plugin as plugin
@@ -81,19 +81,41 @@ for kk in (32, 41):
         ref, _ = oracle.spmm_fw(rowptr, col, val, xk, red)
         if red == "max":
             assert np.array_equal(want.cpu().numpy(), ref[part.row0:part.row0 + part.rows])
+# direct per-peer exchange (P-1 send / receive pairs in 1, 2 or P-1 groups, shards aggregated as they land): bitwise
+# the column-sliced SpMM over the all-gathered buffer, every reduction, arg included
+plan = part.plan(32, "sum", slices=2 * world)
+xk = cases.dense(n, 32, 11)
+shard, buf = part.shard(t(xk)), part.gather_buffer(32)
+for red in ("sum", "mean", "max", "min"):
+    part.all_gather(shard, buf)
+    want, want_arg = cabi.spmm_sliced(part.rowptr, part.col_padded, part.val, plan[1], plan[0], buf, red)
+    for nb in sorted({{1, 2, max(world - 1, 1)}}):
+        buf.fill_(float("nan"))                     # nothing may be read before it has landed
+        out = torch.zeros((part.rows, 32), device=dev)
+        arg = torch.zeros((part.rows, 32), dtype=torch.int64, device=dev) if red in ("max", "min") else None
+        part.spmm_direct(shard, buf, out, (plan[0], plan[1], cabi.sliced_workspace(red, part.rows, 32, plan[0], dev)), red, arg, batches=nb)
+        torch.cuda.synchronize()
+        assert torch.equal(out, want), (red, nb)
+        if arg is not None:
+            assert torch.equal(arg, want_arg), (red, nb)
+        dist.barrier()
+    ref, _ = oracle.spmm_fw(rowptr, col, val, xk, red)
+    if red in ("max", "min"):
+        assert np.array_equal(want.cpu().numpy(), ref[part.row0:part.row0 + part.rows])
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
 """
 
 
-def test_dist_graph_forward_backward_two_ranks_on_one_gpu(gpu, tmp_path):
+@pytest.mark.parametrize("world", (2, 4))
+def test_dist_graph_forward_backward_ranks_share_one_gpu(gpu, tmp_path, world):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER.format(root=ROOT))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", WORLD_SIZE="2", OMP_NUM_THREADS="4")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29547 + world), WORLD_SIZE=str(world), OMP_NUM_THREADS="4")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
-                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
-    outs = [p.communicate(timeout=300)[0] for p in procs]
+                              stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{o[-3000:]}"
         assert f"rank {r} ok" in o

@@ -202,6 +202,20 @@ for red in ("sum", "mean", "max", "min"):
     if arg is not None:
         garg = np.where(arg == part.nnz, part.total_nnz, arg + part.edge0)
         assert np.array_equal(garg, ref_arg[r0:r1]), red
+# the direct per-peer exchange (P-1 send / receive pairs in 1, 2 or P-1 groups) fills the same buffer as the all-gather
+want = buf.clone()
+shard = part.shard(t(x))
+for nb in sorted({{1, 2, max(world - 1, 1)}}):
+    got = torch.full_like(buf, float("nan"))
+    landed = set()
+    for d0, d1, reqs in part.post_direct(shard, got, nb):
+        for req in reqs:
+            req.wait()
+        landed.update((rank - d) % world for d in range(d0, d1))
+    assert landed == set(range(world)) - {{rank}}
+    got[rank * part.max_rows:(rank + 1) * part.max_rows] = shard
+    assert torch.equal(got, want), nb
+    dist.barrier()
 sizes = [part.row_cuts[i + 1] - part.row_cuts[i] for i in range(world)]
 assert sum(sizes) == 97
 dist.barrier()
@@ -210,12 +224,13 @@ print("rank", rank, "ok")
 """
 
 
-def test_row_partition_equivalence_gloo_world2(tmp_path):
+@pytest.mark.parametrize("world", (2, 3))
+def test_row_partition_equivalence_gloo(tmp_path, world):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER.format(root=ROOT))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29541 + world), WORLD_SIZE=str(world), OMP_NUM_THREADS="2")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
-                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+                              stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = [p.communicate(timeout=240)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{o}"

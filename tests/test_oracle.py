@@ -258,3 +258,14 @@ def test_generic_pipeline_status_codes(oracle_mod):
     assert call(_word(2, 0, 1, 3, 2)) == 128           # MEAN with MAX
     assert call(_word(0, 0, 1, 1, 1)) == 128           # VOP_NOOP: nothing to aggregate
     assert call(_word(2, 0, 1, 1, 0)) == 128           # AOP_NOOP
+
+
+def test_timed_baseline_entry_computes_the_same_rows(oracle_mod):
+    """bench.py's cpu_baseline leg (static nnz-balanced row blocks, first-touch placement) runs the oracle's own inner
+    loop: bit-identical output, hub row and empty rows included."""
+    rowptr, col = cases.random_csr(500, 300, 12.0, seed=8, empty_rows=(0, 499), hub=(17, 4000))
+    val = cases.weights(col.size, 4)
+    x = cases.dense(300, 24, 3)
+    ref, _ = oracle_mod.spmm_fw(rowptr, col, val, x, "sum")
+    secs, out = oracle_mod.spmm_sum_timed(rowptr, col, val, x, reps=2)
+    assert secs.shape == (2,) and np.all(secs >= 0) and np.array_equal(out, ref)
