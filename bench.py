@@ -54,6 +54,7 @@ def parse():
     p.add_argument("--short", type=int, default=128, help="tasks: rows shorter than this are not sliced")
     p.add_argument("--tune", default="", help="debug: comma list of key=value for isplib_hip_tune")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-extra", action="store_true", help="skip the other BASELINE.json configs (the `extra` array)")
     p.add_argument("--no-backward", action="store_true")
     return p.parse_args()
 
@@ -94,6 +95,152 @@ def cpu_baseline(rowptr, col, x, nnz):
                       "row blocks, NUMA first touch)",
             "ms_per_step": t * 1e3, "gathered_GBps": nnz * (12 + 4 * k) / t / 1e9, "host_cpus": os.cpu_count(),
             "oracle_dynamic16_single_node_ms": plain_ms, "torch_sparse_mm_ms": torch_ms}
+
+
+def _time_launches(fn, reps=5, warm=2):
+    for _ in range(warm):
+        fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps
+
+
+def extra_configs(dev, rowptr, col, n, with_cpu_epoch=True):
+    """The other configurations of BASELINE.json under the same clock as the headline (N = 1, outside its timed region):
+    config 3 (Reddit-shaped mean / max / min, K=64, weighted), config 2 with weights, config 4's shape on one GPU
+    (ogbn-products-shaped, K=256) and config 5 (2-layer GCN epoch through the plug-in) with the oracle-aggregated CPU
+    epoch beside it.  Each entry: ms per launch (HIP events, 5 launches), edges/s, roofline fraction from its own
+    algorithmic bytes, and the schedule that ran."""
+    import numpy as np
+    from isplib_amd import cabi, synth
+    from isplib_amd.plan import build_stream_plan, build_task_plan
+    from isplib_amd.plugin import skew_adjusted, suggest_slices
+    out = []
+    nnz = col.numel()
+    col32 = cabi.pack_indices(col)
+    w = synth.edge_weights(nnz, device=dev)
+
+    def entry(name, ms, m, nn, e, k, with_arg, schedule):
+        b_alg = synth.algorithmic_bytes(m, nn, e, k, with_arg)
+        out.append({"config": name, "ms": ms, "edges_per_s": e / (ms * 1e-3), "schedule": schedule,
+                    "roofline": {"bound": "hbm", "achieved": b_alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                 "frac": b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": b_alg}})
+
+    def run(red, k, val, name):
+        x = synth.features(n, k, device=dev, integer=red in ("max", "min"))
+        z = torch.empty((n, k), dtype=torch.float32, device=dev)
+        arg = torch.empty((n, k), dtype=torch.int64, device=dev) if red in ("max", "min") else None
+        msg = cabi.MESSAGE[red]
+        geom = cabi.suggest_stream(n, n, nnz, k) if red in ("sum", "mean") else None
+        if geom is not None:
+            plan = build_stream_plan(rowptr, col, val, n, geom[1], None, None, geom[0], geom[2])
+            ws = plan.workspace()
+            ms = _time_launches(lambda: cabi.fusedMM_csr_stream_hip(msg, rowptr, nnz, plan, x, z, ws))
+            sched = f"stream, {plan.slices} slices, {plan.gens} generation(s)"
+        else:
+            sl = skew_adjusted(rowptr, suggest_slices(n, n, nnz, k, red in ("max", "min")))
+            plan = build_task_plan(rowptr, col, n, sl, col32=col32)
+            ws = plan.workspace(red, k)
+            ms = _time_launches(lambda: cabi.fusedMM_csr_tasks_hip(msg, rowptr, col, val, plan, x, z, arg, ws))
+            sched = f"task list, {sl} slices"
+        entry(name, ms, n, n, nnz, k, arg is not None, sched)
+
+    for red in ("mean", "max", "min"):
+        run(red, 64, w, f"config 3: reddit-like SpMM-{red} K=64, U(0,1) weights" + (" (+arg)" if red != "mean" else ""))
+    run("sum", 128, w, "config 2: reddit-like SpMM-sum K=128, U(0,1) weights")
+    del w, col32
+
+    # config 5: the GCN epoch of tests/cpu/gcn-sparse.py:55-129 through iSpLibPlugin.patch_pyg (scripts/gcn_epoch.py restates it)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gcn_epoch", os.path.join(ROOT, "scripts", "gcn_epoch.py"))
+    ge = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ge)
+    import isplib_amd
+    import torch.nn.functional as F
+    torch.manual_seed(0)
+    feats, hidden, classes = 602, 32, 41
+    x = synth.features(n, feats, device=dev)
+    y = torch.randint(0, classes, (n,), device=dev)
+    mask = torch.rand(n, device=dev) < 0.66
+    n_train = int(mask.sum())
+    model = ge.Net(feats, hidden, classes).to(dev)
+    init = {k_: v.detach().cpu().clone() for k_, v in model.state_dict().items()}
+    opt = torch.optim.Adam(model.parameters(), lr=0.01, weight_decay=5e-4)
+    adj = isplib_amd.SparseTensor.from_csr(rowptr, col, None, (n, n), validate=False)
+    isplib_amd.iSpLibPlugin.patch_pyg()
+    times = []
+    try:
+        for epoch in range(6):                      # epoch 0 builds the per-graph operands; not timed
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            model.train()
+            opt.zero_grad()
+            o = model(x, adj, isplib_amd.matmul)
+            loss = F.nll_loss(o[mask], y[mask], reduction="sum") / n_train
+            loss.backward()
+            opt.step()
+            model(x, adj, isplib_amd.matmul).argmax(1)        # the second forward of :89
+            torch.cuda.synchronize()
+            if epoch:
+                times.append(time.perf_counter() - t0)
+    finally:
+        isplib_amd.iSpLibPlugin.unpatch_pyg()
+    gpu_epoch_ms = statistics.mean(times) * 1e3
+    rec = {"config": "config 5: 2-layer GCN 602-32-41 epoch on the reddit-like graph through iSpLibPlugin.patch_pyg (6 SpMM + dense + Adam)",
+           "ms": gpu_epoch_ms, "epoch_ms_std": statistics.pstdev(times) * 1e3, "epochs_timed": len(times)}
+    if with_cpu_epoch:
+        # the same epoch on the host cores with the oracle doing every aggregation (the reference's CPU mode `isplib`,
+        # tests/cpu/gcn-sparse.py:29-36,83-92): A is symmetric with unit weights here, so A^T dY is the same call
+        import oracle
+        oracle.build()
+        rp, cl = rowptr.cpu().numpy(), col.cpu().numpy()
+        ones = np.ones(cl.size, np.float32)
+
+        class CpuAgg(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, mat):
+                return torch.from_numpy(oracle.spmm_fw(rp, cl, ones, mat.detach().numpy(), "sum")[0])
+
+            @staticmethod
+            def backward(ctx, g):
+                return torch.from_numpy(oracle.spmm_fw(rp, cl, ones, g.contiguous().numpy(), "sum")[0])
+
+        cpu_model = ge.Net(feats, hidden, classes)
+        cpu_model.load_state_dict(init)
+        cpu_opt = torch.optim.Adam(cpu_model.parameters(), lr=0.01, weight_decay=5e-4)
+        xc, yc, mc = x.cpu(), y.cpu(), mask.cpu()
+        agg = lambda a_, m_, r_: CpuAgg.apply(m_)  # noqa: E731
+        ctimes = []
+        for epoch in range(3):
+            t0 = time.perf_counter()
+            cpu_model.train()
+            cpu_opt.zero_grad()
+            o = cpu_model(xc, None, agg)
+            loss = F.nll_loss(o[mc], yc[mc], reduction="sum") / n_train
+            loss.backward()
+            cpu_opt.step()
+            cpu_model(xc, None, agg).argmax(1)
+            if epoch:
+                ctimes.append(time.perf_counter() - t0)
+        rec["cpu_epoch"] = {"ms": statistics.mean(ctimes) * 1e3, "epochs_timed": len(ctimes), "cores": oracle.num_threads(), "kind": "port",
+                            "what": "the same model and epoch structure on the host cores, every aggregation by oracle/fusedmm_oracle.c "
+                                    "(OpenMP), dense layers and Adam by torch CPU"}
+    out.append(rec)
+    del x, y, mask, model, opt, adj
+
+    # config 4's shape on ONE GPU: the dense operand (2.5 GB) is ten times the Infinity Cache; no schedule reuses it
+    # (isplib_suggest_stream / isplib_suggest_slices both say so): plain row-per-wave kernel
+    torch.cuda.empty_cache()
+    p_rowptr, p_col, pn = synth.dataset_like("products", device=dev)
+    px = synth.features(pn, 256, device=dev)
+    pz = torch.empty((pn, 256), dtype=torch.float32, device=dev)
+    ms = _time_launches(lambda: cabi.fusedMM_csr_hip(cabi.MSG_SPMM_SUM, p_rowptr, p_col, None, px, pz))
+    entry("config 4 (one GPU): products-like SpMM-sum K=256, unit weights", ms, pn, pn, p_col.numel(), 256, False, "plain row-per-wave kernel")
+    return out
 
 
 def launcher_command(gpus: int, argv, port: int):
@@ -541,6 +688,10 @@ def main():
             res["backward"] = bwd
         if not multi and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(rowptr, col, x, nnz)
+        if not multi and not a.no_extra and a.workload == "reddit" and a.scale == 1.0 and a.generator == "chunglu":
+            del x, out
+            torch.cuda.empty_cache()
+            res["extra"] = extra_configs(dev, rowptr, col, n, with_cpu_epoch=not a.no_cpu_baseline)
         print(json.dumps(res), flush=True)
     if multi:
         dist.barrier()
