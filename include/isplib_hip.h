@@ -396,6 +396,21 @@ int isplib_spmm_minmax_bw_hip(int64_t m, int64_t n, int64_t k, int64_t nnz,
                               float *grad_val, void *stream);
 
 /*
+ * The same gradients WITHOUT atomics: bitwise reproducible from launch to launch, like the reference's CPU
+ * scatter_add_ (csrc/fusedmm.cpp:421-446).  grad_mat: the (destination, value) pairs of all (row, feature)
+ * elements are sorted by destination with a stable radix sort and every run is added up in ascending row order by one
+ * thread; grad_val: every destination of row i is an entry of row i, so one thread per row updates them in feature
+ * order.  workspace: isplib_spmm_minmax_bw_workspace_bytes(m, n, k) bytes, 256-byte aligned (0 = not served:
+ * n*k + 1 or m*k beyond 32-bit keys -- use the atomic form above).
+ */
+size_t isplib_spmm_minmax_bw_workspace_bytes(int64_t m, int64_t n, int64_t k);
+int isplib_spmm_minmax_bw_det_hip(int64_t m, int64_t n, int64_t k, int64_t nnz,
+                                  const int64_t *indx, const float *val,
+                                  const float *mat, const int64_t *arg,
+                                  const float *grad_out, float *grad_mat,
+                                  float *grad_val, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * SDDMM-style value gradient of SpMM-sum / SpMM-mean:
  *   dval[j] = < y[indx[j], :], g[i, :] > * (mean ? 1/max(deg_i,1) : 1),  j in row i
  */

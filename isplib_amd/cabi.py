@@ -52,7 +52,7 @@ EXPORTS = (
     "isplib_suggest_slices", "isplib_graph_create", "isplib_graph_set_slices", "isplib_graph_spmm", "isplib_graph_spmm_backward",
     "isplib_graph_destroy", "isplib_suggest_slices_whole_rows", "isplib_graph_sddmm",
     "fusedMM_csr_sweep_hip", "isplib_spmm_sweep_workspace_bytes", "isplib_spmm_sweep_resident_waves",
-    "fusedMM_csr_stream_hip", "isplib_spmm_stream_workspace_bytes", "isplib_spmm_stream_geometry", "isplib_suggest_stream",
+    "fusedMM_csr_stream_hip", "isplib_spmm_stream_workspace_bytes", "isplib_spmm_stream_geometry", "isplib_suggest_stream", "isplib_spmm_minmax_bw_det_hip", "isplib_spmm_minmax_bw_workspace_bytes",
 )
 
 _i64, _f32, _vp, _i32 = ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_int32
@@ -169,6 +169,10 @@ def lib() -> ctypes.CDLL:
         L.isplib_graph_destroy.argtypes = [_vp]
         L.isplib_hip_tune.restype = ctypes.c_int
         L.isplib_hip_tune.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.isplib_spmm_minmax_bw_workspace_bytes.restype = ctypes.c_size_t
+        L.isplib_spmm_minmax_bw_workspace_bytes.argtypes = [_i64, _i64, _i64]
+        L.isplib_spmm_minmax_bw_det_hip.restype = ctypes.c_int
+        L.isplib_spmm_minmax_bw_det_hip.argtypes = [_i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]
         L.isplib_suggest_stream.restype = ctypes.c_int
         L.isplib_suggest_stream.argtypes = [_i64, _i64, _i64, _i64, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
         L.isplib_spmm_stream_geometry.restype = ctypes.c_int
@@ -288,7 +292,8 @@ def perform_dummy_spmm(flag: int = 0) -> None:
     lib().performDummySpMM_hip(int(flag), _stream(None))
 
 
-def spmm_minmax_bw(col, val, mat, arg, grad_out, need_mat=True, need_val=True):
+def spmm_minmax_bw(col, val, mat, arg, grad_out, need_mat=True, need_val=True, deterministic=False):
+    """(grad_val, grad_mat) of SpMM-max/min; deterministic=True: the atomic-free form (isplib_spmm_minmax_bw_det_hip)."""
     col = _dev(col, "col", torch.int64)
     mat = _dev(mat, "mat", torch.float32)
     arg = _dev(arg, "arg", torch.int64)
@@ -300,6 +305,13 @@ def spmm_minmax_bw(col, val, mat, arg, grad_out, need_mat=True, need_val=True):
     grad_mat = torch.empty_like(mat) if need_mat else None
     grad_val = torch.empty(nnz, dtype=torch.float32, device=mat.device) if need_val else None
     with torch.cuda.device(mat.device):
+        if deterministic:
+            ws = lib().isplib_spmm_minmax_bw_workspace_bytes(m, n, k)
+            work = torch.empty(max(ws, 256), dtype=torch.uint8, device=mat.device)
+            st = lib().isplib_spmm_minmax_bw_det_hip(m, n, k, nnz, _ptr(col), _ptr(val), _ptr(mat), _ptr(arg), _ptr(grad_out),
+                                                     _ptr(grad_mat), _ptr(grad_val), _ptr(work), work.numel(), _stream(mat.device))
+            _check(st, "isplib_spmm_minmax_bw_det_hip")
+            return grad_val, grad_mat
         st = lib().isplib_spmm_minmax_bw_hip(m, n, k, nnz, _ptr(col), _ptr(val), _ptr(mat), _ptr(arg), _ptr(grad_out),
                                              _ptr(grad_mat), _ptr(grad_val), _stream(mat.device))
     _check(st, "isplib_spmm_minmax_bw_hip")

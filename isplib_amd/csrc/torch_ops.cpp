@@ -144,6 +144,18 @@ struct GraphKeyHash {
 };
 std::mutex g_graph_mutex;
 std::unordered_map<GraphKey, GraphCacheEntry, GraphKeyHash> g_graphs;
+// Handles whose graph is gone or has changed.  isplib_graph_destroy synchronises the device (nothing of the handle's may
+// still be in flight when its memory goes), which must not happen inside somebody's forward call: retired handles wait
+// here until graph_cache_clear() -- or, should a process retire graphs by the dozen, until the list is 32 long.
+std::vector<isplib_graph *> g_retired;
+
+void retire_handle_locked(isplib_graph *h) {
+   g_retired.push_back(h);
+   if (g_retired.size() >= 32) {
+      for (isplib_graph *r : g_retired) isplib_graph_destroy(r);
+      g_retired.clear();
+   }
+}
 
 // runs the SpMM through a cached handle; false = not applicable (caller falls through to the plain kernel)
 // the handle of (rowptr, col, value) with N dense rows; g_graph_mutex must be held
@@ -152,14 +164,14 @@ isplib_graph *graph_handle_locked(const Tensor &rowptr, const Tensor &col, const
    const GraphKey key{rowptr.data_ptr(), col.data_ptr(), value.defined() ? value.data_ptr() : nullptr, N};
    auto it = g_graphs.find(key);
    if (it != g_graphs.end() && !it->second.matches(rowptr, col, value)) {
-      isplib_graph_destroy(it->second.handle);
+      retire_handle_locked(it->second.handle);
       g_graphs.erase(it);
       it = g_graphs.end();
    }
    if (it == g_graphs.end()) {
       for (auto dead = g_graphs.begin(); dead != g_graphs.end();) {      // graphs whose tensors are gone
          if (!dead->second.alive()) {
-            isplib_graph_destroy(dead->second.handle);
+            retire_handle_locked(dead->second.handle);
             dead = g_graphs.erase(dead);
          } else {
             ++dead;
@@ -545,11 +557,22 @@ class SpmmMinMax : public torch::autograd::Function<SpmmMinMax<RED>> {
          if (need_val) grad_value = at::empty({nnz}, y.options());
          if (need_mat) grad_mat = at::empty({N, K}, y.options());
          // one fused pass for :417-446 (mask, gather, mul, masked_fill, scatter_add x2)
-         const int st = isplib_spmm_minmax_bw_hip(
-             M, N, K, nnz, col.data_ptr<int64_t>(), has_value ? value.data_ptr<float>() : nullptr, y.data_ptr<float>(),
-             arg_out.data_ptr<int64_t>(), grad_out.data_ptr<float>(), need_mat ? grad_mat.data_ptr<float>() : nullptr,
-             need_val ? grad_value.data_ptr<float>() : nullptr, current_stream(y));
-         check_status(st, "isplib_spmm_minmax_bw_hip");
+         // the atomic-free form (bitwise reproducible gradients) wherever its 32-bit keys reach; else the one-pass scatter
+         const size_t ws = isplib_spmm_minmax_bw_workspace_bytes(M, N, K);
+         if (ws > 0) {
+            Tensor work = at::empty({(int64_t)ws}, y.options().dtype(at::kByte));
+            const int st = isplib_spmm_minmax_bw_det_hip(
+                M, N, K, nnz, col.data_ptr<int64_t>(), has_value ? value.data_ptr<float>() : nullptr, y.data_ptr<float>(),
+                arg_out.data_ptr<int64_t>(), grad_out.data_ptr<float>(), need_mat ? grad_mat.data_ptr<float>() : nullptr,
+                need_val ? grad_value.data_ptr<float>() : nullptr, work.data_ptr(), ws, current_stream(y));
+            check_status(st, "isplib_spmm_minmax_bw_det_hip");
+         } else {
+            const int st = isplib_spmm_minmax_bw_hip(
+                M, N, K, nnz, col.data_ptr<int64_t>(), has_value ? value.data_ptr<float>() : nullptr, y.data_ptr<float>(),
+                arg_out.data_ptr<int64_t>(), grad_out.data_ptr<float>(), need_mat ? grad_mat.data_ptr<float>() : nullptr,
+                need_val ? grad_value.data_ptr<float>() : nullptr, current_stream(y));
+            check_status(st, "isplib_spmm_minmax_bw_hip");
+         }
       }
       return {Variable(), Variable(), grad_value, grad_mat, Variable()};
    }
@@ -665,6 +688,8 @@ void graph_cache_clear() {
    std::lock_guard<std::mutex> lock(g_graph_mutex);
    for (auto &kv : g_graphs) isplib_graph_destroy(kv.second.handle);
    g_graphs.clear();
+   for (isplib_graph *r : g_retired) isplib_graph_destroy(r);
+   g_retired.clear();
 }
 
 void performDummySpMM(int64_t flag) { performDummySpMM_hip(flag, (void *)c10::hip::getCurrentHIPStream().stream()); }
