@@ -5,11 +5,11 @@
 // bits.  This form gives bitwise reproducible gradients at about the same cost:
 //   grad_mat[j, c] = sum over the rows i whose arg[i, c] names an entry of column j, of val[arg] * grad_out[i, c]:
 //       every (i, c) becomes a (key = j * k + c, value) pair -- the key IS the flat index of its destination -- the
-//       pairs are sorted by key with a STABLE radix sort (rocPRIM; equal keys keep ascending i), and the thread that
-//       finds the head of a run adds the run up in that order and stores it.  No two threads write one element.
+//       pairs are sorted by key with a STABLE radix sort (rocPRIM; equal keys keep ascending i), and every run of equal
+//       keys is added up in that order (two levels, see below).  No two threads write one element.
 //   grad_val[a]    = sum over the features c of row i with arg[i, c] == a of mat[indx[a], c] * grad_out[i, c]:
-//       every destination of row i is an entry OF row i, so one thread per row walks its k features in order and
-//       updates grad_val in place.
+//       every destination of row i is an entry OF row i, so one wave per row adds the features of each entry in
+//       lane order and updates grad_val in place.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -39,29 +39,97 @@ __global__ __launch_bounds__(256) void minmax_pairs_kernel(int64_t total, int64_
    }
 }
 
-__global__ __launch_bounds__(256) void minmax_runs_kernel(int64_t total, uint32_t limit, const uint32_t *__restrict__ keys,
-                                                          const float *__restrict__ vals, float *__restrict__ grad_mat) {
+// Run sums in two levels, so that a destination with thousands of contributions (a hub column wins in many rows) does
+// not leave one thread adding them up alone.  Level 1: every thread walks its own RUN_CHUNK consecutive sorted pairs;
+// runs that begin and end inside the chunk are finished there; of a run that crosses chunk borders the thread keeps
+// its piece: `open` = the piece of a run that begins here and goes on, `cont` = the piece of a run that began earlier.
+// Level 2: the thread of every chunk with an open run adds the following chunks' cont pieces from left to right.
+// Every sum is formed in one fixed order (ascending row inside a chunk, then chunk by chunk).
+constexpr int RUN_CHUNK = 32;
+enum { RUN_OPEN = 1, RUN_CONT_ENDS = 2, RUN_CONT_GOES_ON = 4 };
+
+__global__ __launch_bounds__(256) void minmax_chunks_kernel(int64_t total, uint32_t limit, const uint32_t *__restrict__ keys,
+                                                            const float *__restrict__ vals, float *__restrict__ grad_mat,
+                                                            float *__restrict__ open_sum, float *__restrict__ cont_sum,
+                                                            unsigned char *__restrict__ state) {
+   const int64_t nchunks = (total + RUN_CHUNK - 1) / RUN_CHUNK;
    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-      const uint32_t key = keys[t];
-      if (key >= limit || (t > 0 && keys[t - 1] == key)) continue;      // not the head of a run of destinations
-      float acc = vals[t];
-      for (int64_t u = t + 1; u < total && keys[u] == key; u++) acc += vals[u];
+   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nchunks; t += stride) {
+      const int64_t base = t * RUN_CHUNK, end = base + RUN_CHUNK < total ? base + RUN_CHUNK : total;
+      const bool has_prev = base > 0;
+      const uint32_t prev_key = has_prev ? keys[base - 1] : 0u;
+      unsigned st = 0;
+      float o = 0.0f, c = 0.0f;
+      int64_t i = base;
+      while (i < end) {
+         const uint32_t key = keys[i];
+         float acc = vals[i];
+         int64_t j = i + 1;
+         while (j < end && keys[j] == key) acc += vals[j++];
+         const bool begins_here = !(i == base && has_prev && key == prev_key);
+         const bool ends_here = j < end || j == total || keys[j] != key;
+         if (key < limit) {
+            if (begins_here && ends_here) grad_mat[key] = acc;
+            else if (begins_here) { o = acc; st |= RUN_OPEN; }
+            else { c = acc; st |= ends_here ? RUN_CONT_ENDS : RUN_CONT_GOES_ON; }
+         }
+         i = j;
+      }
+      open_sum[t] = o;
+      cont_sum[t] = c;
+      state[t] = (unsigned char)st;
+   }
+}
+
+__global__ __launch_bounds__(256) void minmax_open_runs_kernel(int64_t total, const uint32_t *__restrict__ keys,
+                                                               const float *__restrict__ open_sum, const float *__restrict__ cont_sum,
+                                                               const unsigned char *__restrict__ state, float *__restrict__ grad_mat) {
+   const int64_t nchunks = (total + RUN_CHUNK - 1) / RUN_CHUNK;
+   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nchunks; t += stride) {
+      if (!(state[t] & RUN_OPEN)) continue;
+      const uint32_t key = keys[(t + 1) * RUN_CHUNK - 1];                 // an open run reaches the end of its (full) chunk
+      float acc = open_sum[t];
+      for (int64_t u = t + 1; u < nchunks; u++) {
+         const unsigned su = state[u];
+         if (!(su & (RUN_CONT_ENDS | RUN_CONT_GOES_ON))) break;
+         acc += cont_sum[u];
+         if (su & RUN_CONT_ENDS) break;
+      }
       grad_mat[key] = acc;
    }
 }
 
+// grad_val: one wave per row, lanes over the features.  Every lane adds up, in lane order, the contributions of all
+// lanes of its 64-feature group that point at the same stored entry; the first such lane adds the sum to grad_val.
+// The groups of a row follow each other in the same wave: one fixed order per entry, nobody else writes it.
 __global__ __launch_bounds__(256) void minmax_dval_rows_kernel(int64_t m, int64_t k, int64_t nnz, const int64_t *__restrict__ indx,
                                                                const float *__restrict__ mat, const int64_t *__restrict__ arg,
                                                                const float *__restrict__ grad_out, float *grad_val) {
-   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
-      const int64_t *ar = arg + i * k;
-      const float *gr = grad_out + i * k;
-      for (int64_t c = 0; c < k; c++) {
-         const int64_t a = ar[c];
-         if (a < 0 || a >= nnz) continue;
-         grad_val[a] += mat[indx[a] * k + c] * gr[c];   // a is an entry of row i: this thread is its only writer
+   const int lane = threadIdx.x & 63;
+   const int64_t waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+   for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < m; i += waves) {
+      for (int64_t c0 = 0; c0 < k; c0 += 64) {
+         const int64_t c = c0 + lane;
+         int64_t a = -1;
+         float v = 0.0f;
+         if (c < k) {
+            a = arg[i * k + c];
+            if (a >= 0 && a < nnz) v = mat[indx[a] * k + c] * grad_out[i * k + c];
+            else a = -1;
+         }
+         const int a_lo = (int)(uint32_t)a, a_hi = (int)(uint32_t)((uint64_t)a >> 32);
+         const int v_bits = __float_as_int(v);
+         float acc = 0.0f;
+         bool first = a >= 0;
+#pragma unroll 8
+         for (int l = 0; l < 64; l++) {
+            const bool same = a >= 0 && __builtin_amdgcn_readlane(a_lo, l) == a_lo && __builtin_amdgcn_readlane(a_hi, l) == a_hi;
+            const float vl = __int_as_float(__builtin_amdgcn_readlane(v_bits, l));
+            if (same) acc += vl;
+            if (same && l < lane) first = false;
+         }
+         if (first) grad_val[a] += acc;
       }
    }
 }
@@ -91,7 +159,8 @@ extern "C" size_t isplib_spmm_minmax_bw_workspace_bytes(int64_t m, int64_t n, in
    const int64_t total = m * k;
    size_t temp = 0;
    if (pair_sort_temp(total, bits_for((uint64_t)(n * k + 1)), &temp) != hipSuccess) { (void)hipGetLastError(); return 0; }
-   return 4 * up256((size_t)total * 4) + up256(temp) + 256;
+   const size_t nchunks = ((size_t)total + RUN_CHUNK - 1) / RUN_CHUNK;
+   return 4 * up256((size_t)total * 4) + up256(temp) + 2 * up256(nchunks * 4) + up256(nchunks) + 256;
 }
 
 extern "C" int isplib_spmm_minmax_bw_det_hip(int64_t m, int64_t n, int64_t k, int64_t nnz, const int64_t *indx, const float *val,
@@ -107,7 +176,7 @@ extern "C" int isplib_spmm_minmax_bw_det_hip(int64_t m, int64_t n, int64_t k, in
    if (!indx || !arg || !grad_out) return fail(ISPLIB_FAIL, "isplib_spmm_minmax_bw_det_hip: null operand");
    if (grad_val && !mat) return fail(ISPLIB_FAIL, "isplib_spmm_minmax_bw_det_hip: grad_val needs mat");
    if (grad_val) {
-      int64_t blocks = (m + 255) / 256;
+      int64_t blocks = (m + 3) / 4;                 // one wave per row
       if (blocks > 256 * 32) blocks = 256 * 32;
       hipLaunchKernelGGL(minmax_dval_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, st, m, k, nnz, indx, mat, arg, grad_out, grad_val);
       const int rc = check_launch("minmax_dval_rows_kernel");
@@ -135,6 +204,16 @@ extern "C" int isplib_spmm_minmax_bw_det_hip(int64_t m, int64_t n, int64_t k, in
    if (rc) return rc;
    ISPLIB_HIP_TRY((rocprim::radix_sort_pairs<rocprim::default_config, const uint32_t *, uint32_t *, const float *, float *>(
        temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)total, 0u, bits, st, false)));
-   hipLaunchKernelGGL(minmax_runs_kernel, dim3((unsigned)blocks), dim3(256), 0, st, total, limit, keys_out, vals_out, grad_mat);
-   return check_launch("minmax_runs_kernel");
+   const size_t nchunks = ((size_t)total + RUN_CHUNK - 1) / RUN_CHUNK;
+   float *open_sum = (float *)((char *)temp + up256(temp_bytes));
+   float *cont_sum = (float *)((char *)open_sum + up256(nchunks * 4));
+   unsigned char *state = (unsigned char *)((char *)cont_sum + up256(nchunks * 4));
+   int64_t cblocks = ((int64_t)nchunks + 255) / 256;
+   if (cblocks > 256 * 32) cblocks = 256 * 32;
+   hipLaunchKernelGGL(minmax_chunks_kernel, dim3((unsigned)cblocks), dim3(256), 0, st, total, limit, keys_out, vals_out, grad_mat, open_sum,
+                      cont_sum, state);
+   rc = check_launch("minmax_chunks_kernel");
+   if (rc) return rc;
+   hipLaunchKernelGGL(minmax_open_runs_kernel, dim3((unsigned)cblocks), dim3(256), 0, st, total, keys_out, open_sum, cont_sum, state, grad_mat);
+   return check_launch("minmax_open_runs_kernel");
 }
