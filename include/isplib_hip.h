@@ -357,7 +357,19 @@ typedef struct isplib_stream_plan {
    const int32_t *wave_part;        /* [dev] same shape: -1 = whole row, else partial row id */
    const int32_t *hub_row;          /* [dev] n_hub */
    const int32_t *hub_off;          /* [dev] n_hub + 1 */
+   const int32_t *perm;             /* [dev] n_steps*streams: CSR position of every word, -1 = padding (for re-gathering
+                                       weights); NULL in plans that do not carry it -- the kernel never reads it */
 } isplib_stream_plan;
+/* Native plan builder (the same construction as isplib_amd/plan.py, on the device with rocPRIM sorts): allocates the
+ * plan's device arrays -- release them with isplib_stream_plan_free -- and synchronises `stream` (twice: the sizes of
+ * the plan are data dependent).  streams / slices / chunk: from isplib_suggest_stream; waves_per_gen <= 0: what
+ * isplib_spmm_stream_geometry reports.  val may be NULL (unit weights).  isplib_stream_plan_set_values_hip re-gathers
+ * the weights (NULL: back to unit weights) when they change. */
+int  isplib_stream_plan_build_hip(int64_t m, int64_t n, int64_t nnz, const int64_t *rowptr, const int64_t *col,
+                                  const float *val, int streams, int slices, int chunk, int waves_per_gen,
+                                  isplib_stream_plan *out /*host*/, void *stream);
+int  isplib_stream_plan_set_values_hip(isplib_stream_plan *plan, const float *val /*[dev] nnz | NULL*/, void *stream);
+void isplib_stream_plan_free(isplib_stream_plan *plan);
 int    isplib_spmm_stream_geometry(int streams, int *rows_per_wave /*out*/, int *waves_resident /*out*/);
 /* the measured rule: nonzero when the stream schedule is expected to beat the task list for an m x n, nnz-entry SpMM
  * over k columns (sum / mean), with the plan parameters to build it with (streams, column slices, hub-row chunk) */
@@ -458,8 +470,9 @@ int    isplib_csr2csc_hip(int64_t m, int64_t n, int64_t nnz,
  *   isplib_graph_create   borrows rowptr[m+1] / col[nnz] / val[nnz]|NULL (device; must outlive the handle and
  *                         must not change: val is examined once, and a vector of exact 1.0f -- what
  *                         isplib/__init__.py:51-57 materialises for an unweighted graph -- is treated as NULL)
- *   isplib_graph_spmm     z = A (x) y for one of the four SpMM words; schedule by isplib_suggest_slices
- *                         (or isplib_graph_set_slices: -1 rule, 0 plain kernel, 1..4096 task list)
+ *   isplib_graph_spmm     z = A (x) y for one of the four SpMM words; schedule by the measured rules: the stream
+ *                         schedule where isplib_suggest_stream accepts the call (sum / mean), else isplib_suggest_slices
+ *                         (or isplib_graph_set_slices: -1 rules, 0 plain kernel, 1..4096 task list)
  *   isplib_graph_spmm_backward   dx = A^T dy (mean != 0: with weights val/max(deg,1), the mean forward's
  *                         backward, csrc/fusedmm.cpp:375); the CSC operands are built on first use
  *   isplib_suggest_slices the measured rule (0 = plain row-per-wave kernel)

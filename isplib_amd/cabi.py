@@ -52,7 +52,7 @@ EXPORTS = (
     "isplib_suggest_slices", "isplib_graph_create", "isplib_graph_set_slices", "isplib_graph_spmm", "isplib_graph_spmm_backward",
     "isplib_graph_destroy", "isplib_suggest_slices_whole_rows", "isplib_graph_sddmm",
     "fusedMM_csr_sweep_hip", "isplib_spmm_sweep_workspace_bytes", "isplib_spmm_sweep_resident_waves",
-    "fusedMM_csr_stream_hip", "isplib_spmm_stream_workspace_bytes", "isplib_spmm_stream_geometry", "isplib_suggest_stream", "isplib_spmm_minmax_bw_det_hip", "isplib_spmm_minmax_bw_workspace_bytes",
+    "fusedMM_csr_stream_hip", "isplib_spmm_stream_workspace_bytes", "isplib_spmm_stream_geometry", "isplib_suggest_stream", "isplib_stream_plan_build_hip", "isplib_stream_plan_set_values_hip", "isplib_stream_plan_free", "isplib_spmm_minmax_bw_det_hip", "isplib_spmm_minmax_bw_workspace_bytes",
 )
 
 _i64, _f32, _vp, _i32 = ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_int32
@@ -82,7 +82,7 @@ class StreamPlanStruct(ctypes.Structure):  # isplib_stream_plan
                 ("reserved", ctypes.c_int32), ("n_steps", ctypes.c_int64), ("n_parts", ctypes.c_int64), ("n_hub", ctypes.c_int64),
                 ("words", ctypes.c_void_p), ("vals", ctypes.c_void_p), ("wave_step_off", ctypes.c_void_p),
                 ("wave_row", ctypes.c_void_p), ("wave_part", ctypes.c_void_p),
-                ("hub_row", ctypes.c_void_p), ("hub_off", ctypes.c_void_p)]
+                ("hub_row", ctypes.c_void_p), ("hub_off", ctypes.c_void_p), ("perm", ctypes.c_void_p)]
 
 
 _sigs_set = False
@@ -173,6 +173,13 @@ def lib() -> ctypes.CDLL:
         L.isplib_spmm_minmax_bw_workspace_bytes.argtypes = [_i64, _i64, _i64]
         L.isplib_spmm_minmax_bw_det_hip.restype = ctypes.c_int
         L.isplib_spmm_minmax_bw_det_hip.argtypes = [_i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]
+        L.isplib_stream_plan_build_hip.restype = ctypes.c_int
+        L.isplib_stream_plan_build_hip.argtypes = [_i64, _i64, _i64, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                   ctypes.POINTER(StreamPlanStruct), _vp]
+        L.isplib_stream_plan_set_values_hip.restype = ctypes.c_int
+        L.isplib_stream_plan_set_values_hip.argtypes = [ctypes.POINTER(StreamPlanStruct), _vp, _vp]
+        L.isplib_stream_plan_free.restype = None
+        L.isplib_stream_plan_free.argtypes = [ctypes.POINTER(StreamPlanStruct)]
         L.isplib_suggest_stream.restype = ctypes.c_int
         L.isplib_suggest_stream.argtypes = [_i64, _i64, _i64, _i64, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
         L.isplib_spmm_stream_geometry.restype = ctypes.c_int
@@ -607,6 +614,62 @@ def suggest_stream(m: int, n: int, nnz: int, k: int):
     if not lib().isplib_suggest_stream(int(m), int(n), int(nnz), int(k), ctypes.byref(st), ctypes.byref(sl), ctypes.byref(ch)):
         return None
     return st.value, sl.value, ch.value
+
+
+class _DevView:
+    """A device array the C library owns, seen through __cuda_array_interface__ (no copy; tests and debugging)."""
+
+    def __init__(self, ptr: int, count: int, typestr: str):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+class NativeStreamPlan:
+    """A stream plan built by the C library (isplib_stream_plan_build_hip) -- the torch-free host's counterpart of
+    isplib_amd.plan.build_stream_plan; same interface as plan.StreamPlan for the boundary wrappers."""
+
+    def __init__(self, rowptr, col, val, ncols: int, streams: int, slices: int, chunk: int, waves_per_gen: int = 0):
+        self._s = StreamPlanStruct()
+        self.device = col.device
+        m = rowptr.numel() - 1
+        with torch.cuda.device(col.device):
+            _check(lib().isplib_stream_plan_build_hip(m, int(ncols), col.numel(), _ptr(rowptr), _ptr(col), _ptr(val), int(streams),
+                                                      int(slices), int(chunk), int(waves_per_gen), ctypes.byref(self._s),
+                                                      _stream(col.device)), "isplib_stream_plan_build_hip")
+        for name in ("rows", "cols", "slices", "gens", "waves_per_gen", "rows_per_wave", "streams", "n_steps", "n_parts", "n_hub"):
+            setattr(self, name, int(getattr(self._s, name)))
+
+    def struct(self):
+        return self._s
+
+    def workspace(self):
+        nbytes = lib().isplib_spmm_stream_workspace_bytes(ctypes.byref(self._s))
+        return torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+
+    def set_values(self, val):
+        with torch.cuda.device(self.device):
+            _check(lib().isplib_stream_plan_set_values_hip(ctypes.byref(self._s), _ptr(val), _stream(self.device)), "isplib_stream_plan_set_values_hip")
+
+    def array(self, name: str) -> torch.Tensor:
+        """A copy of one of the plan's device arrays as a tensor."""
+        nw = self.gens * self.waves_per_gen
+        count, typestr = {"words": (self.n_steps * self.streams, "<i4"), "perm": (self.n_steps * self.streams, "<i4"),
+                          "vals": (self.n_steps * self.streams, "<f4"), "wave_step_off": (nw + 1, "<i8"),
+                          "wave_row": (nw * self.rows_per_wave, "<i4"), "wave_part": (nw * self.rows_per_wave, "<i4"),
+                          "hub_row": (self.n_hub, "<i4"), "hub_off": (self.n_hub + 1, "<i4")}[name]
+        ptr = getattr(self._s, name)
+        if not ptr or count == 0:
+            return torch.empty(0, device=self.device)
+        return torch.as_tensor(_DevView(ptr, count, typestr), device=self.device).clone()
+
+    def close(self):
+        if self._s.words or self._s.wave_row:
+            lib().isplib_stream_plan_free(ctypes.byref(self._s))
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
 
 
 def stream_geometry(streams: int = 4):

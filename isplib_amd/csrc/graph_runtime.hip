@@ -37,6 +37,10 @@ struct Side {                    // A, or A^T, as CSR
                                  // materialises unit weights as a ones vector) -> the kernels skip the value stream
    int32_t *col32 = nullptr;
    std::map<int, Plan> plans;
+   // stream plans (sum / mean) per (streams, slices, chunk); the weights they were last given (the plans own a copy in
+   // stream order: `val` of the side, or the mean backward's weights)
+   struct Stream { isplib_stream_plan plan; const float *vals_of = nullptr; bool has_vals = false; };
+   std::map<uint64_t, Stream> streams;
 };
 
 __global__ __launch_bounds__(256) void not_all_ones_kernel(int64_t nnz, const float *__restrict__ val, int *__restrict__ flag) {
@@ -64,6 +68,8 @@ void free_side(Side &s, bool owns_arrays) {
       (void)hipFree(kv.second.seg_off); (void)hipFree(kv.second.task_b);
    }
    s.plans.clear();
+   for (auto &kv : s.streams) isplib_stream_plan_free(&kv.second.plan);
+   s.streams.clear();
    (void)hipFree(s.col32);
    s.col32 = nullptr;
    if (owns_arrays) {
@@ -267,6 +273,37 @@ static int run_side(isplib_graph *g, Side &s, const float *val, int32_t imessage
                     float *z, int64_t ldz, int64_t *z_arg, hipStream_t st) {
    if (val && val == s.val && weights_are_unit(s, st) == 1) val = nullptr;
    const int minmax = (imessage & 0xF0000) != ISPLIB_AOP_ADD;
+   // sum / mean on graphs with work for the whole chip: the stream schedule (rows resident in LDS, the plan's own copy of
+   // the edges), unless a slice count was forced
+   int st_streams = 0, st_slices = 0, st_chunk = 0;
+   if (!minmax && g->forced_slices < 0 && (k % 4) == 0 && (ldy % 4) == 0 && (ldz % 4) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)z & 15) == 0 &&
+       ldy < (1LL << 22) && isplib_suggest_stream(s.m, s.n, s.nnz, k, &st_streams, &st_slices, &st_chunk)) {
+      const uint64_t key = ((uint64_t)st_streams << 48) | ((uint64_t)st_slices << 32) | (uint64_t)(uint32_t)st_chunk;
+      auto it = s.streams.find(key);
+      if (it == s.streams.end()) {
+         Side::Stream fresh;
+         const int rc = isplib_stream_plan_build_hip(s.m, s.n, s.nnz, s.rowptr, s.col, val, st_streams, st_slices, st_chunk, 0, &fresh.plan, st);
+         if (rc == ISPLIB_SUCCESS) {
+            fresh.vals_of = val; fresh.has_vals = val != nullptr;
+            it = s.streams.emplace(key, fresh).first;
+         } else if (rc != ISPLIB_NOT_ENOUGH_MEM) {
+            return rc;
+         }                                           // no room for the plan: the task list / plain kernel below need less
+      }
+      if (it != s.streams.end()) {
+         Side::Stream &sp = it->second;
+         if (sp.vals_of != val || sp.has_vals != (val != nullptr)) {       // other weights than last time (sum vs mean backward)
+            const int rc = isplib_stream_plan_set_values_hip(&sp.plan, val, st);
+            if (rc) return rc;
+            sp.vals_of = val; sp.has_vals = val != nullptr;
+         }
+         const size_t need = isplib_spmm_stream_workspace_bytes(&sp.plan);
+         isplib_graph::Work *w = nullptr;
+         const int rc = ensure_work(g, need, st, &w);
+         if (rc) return rc;
+         return fusedMM_csr_stream_hip(imessage, s.m, s.n, k, s.nnz, s.rowptr, s.rowptr + 1, &sp.plan, y, ldy, z, ldz, w->ptr, w->bytes, nullptr, st);
+      }
+   }
    int slices = g->forced_slices >= 0 ? g->forced_slices : isplib_suggest_slices(s.m, s.n, s.nnz, k, minmax);
    if (k < 4 || (double)s.n * (double)ldy * 4.0 > 3.5 * 1073741824.0) slices = 0;      // outside the task entry's domain
    if (g->forced_slices < 0) slices = skew_adjusted(s, slices, st);

@@ -251,6 +251,7 @@ std::tuple<Tensor, Tensor> spmm_fw(const Tensor &rowptr_, const Tensor &col_, co
       sp.wave_part = wave_part.data_ptr<int32_t>();
       sp.hub_row = sp.n_hub ? hub_row.data_ptr<int32_t>() : nullptr;
       sp.hub_off = hub_off.data_ptr<int32_t>();
+      sp.perm = nullptr;
       const size_t ws = isplib_spmm_stream_workspace_bytes(&sp);
       Tensor work = at::empty({(int64_t)ws}, mat.options().dtype(at::kByte));
       const int st = fusedMM_csr_stream_hip(msg, M, N, K, nnz, rp, rp + 1, &sp, mat.data_ptr<float>(), K, out.data_ptr<float>(), K,

@@ -341,3 +341,24 @@ def test_fullsize_weighted_nonsymmetric_backward(gpu, reddit, oracle_mod):
     ref = oracle_mod.sddmm(rp, cl, xx, gg, mean=True)
     bound = 1e-5 * oracle_mod.sddmm(rp, cl, np.abs(xx), np.abs(gg), mean=True) + 1e-30
     assert np.all(np.abs(dval_mean.cpu().numpy() - ref) <= bound)
+
+
+def test_graph_handle_takes_the_stream_schedule_at_full_size(gpu, reddit, reddit_stream, oracle_mod):
+    """The torch-free host's object (isplib_graph: plans built by the native builder inside the library): sum K=128 on the
+    Reddit shape must run the stream schedule -- bit for bit the result of the torch-built plan of the same geometry --
+    and its backward (plan of A^T, here = A) likewise; mean through the same plan within the bound."""
+    from isplib_amd import cabi, synth
+    rowptr, col, n, _ = reddit
+    x = synth.features(n, 128, device=gpu)
+    want = cabi.spmm_stream(rowptr, col.numel(), reddit_stream, x, "sum")
+    h = cabi.GraphHandle(rowptr, col, None, n)
+    try:
+        got, _ = h.spmm(x, "sum")
+        assert torch.equal(got, want), "the handle did not run the stream schedule with the library's plan"
+        dx = h.spmm_backward(x, mean=False)                 # A is symmetric: A^T x == A x, and the same plan geometry
+        assert torch.equal(dx, want)
+        mean, _ = h.spmm(x, "mean")
+        deg = (rowptr[1:] - rowptr[:-1]).clamp(min=1).to(torch.float32).unsqueeze(1)
+        assert torch.equal(mean, want / deg)
+    finally:
+        h.close()

@@ -250,3 +250,36 @@ def test_stream_status_codes(gpu):
     x41 = torch.zeros((41, 8), device=gpu)
     assert cabi.fusedMM_csr_stream_hip(cabi.MSG_SPMM_SUM, d_rowptr, col.size, plan, x41, z, check=False) == 1       # other n than the plan's
     assert cabi.fusedMM_csr_stream_hip(cabi.MSG_SPMM_SUM, d_rowptr, col.size, plan, x, z, check=False) == 0
+
+
+@pytest.mark.parametrize("geom", ((4, 8, 64, 16), (8, 5, 2048, 7), (2, 16, 100, 9), (4, 3, 300, 3)))
+def test_native_stream_plan_equals_the_torch_built_one(gpu, oracle_mod, geom):
+    """isplib_stream_plan_build_hip (the torch-free host's builder: rocPRIM sorts + HIP kernels) against
+    isplib_amd/plan.py's construction, which the CPU tests replay edge by edge: every array identical, and the native
+    plan drives the kernel to the oracle's answer (weights re-gathered through its own permutation)."""
+    from isplib_amd import cabi
+    from isplib_amd.plan import build_stream_plan
+    streams, slices, chunk, wpg = geom
+    rowptr, col = cases.random_csr(700, 500, 40.0, seed=31, empty_rows=(0, 350, 699), hub=(11, 4000))
+    val = cases.weights(col.size, 4)
+    x = cases.dense(500, 64, 3)
+    d_rowptr, d_col, d_val, d_x = _t(rowptr, gpu), _t(col, gpu), _t(val, gpu), _t(x, gpu)
+    ref_plan = build_stream_plan(d_rowptr, d_col, d_val, 500, slices, wpg, None, streams, chunk)
+    nat = cabi.NativeStreamPlan(d_rowptr, d_col, d_val, 500, streams, slices, chunk, wpg)
+    try:
+        for name in ("gens", "waves_per_gen", "rows_per_wave", "streams", "n_steps", "n_parts", "n_hub", "slices"):
+            assert getattr(nat, name) == getattr(ref_plan, name), name
+        for name in ("words", "perm", "vals", "wave_step_off", "wave_row", "wave_part", "hub_row", "hub_off"):
+            want = getattr(ref_plan, name)
+            got = nat.array(name)
+            assert torch.equal(got.to(want.dtype), want), name
+        for red in ("sum", "mean"):
+            out = cabi.spmm_stream(d_rowptr, col.size, nat, d_x, red)
+            _check(oracle_mod, rowptr, col, val, x, red, out, None)
+        val2 = cases.weights(col.size, 77)
+        nat.set_values(_t(val2, gpu))
+        _check(oracle_mod, rowptr, col, val2, x, "sum", cabi.spmm_stream(d_rowptr, col.size, nat, d_x, "sum"), None)
+        nat.set_values(None)
+        _check(oracle_mod, rowptr, col, np.ones_like(val), x, "sum", cabi.spmm_stream(d_rowptr, col.size, nat, d_x, "sum"), None)
+    finally:
+        nat.close()
