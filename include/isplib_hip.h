@@ -344,7 +344,8 @@ int    fusedMM_csr_sweep_hip(int32_t imessage, int64_t m, int64_t n, int64_t k, 
  * isplib_spmm_stream_geometry reports the rows per wave the kernel of a slot width is built for and the waves the
  * device holds at once (what waves_per_gen should be: persistent waves only stay on the same slices -- and the slices
  * in the L2 -- when they all start together).
- * Requirements as fusedMM_csr_sweep_hip, plus n < 2^24 and ldy < 2^22 (24-bit address arithmetic per edge).
+ * Requirements: k >= 4 (any k: a last vector that would reach past column k is shifted back to end there; rows need
+ * only 4-byte alignment), n < 2^24 and ldy < 2^22 (24-bit address arithmetic per edge), n*ldy*4 <= 3.5 GiB.
  */
 typedef struct isplib_stream_plan {
    int64_t rows, cols;              /* m, n of the graph the plan was built for */

@@ -276,8 +276,7 @@ static int run_side(isplib_graph *g, Side &s, const float *val, int32_t imessage
    // sum / mean on graphs with work for the whole chip: the stream schedule (rows resident in LDS, the plan's own copy of
    // the edges), unless a slice count was forced
    int st_streams = 0, st_slices = 0, st_chunk = 0;
-   if (!minmax && g->forced_slices < 0 && (k % 4) == 0 && (ldy % 4) == 0 && (ldz % 4) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)z & 15) == 0 &&
-       ldy < (1LL << 22) && isplib_suggest_stream(s.m, s.n, s.nnz, k, &st_streams, &st_slices, &st_chunk)) {
+   if (!minmax && g->forced_slices < 0 && ldy < (1LL << 22) && isplib_suggest_stream(s.m, s.n, s.nnz, k, &st_streams, &st_slices, &st_chunk)) {
       const uint64_t key = ((uint64_t)st_streams << 48) | ((uint64_t)st_slices << 32) | (uint64_t)(uint32_t)st_chunk;
       auto it = s.streams.find(key);
       if (it == s.streams.end()) {

@@ -228,15 +228,16 @@ __global__ __launch_bounds__(256, (sweep_wgs_per_cu<OP, LPR, NVMAX>())) void spm
    }
 }
 
-// rows cut into several virtual rows: fold their partial rows in chunk order (= ascending CSR position)
-template <int OP>
+// rows cut into several virtual rows: fold their partial rows in chunk order (= ascending CSR position); VEC = 1 serves
+// panels whose width is not a multiple of 4 (stream schedule at ragged k)
+template <int OP, int VEC>
 __global__ __launch_bounds__(256) void sweep_hub_fold_kernel(const SweepArgs a) {
-   const int64_t kv = a.k / 4;
+   const int64_t kv = a.k / VEC;
    const int64_t total = a.n_hub * kv;
    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
       const int64_t h = i / kv;
-      const int c = (int)(i - h * kv) * 4;
+      const int c = (int)(i - h * kv) * VEC;
       float v[4];
       int bi[4];
 #pragma unroll
@@ -244,10 +245,10 @@ __global__ __launch_bounds__(256) void sweep_hub_fold_kernel(const SweepArgs a) 
       const int p1 = a.hub_off[h + 1];
       for (int p = a.hub_off[h]; p < p1; p++) {
          const size_t po = (size_t)p * (size_t)a.k + c;
-         float t[4];
-         load_vec<4>(a.part_val + po, t);
+         float t[VEC];
+         load_vec<VEC>(a.part_val + po, t);
 #pragma unroll
-         for (int q = 0; q < 4; q++) {
+         for (int q = 0; q < VEC; q++) {
             if (OP == OP_ADD) {
                v[q] += t[q];
             } else {
@@ -260,12 +261,27 @@ __global__ __launch_bounds__(256) void sweep_hub_fold_kernel(const SweepArgs a) 
       }
       const int row = a.hub_row[h];
       int64_t arg[4];
-      finish_row<OP>(a, row, c, v, bi, arg);
-      store_vec<4>(a.z + (size_t)row * (size_t)a.ldz + c, v);
+      if (VEC == 4) {
+         finish_row<OP>(a, row, c, v, bi, arg);
+         store_vec<4>(a.z + (size_t)row * (size_t)a.ldz + c, v);
+      } else {                                             // one column: the row finish reads four, so do it by hand
+         const int64_t rb = a.pntrb[row], deg = a.pntre[row] - rb;
+         if (OP == OP_ADD) {
+            if (a.mean) v[0] = v[0] / (float)(deg > 1 ? deg : 1);
+            if (a.ep_self) v[0] += a.ep_self[(size_t)row * (size_t)a.ep_ld_self + c];
+            if (a.ep_row_scale) v[0] *= a.ep_row_scale[row];
+            if (a.ep_bias) v[0] += a.ep_bias[c];
+            if (a.ep_relu) v[0] = v[0] > 0.0f ? v[0] : 0.0f;
+         } else {
+            if (deg <= 0) v[0] = 0.0f;
+            arg[0] = bi[0] == INT_MAX ? a.nnz : rb + (int64_t)bi[0];
+         }
+         a.z[(size_t)row * (size_t)a.ldz + c] = v[0];
+      }
       if (OP != OP_ADD && a.z_arg) {
          int64_t *ar = a.z_arg + (size_t)row * (size_t)a.ldz + c;
 #pragma unroll
-         for (int q = 0; q < 4; q++) ar[q] = arg[q];
+         for (int q = 0; q < VEC; q++) ar[q] = arg[q];
       }
    }
 }
@@ -305,8 +321,13 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, NVMAX, WGS>())) void s
    for (int i = lane * 4; i < WAVE_FLOATS; i += 256)
       *reinterpret_cast<float4 *>(my + i) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.y), 0, (int)a.ybytes, 0x00020000);
+   // a lane holds columns lc*4 .. lc*4+3 of the panel; when k is not a multiple of 4 the last lane's vector is shifted
+   // back to END at column k (its first `vfirst` components repeat the neighbour's columns and are never stored), so
+   // no load reaches past a row and rows need only 4-byte alignment (the GCN's K = 41 runs here instead of the task list)
    const bool cok = lc * 4 < a.k;
-   const unsigned cbyte = (unsigned)lc * 16u, poison = cok ? 0u : BUF_OOB;
+   int ccol = lc * 4, vfirst = 0;
+   if (cok && ccol + 4 > (int)a.k) { vfirst = ccol + 4 - (int)a.k; ccol = (int)a.k - 4; }
+   const unsigned cbyte = (unsigned)ccol * 4u, poison = cok ? 0u : BUF_OOB;
    float *lane_base = my + lc * 4;                        // a lane's four columns of a row are contiguous
    const int64_t s0 = a.wave_step_off[w], s1 = a.wave_step_off[w + 1];
    const int64_t nwords = (s1 - s0) * G;
@@ -392,14 +413,14 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, NVMAX, WGS>())) void s
       const float4 t4 = *reinterpret_cast<const float4 *>(lane_base + lrow * PANEL);
       float v[4] = {t4.x, t4.y, t4.z, t4.w};
       int bi[4] = {INT_MAX, INT_MAX, INT_MAX, INT_MAX};
-      const int c = lc * 4;
+      const int c = ccol;
       if (part >= 0) {
-         store_vec<4>(a.part_val + (size_t)part * (size_t)a.k + c, v);
+         store_tail<4>(a.part_val + (size_t)part * (size_t)a.k + c, v, vfirst);
          continue;
       }
       int64_t arg[4];
       finish_row<OP_ADD>(a, row, c, v, bi, arg);
-      store_vec<4>(a.z + (size_t)row * (size_t)a.ldz + c, v);
+      store_tail<4>(a.z + (size_t)row * (size_t)a.ldz + c, v, vfirst);
    }
 }
 
@@ -570,9 +591,9 @@ extern "C" int fusedMM_csr_sweep_hip(int32_t imessage, int64_t m, int64_t n, int
       if (plan->n_hub > 0) {
          int64_t blocks = (plan->n_hub * (p.k / 4) + 255) / 256;
          if (blocks > 4096) blocks = 4096;
-         if (aop == ISPLIB_AOP_ADD) hipLaunchKernelGGL((sweep_hub_fold_kernel<OP_ADD>), dim3((unsigned)blocks), dim3(256), 0, st, p);
-         else if (aop == ISPLIB_AOP_MAX) hipLaunchKernelGGL((sweep_hub_fold_kernel<OP_MAX>), dim3((unsigned)blocks), dim3(256), 0, st, p);
-         else hipLaunchKernelGGL((sweep_hub_fold_kernel<OP_MIN>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+         if (aop == ISPLIB_AOP_ADD) hipLaunchKernelGGL((sweep_hub_fold_kernel<OP_ADD, 4>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+         else if (aop == ISPLIB_AOP_MAX) hipLaunchKernelGGL((sweep_hub_fold_kernel<OP_MAX, 4>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+         else hipLaunchKernelGGL((sweep_hub_fold_kernel<OP_MIN, 4>), dim3((unsigned)blocks), dim3(256), 0, st, p);
          const int rc = check_launch("sweep_hub_fold_kernel");
          if (rc) return rc;
       }
@@ -596,15 +617,17 @@ extern "C" int isplib_spmm_stream_geometry(int streams, int *rows_per_wave, int 
 
 extern "C" int isplib_suggest_stream(int64_t m, int64_t n, int64_t nnz, int64_t k, int *streams, int *slices, int *chunk) {
    // When does the stream schedule pay, and with which plan?  Measured on MI355X:
-   //   * slots of 16 lanes (64-column panels) from k = 33, of 8 lanes (32-column panels) below;
+   //   * slots of 8 lanes (32-column panels) up to k = 32, of 16 lanes (64-column panels) up to 64 and from 128 on, of
+   //     32 lanes (one 128-column pass) in between -- 64 + 36 columns in two passes cost K=100 3.23 ms, one pass 2.63
+   //     (task list 3.17); K=72: 2.92 / 2.30 (2.42); K=96: 2.51 / 2.30 (2.56); K=160 wants 64 + 64 + 32: 3.85 / 4.97 (4.15);
    //   * a column slice of ~1.9 MB of the panel (Reddit shape: 32 slices at 64 columns, 16 at 32);
    //   * every generation of waves sweeps the whole dense operand once per XCD, so the rows a generation holds must
    //     reuse each row of it often: edges per generation and XCD >= 8 x rows of y (Reddit shape: 31; the
    //     ogbn-products shape, mean degree 50 over 2.4 M rows: 0.3 -- such graphs stay on the plain kernel);
    //   * rows longer than ~0.3 of a stream's share of the edges are dealt to several virtual rows (chunk).
    clear_error();
-   if (m <= 0 || n <= 0 || nnz <= 0 || k < 4 || (k % 4) != 0 || n >= (1LL << 24) || nnz < (1LL << 22)) return 0;
-   const int st = k <= 32 ? 8 : 4;
+   if (m <= 0 || n <= 0 || nnz <= 0 || k < 4 || n >= (1LL << 24) || nnz < (1LL << 22)) return 0;
+   const int st = k <= 32 ? 8 : (k <= 64 ? 4 : (k < 128 ? 2 : 4));
    int rpw = 0, resident = 0;
    if (isplib_spmm_stream_geometry(st, &rpw, &resident) != ISPLIB_SUCCESS || rpw <= 0 || resident <= 0) return 0;
    const int64_t per_gen = (int64_t)rpw * resident;
@@ -643,8 +666,7 @@ extern "C" int fusedMM_csr_stream_hip(int32_t imessage, int64_t m, int64_t n, in
       return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: bad plan geometry (streams 2, 4 or 8)");
    if (plan->gens < 1 || plan->waves_per_gen < 1 || plan->rows_per_wave != stream_geom(plan->streams).nvmax)
       return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: bad plan geometry (rows_per_wave must be what isplib_spmm_stream_geometry reports)");
-   if ((k % 4) != 0 || (ldy % 4) != 0 || (ldz % 4) != 0 || ((uintptr_t)y & 15) != 0 || ((uintptr_t)z & 15) != 0)
-      return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: k, ldy, ldz must be multiples of 4 and y, z 16-byte aligned (use fusedMM_csr_tasks_hip)");
+   if (k < 4) return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: k >= 4 required (use fusedMM_csr_hip)");
    if (ldy < k || ldz < k) return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: leading dimension smaller than k");
    const unsigned long long yb = (unsigned long long)n * (unsigned long long)ldy * 4ull;
    if (yb > BUF_LIMIT) return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: dense operand larger than 3.5 GiB (use fusedMM_csr_hip)");
@@ -673,6 +695,10 @@ extern "C" int fusedMM_csr_stream_hip(int32_t imessage, int64_t m, int64_t n, in
    for (int64_t c0 = 0; c0 < k; c0 += pw) {
       SweepArgs p = a;
       p.k = (k - c0) < pw ? (k - c0) : pw;
+      if (p.k < 4) {                              // a sliver of 1-3 columns: widen it backwards (the overlap is rewritten identically)
+         p.k = 4;
+         c0 = k - 4;
+      }
       p.y = y + c0;
       p.z = z + c0;
       p.ep_self = a.ep_self ? a.ep_self + c0 : nullptr;
@@ -688,9 +714,11 @@ extern "C" int fusedMM_csr_stream_hip(int32_t imessage, int64_t m, int64_t n, in
          if (rc) return rc;
       }
       if (plan->n_hub > 0) {
-         int64_t blocks = (plan->n_hub * (p.k / 4) + 255) / 256;
+         const bool v4 = (p.k % 4) == 0 && (p.ldz % 4) == 0 && ((uintptr_t)p.z & 15) == 0 && (!p.ep_self || ((p.ep_ld_self % 4) == 0 && ((uintptr_t)p.ep_self & 15) == 0));
+         int64_t blocks = (plan->n_hub * (v4 ? p.k / 4 : p.k) + 255) / 256;
          if (blocks > 4096) blocks = 4096;
-         hipLaunchKernelGGL((sweep_hub_fold_kernel<OP_ADD>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+         if (v4) hipLaunchKernelGGL((sweep_hub_fold_kernel<OP_ADD, 4>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+         else hipLaunchKernelGGL((sweep_hub_fold_kernel<OP_ADD, 1>), dim3((unsigned)blocks), dim3(256), 0, st, p);
          const int rc = check_launch("sweep_hub_fold_kernel");
          if (rc) return rc;
       }

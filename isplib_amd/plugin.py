@@ -182,7 +182,7 @@ def choose_stream(storage: SparseStorage, m: int, n: int, k: int):
     ISPLIB_STREAM=0 disables it, ISPLIB_SLICES (the task list's override) disables it too: explicit schedules win."""
     if os.environ.get("ISPLIB_STREAM", "1") == "0" or os.environ.get("ISPLIB_SLICES") is not None:
         return None
-    if k < 4 or k % 4 != 0 or n >= (1 << 24):
+    if k < 4 or n >= (1 << 24):
         return None
     forced = os.environ.get("ISPLIB_STREAM_GEOM")          # "streams:slices:chunk": tests and experiments
     if forced:

@@ -155,7 +155,7 @@ def _stream_all(gpu, oracle, rowptr, col, val, x, unit=False, geoms=((8, 16, 4, 
             _check(oracle, rowptr, col, val, x, red, out, None)
 
 
-@pytest.mark.parametrize("k", (4, 16, 32, 64, 100, 128, 256, 600))
+@pytest.mark.parametrize("k", (4, 5, 16, 32, 41, 64, 67, 100, 101, 128, 256, 602))
 def test_stream_widths_weighted(gpu, oracle_mod, k):
     rowptr, col = cases.random_csr(300, 257, 9.0, seed=10 + k, empty_rows=(0, 150, 299))
     val = cases.weights(col.size, 4)
@@ -192,7 +192,7 @@ def test_stream_special_values(gpu, oracle_mod, kind):
             assert np.array_equal(out, ref)
 
 
-@pytest.mark.parametrize("k", (32, 128))
+@pytest.mark.parametrize("k", (32, 41, 128, 130))
 def test_stream_hub_row_is_cut_into_virtual_rows(gpu, oracle_mod, k):
     rowptr, col = cases.random_csr(64, 400, 6.0, seed=9, empty_rows=(0, 63), hub=(17, 12345), duplicates=True)
     val = cases.weights(col.size, 4, "signed_int")
@@ -245,8 +245,8 @@ def test_stream_status_codes(gpu):
     plan = build_stream_plan(d_rowptr, d_col, None, 40, 2, 4, None, 4)
     x, z = torch.zeros((40, 8), device=gpu), torch.zeros((40, 8), device=gpu)
     assert cabi.fusedMM_csr_stream_hip(cabi.MSG_SPMM_MAX, d_rowptr, col.size, plan, x, z, check=False) == 128      # sum / mean only
-    x6, z6 = torch.zeros((40, 6), device=gpu), torch.zeros((40, 6), device=gpu)
-    assert cabi.fusedMM_csr_stream_hip(cabi.MSG_SPMM_SUM, d_rowptr, col.size, plan, x6, z6, check=False) == 1       # k % 4
+    x3, z3 = torch.zeros((40, 3), device=gpu), torch.zeros((40, 3), device=gpu)
+    assert cabi.fusedMM_csr_stream_hip(cabi.MSG_SPMM_SUM, d_rowptr, col.size, plan, x3, z3, check=False) == 1       # k < 4
     x41 = torch.zeros((41, 8), device=gpu)
     assert cabi.fusedMM_csr_stream_hip(cabi.MSG_SPMM_SUM, d_rowptr, col.size, plan, x41, z, check=False) == 1       # other n than the plan's
     assert cabi.fusedMM_csr_stream_hip(cabi.MSG_SPMM_SUM, d_rowptr, col.size, plan, x, z, check=False) == 0
