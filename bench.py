@@ -408,6 +408,18 @@ def main():
                 a.slices = whole
                 tplan = build_task_plan(l_rowptr, l_col, x_in.size(0), a.slices, a.chunk, a.short)
         twork = tplan.workspace(a.reduce, k)
+    if world > 1:
+        # Which schedules exist is decided from this rank's shard (its row count, its degree skew); a schedule that one
+        # rank has and another lacks would leave the ranks in different collectives below.  Keep what EVERY rank has.
+        have = torch.tensor([plan is not None, splan is not None, tplan is not None], dtype=torch.int32, device=dev)
+        dist.all_reduce(have, op=dist.ReduceOp.MIN)
+        have = have.tolist()
+        if not have[0]:
+            plan = None
+        if not have[1]:
+            splan = swork = None
+        if not have[2]:
+            tplan = twork = None
     use_tasks = tplan is not None and not multi      # N > 1: decided by a short measurement below
 
     def spmm(rp, cl, vl, tb, xin, o, ar, tp=None, sp=None):
@@ -429,6 +441,7 @@ def main():
     #   pipelined xC     : X travels in C column panels; panel c is aggregated while panels c+1.. travel
     #   direct xB        : P-1 per-peer send / receive pairs in B groups, a group's shards aggregated as it lands
     #   gather+stream    : one all-gather, then the stream schedule
+    #   pipelined stream xC : the pipelined exchange with the stream schedule on every panel
     # Every candidate is first checked against gather+spmm of the same kernel family (bit for bit, except that
     # panelled sums are held to the parity tests' 1e-5 bound: their summation order differs), then all
     # are timed for a few steps (max over ranks) and the fastest is kept: which one wins depends on how
@@ -491,7 +504,8 @@ def main():
                 fn = lambda: part.spmm_overlapped(x_shard, x_in, out, plan, a.reduce, arg)  # noqa: E731
                 if checked("overlapped sliced", fn, gather_then_sliced):
                     candidates["overlapped sliced"] = fn
-            if plan is not None and world > 1:
+            # (over gloo a point-to-point transfer of a shard takes seconds: the rehearsal leaves these to tests/test_gpu_dist.py)
+            if plan is not None and world > 1 and (backend == "nccl" or os.environ.get("ISPLIB_BENCH_DIRECT") == "1"):
                 for nb in sorted({1, 2, world - 1}):
                     if nb > world - 1:
                         continue
@@ -503,28 +517,43 @@ def main():
                     if k // panels < 16:
                         continue
                     state = part.pipeline_state(k, panels, a.reduce)        # own plan: slice count for the panel width
-                    if state is None:
+                    if not all_ranks_agree(state is not None):              # (a collective: every rank asks, whatever it got)
                         continue
                     fn = (lambda st: lambda: part.spmm_pipelined(x_shard, out, st, a.reduce, arg))(state)
                     if checked(f"pipelined x{panels}", fn, gather_then_tasks, exact=a.reduce in ("max", "min")):
                         candidates[f"pipelined x{panels}"] = fn
 
+            if splan is not None and "gather+stream" in candidates:
+                for panels in (2, 4):
+                    if k // panels < 32:
+                        continue
+                    state = part.pipeline_state(k, panels, a.reduce, stream=True)
+                    if not all_ranks_agree(state is not None):
+                        continue
+                    fn = (lambda st: lambda: part.spmm_pipelined(x_shard, out, st, a.reduce, arg))(state)
+                    if checked(f"pipelined stream x{panels}", fn, gather_then_stream, exact=False):
+                        candidates[f"pipelined stream x{panels}"] = fn
+
         def timed(fn, reps=4):
-            fn()
-            torch.cuda.synchronize()
-            dist.barrier()
-            t_ = time.perf_counter()
-            for _ in range(reps):
-                fn()
-            torch.cuda.synchronize()
-            tt = torch.tensor([time.perf_counter() - t_], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            return float(tt) / reps * 1e3
+            def clocked(count):
+                torch.cuda.synchronize()
+                dist.barrier()
+                t_ = time.perf_counter()
+                for _ in range(count):
+                    fn()
+                torch.cuda.synchronize()
+                tt = torch.tensor([time.perf_counter() - t_], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                return float(tt) / count * 1e3
+            first = clocked(1)                # (also the warm-up; the same value on every rank, so is the branch below)
+            return first if first > 250.0 else clocked(reps)      # a schedule this slow is not worth four more steps
 
         times = {name: timed(fn) for name, fn in candidates.items()}
         chosen = min(times, key=times.get)
         use_tasks = tplan is not None and chosen != "overlapped sliced"
         use_stream = chosen == "gather+stream"
+        if chosen.startswith("pipelined stream"):
+            use_tasks = False
         if chosen.startswith("direct"):
             use_tasks = False
         if chosen not in ("gather+spmm", "gather+stream"):
@@ -641,7 +670,9 @@ def main():
                 traffic = rec.get("fabric_bytes_per_launch", rec.get("hbm_bytes_per_launch")) if rec else None
             except Exception:
                 traffic = None
-        if use_stream:
+        if chosen.startswith("pipelined stream"):
+            kernel_label = f"spmm_stream_kernel + sweep_hub_fold_kernel per column panel ({chosen}), exchange included in the events"
+        elif use_stream:
             pw = 256 // splan.streams
             kernel_label = (f"spmm_stream_kernel x {splan.gens} generation(s) + sweep_hub_fold_kernel, "
                             f"{-(-k // pw)} pass(es) of {pw} columns per launch")
@@ -666,6 +697,7 @@ def main():
                 "schedule": (f"stream: {splan.streams} streams x {splan.rows_per_wave // splan.streams} rows per wave, {splan.slices} column slices, "
                              f"{splan.gens} generation(s) of {splan.waves_per_gen} waves, rows > {splan.chunk} edges dealt to {splan.n_parts} virtual rows"
                              if use_stream else
+                             f"stream schedule per column panel ({chosen})" if chosen.startswith("pipelined stream") else
                              f"task list: {a.slices} column slices, {tplan.n_tasks} tasks of <= {a.chunk} edges, rows < {a.short} unsliced"
                              if use_tasks else
                              f"{sliced_slices} column slices, XCD-affine" if a.slices > 0 else "row-per-wave, unsliced"),

@@ -212,14 +212,33 @@ class RowPartition:
             self._col32 = cabi.pack_indices(self.col_padded)
         return build_task_plan(self.rowptr, self.col_padded, self.ncols_padded, slices, chunk, short_row, col32=self._col32)
 
-    def pipeline_state(self, k: int, panels: int, reduce: str = "sum", tplan=None):
+    def pipeline_state(self, k: int, panels: int, reduce: str = "sum", tplan=None, stream: bool = False):
         """Operands of `spmm_pipelined` for width k: panel bounds (multiples of 4 columns), one send and one
         gather buffer per panel, a task plan whose slice count suits the PANEL width (built here unless given;
-        None -> no plan possible) and the task workspace of the widest panel."""
+        None -> no plan possible) and the task workspace of the widest panel.  stream=True / a (streams, slices,
+        chunk) triple (sum / mean): a stream plan
+        for the panel width instead (isplib_suggest_stream decides; None when it declines) -- the stream kernel works
+        in column panels anyway, so cutting K = 128 into two 64-column collectives costs it nothing."""
         from .plugin import suggest_slices
         dev = self.col.device
         w = ((k + panels - 1) // panels + 3) // 4 * 4
-        if tplan is None:
+        if stream:
+            from . import cabi
+            from .plan import build_stream_plan
+            if reduce not in ("sum", "mean"):
+                return None
+            # stream may also be the plan parameters themselves, (streams, slices, chunk): tests, experiments
+            geom = tuple(stream) if isinstance(stream, (tuple, list)) else cabi.suggest_stream(self.rows, self.ncols_padded, self.nnz, w)
+            if geom is None:
+                return None
+            plans = self.__dict__.setdefault("_stream_plans", {})
+            if geom not in plans:
+                plans[geom] = build_stream_plan(self.rowptr, self.col_padded, self.val, self.ncols_padded, geom[1], None, None,
+                                                geom[0], geom[2])
+            tplan = plans[geom]
+            if tplan is None:
+                return None
+        elif tplan is None:
             s = max(1, suggest_slices(self.rows, self.ncols_padded, self.nnz, w, reduce in ("max", "min")))
             plans = self.__dict__.setdefault("_task_plans", {})
             if s not in plans:
@@ -233,7 +252,8 @@ class RowPartition:
             bounds[-1] = (bounds[-1][0], last[1])
         send = [torch.zeros((self.max_rows, c1 - c0), dtype=torch.float32, device=dev) for c0, c1 in bounds]
         recv = [torch.empty((self.ncols_padded, c1 - c0), dtype=torch.float32, device=dev) for c0, c1 in bounds]
-        return bounds, send, recv, tplan, tplan.workspace(reduce, max(c1 - c0 for c0, c1 in bounds))
+        work = tplan.workspace() if stream else tplan.workspace(reduce, max(c1 - c0 for c0, c1 in bounds))
+        return bounds, send, recv, tplan, work
 
     def spmm_pipelined(self, x_shard: torch.Tensor, out: torch.Tensor, state, reduce: str = "sum",
                        arg: Optional[torch.Tensor] = None):
@@ -257,8 +277,11 @@ class RowPartition:
         for (c0, c1), r_buf, handle in zip(bounds, recv, handles):
             if handle is not None:
                 handle.wait()
-            cabi.fusedMM_csr_tasks_hip(msg, self.rowptr, self.col_padded, self.val, tplan, r_buf, out[:, c0:c1],
-                                       None if arg is None else arg[:, c0:c1], work)
+            if hasattr(tplan, "words"):                     # a stream plan (sum / mean)
+                cabi.fusedMM_csr_stream_hip(msg, self.rowptr, self.nnz, tplan, r_buf, out[:, c0:c1], work)
+            else:
+                cabi.fusedMM_csr_tasks_hip(msg, self.rowptr, self.col_padded, self.val, tplan, r_buf, out[:, c0:c1],
+                                           None if arg is None else arg[:, c0:c1], work)
         return out
 
 
@@ -295,7 +318,8 @@ class DistGraph:
 def _spmm_auto(self, x_local: torch.Tensor) -> torch.Tensor:
     """Sum-SpMM of this partition on unpadded local rows [x_rows, K]: pads into the shard pitch, then
     ISPLIB_DIST_SCHEDULE = tasks (default: one all-gather, task-list SpMM) | overlap (local column slices
-    during the all-gather) | pipelined (two column panels, panel 2 travels while panel 1 is aggregated) | direct
+    during the all-gather) | pipelined (two column panels, panel 2 travels while panel 1 is aggregated; on the stream
+    schedule where isplib_suggest_stream accepts the panel, else on the task list) | direct
     (per-peer send / receive in ISPLIB_DIRECT_BATCHES groups, shards aggregated as they land).
     Whatever the schedule, a graph for which the slice rule says 0 runs gather + the plain kernel."""
     import os
@@ -313,13 +337,22 @@ def _spmm_auto(self, x_local: torch.Tensor) -> torch.Tensor:
         if s > 0 and mode in ("overlap", "direct"):
             forced = os.environ.get("ISPLIB_SLICES")        # one-pass sliced kernel: its own (whole-row) slice rule
             ops = self.plan(k, "sum", slices=int(forced) if forced else None)
-        elif s > 0 and mode == "pipelined" and k >= 32:
-            ops = self.pipeline_state(k, 2, "sum")
+        elif mode == "pipelined" and k >= 32:
+            ops = self.pipeline_state(k, 2, "sum", stream=True)
+            if ops is None and s > 0:
+                ops = self.pipeline_state(k, 2, "sum")
         elif s > 0:
             plans = self.__dict__.setdefault("_task_plans", {})
             if s not in plans:
                 plans[s] = self.task_plan(s)
             ops = None if plans[s] is None else (plans[s], plans[s].workspace("sum", k))
+        if self.world > 1 and mode in ("pipelined", "direct"):
+            # these two exchange X with other collectives than the one all-gather of the fallback: every rank must take
+            # the same branch, and whether a plan exists is decided from the rank's own shard
+            ok = torch.tensor([0 if ops is None else 1], dtype=torch.int32, device=x_local.device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+            if not int(ok):
+                ops = None
         cache[key] = (ops, self.gather_buffer(k, x_local.device),
                       torch.zeros((self.max_rows, k), dtype=torch.float32, device=x_local.device))
     ops, buf, shard = cache[key]

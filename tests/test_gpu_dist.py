@@ -81,6 +81,24 @@ for kk in (32, 41):
         ref, _ = oracle.spmm_fw(rowptr, col, val, xk, red)
         if red == "max":
             assert np.array_equal(want.cpu().numpy(), ref[part.row0:part.row0 + part.rows])
+# the same pipelined exchange with the stream schedule on every panel (sum / mean; the rule would decline a graph this
+# small, so the plan parameters are given): panels narrower and wider than a slot, ragged widths, weights in the plan
+for kk, geom in ((64, (4, 3, 200)), (41, (8, 2, 64)), (130, (2, 4, 500))):
+    xk = cases.dense(n, kk, 13)
+    shard = part.shard(t(xk))
+    for red in ("sum", "mean"):
+        state = part.pipeline_state(kk, 2, red, stream=geom)
+        assert state is not None and hasattr(state[3], "words")
+        out = torch.zeros((part.rows, kk), device=dev)
+        part.spmm_pipelined(shard, out, state, red)
+        first = out.clone()
+        part.spmm_pipelined(shard, out, state, red)               # buffers are reused across steps
+        torch.cuda.synchronize()
+        assert torch.equal(first, out), (kk, red)
+        ref, _ = oracle.spmm_fw(rowptr, col, val, xk, red)
+        mag, _ = oracle.spmm_fw(rowptr, col, np.abs(val), np.abs(xk), "sum")
+        sl = slice(part.row0, part.row0 + part.rows)
+        assert np.all(np.abs(out.cpu().numpy() - ref[sl]) <= 1e-5 * mag[sl] + 1e-30), (kk, red)
 # direct per-peer exchange (P-1 send / receive pairs in 1, 2 or P-1 groups, shards aggregated as they land): bitwise
 # the column-sliced SpMM over the all-gathered buffer, every reduction, arg included
 plan = part.plan(32, "sum", slices=2 * world)
