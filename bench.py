@@ -243,6 +243,105 @@ def extra_configs(dev, rowptr, col, n, with_cpu_epoch=True):
     return out
 
 
+def dist_extra_configs(dev, rank, world, rowptr, col, n):
+    """The two configurations of BASELINE.json that exist only on several GPUs, run on the ranks of this job after the
+    headline (outside its timed region): config 5 -- the 2-layer GCN epoch on the 1-D row-partitioned graph
+    (isplib_amd.dist.DistGraph: one all-gather of the layer input per aggregation, forward and backward; replicated
+    dense weights, gradients all-reduced) -- and config 4 -- the ogbn-products-shaped SpMM-sum at K=256, one
+    all-gather(X) + the local SpMM per step.  Wall clock between device synchronisations, max over ranks."""
+    import importlib.util
+    import torch.distributed as dist
+    import torch.nn.functional as F
+    from isplib_amd import cabi, synth
+    from isplib_amd.dist import DistGraph, RowPartition
+    out = []
+
+    def over_ranks(seconds):
+        t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t)
+
+    # config 5
+    spec = importlib.util.spec_from_file_location("gcn_epoch", os.path.join(ROOT, "scripts", "gcn_epoch.py"))
+    ge = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ge)
+    torch.manual_seed(0)                                     # the same replicated weights and labels on every rank
+    feats, hidden, classes = 602, 32, 41
+    x = synth.features(n, feats, device=dev)
+    y = torch.randint(0, classes, (n,), device=dev)
+    mask = torch.rand(n, device=dev) < 0.66
+    n_train = int(mask.sum())
+    model = ge.Net(feats, hidden, classes).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01, weight_decay=5e-4)
+    graph = DistGraph(rowptr, col, None, n, rank, world)
+    r0, r1 = graph.row0, graph.row0 + graph.rows
+    x, y, mask = x[r0:r1].contiguous(), y[r0:r1].contiguous(), mask[r0:r1].contiguous()
+    agg = lambda g_, m_, red_: g_.matmul(m_)  # noqa: E731
+    times = []
+    for epoch in range(6):                                   # epoch 0 builds the per-graph operands; not timed
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        model.train()
+        opt.zero_grad()
+        o = model(x, graph, agg)
+        loss = F.nll_loss(o[mask], y[mask], reduction="sum") / n_train
+        loss.backward()
+        for prm in model.parameters():                       # replicated dense weights: sum the shard gradients
+            dist.all_reduce(prm.grad)
+        opt.step()
+        model(x, graph, agg).argmax(1)                       # the second forward of tests/cpu/gcn-sparse.py:89
+        torch.cuda.synchronize()
+        if epoch:
+            times.append(time.perf_counter() - t0)
+    out.append({"config": f"config 5 on {world} GPUs: 2-layer GCN 602-32-41 epoch on the reddit-like graph, rows of A, A^T and X "
+                          "partitioned by nnz (6 aggregations = 6 all-gathers + local SpMM, dense layers on the local rows, "
+                          "weight gradients all-reduced, Adam)",
+                "ms": over_ranks(statistics.mean(times)) * 1e3, "epochs_timed": len(times), "n_gpus": world})
+    del x, y, mask, model, opt, graph
+    torch.cuda.empty_cache()
+
+    # config 4
+    k = 256
+    p_rowptr, p_col, pn = synth.dataset_like("products", device=dev)
+    dist.broadcast(p_rowptr, 0)                              # same seed, same generator: rank 0's copy is authoritative anyway
+    dist.broadcast(p_col, 0)
+    e = p_col.numel()
+    part = RowPartition(p_rowptr, p_col, None, pn, rank, world)
+    del p_rowptr, p_col
+    shard = part.shard(synth.features(pn, k, device=dev))
+    torch.cuda.empty_cache()
+    buf = part.gather_buffer(k)
+    z = torch.empty((part.rows, k), dtype=torch.float32, device=dev)
+
+    def step():
+        part.all_gather(shard, buf)
+        cabi.fusedMM_csr_hip(cabi.MSG_SPMM_SUM, part.rowptr, part.col_padded, None, buf, z)
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    ms = over_ranks(time.perf_counter() - t0) / 5 * 1e3
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    part.all_gather(shard, buf)
+    ev0.record()
+    cabi.fusedMM_csr_hip(cabi.MSG_SPMM_SUM, part.rowptr, part.col_padded, None, buf, z)
+    ev1.record()
+    torch.cuda.synchronize()
+    b_alg = synth.algorithmic_bytes(pn, pn, e, k, False)
+    out.append({"config": f"config 4 on {world} GPUs: products-like SpMM-sum K=256 (N={pn}, nnz={e}), rows by nnz, one all-gather(X) "
+                          f"({pn * k * 4 / 1e9:.2f} GB gathered per rank) + the plain row-per-wave kernel per step",
+                "ms": ms, "edges_per_s": e / (ms * 1e-3), "local_spmm_ms_rank0": ev0.elapsed_time(ev1), "n_gpus": world,
+                "roofline": {"bound": "hbm", "achieved": b_alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS * world, "unit": "GB/s",
+                             "frac": b_alg / (ms * 1e-3) / 1e9 / (HBM_PEAK_GBPS * world), "algorithmic_bytes_per_launch": b_alg}})
+    return out
+
+
 def launcher_command(gpus: int, argv, port: int):
     """The command `python bench.py --gpus N ...` turns into when no launcher set WORLD_SIZE: one fresh process per
     GPU under torch.distributed.run, rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
@@ -653,6 +752,7 @@ def main():
         bwd = {"ms": bms, "edges_per_s": nnz / (bms * 1e-3)}
         del colptr, row_t, val_t, dy, dx
 
+    res = None
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
         with_arg = a.reduce in ("max", "min")
@@ -724,6 +824,15 @@ def main():
             del x, out
             torch.cuda.empty_cache()
             res["extra"] = extra_configs(dev, rowptr, col, n, with_cpu_epoch=not a.no_cpu_baseline)
+    if world > 1 and not a.no_extra and a.workload == "reddit" and a.scale == 1.0 and a.generator == "chunglu":
+        # every rank: the multi-GPU-only configurations, after the headline and outside its timed region
+        step_fn = candidates = splan = tplan = plan = swork = twork = table = work = None
+        del x_in, out, x_shard, part, x
+        torch.cuda.empty_cache()
+        dist_extra = dist_extra_configs(dev, rank, world, rowptr, col, n)
+        if rank == 0:
+            res["extra"] = dist_extra
+    if rank == 0:
         print(json.dumps(res), flush=True)
     if multi:
         dist.barrier()
