@@ -469,8 +469,9 @@ int    isplib_csr2csc_hip(int64_t m, int64_t n, int64_t nnz,
  * the reference's C++ layer (csrc/fusedmm.cpp:113-203) would hold per graph in place of the pointer-keyed
  * dicts of isplib/__init__.py:35-40.
  *   isplib_graph_create   borrows rowptr[m+1] / col[nnz] / val[nnz]|NULL (device; must outlive the handle and
- *                         must not change: val is examined once, and a vector of exact 1.0f -- what
- *                         isplib/__init__.py:51-57 materialises for an unweighted graph -- is treated as NULL)
+ *                         must not change without isplib_graph_set_values: val is examined once, and a vector
+ *                         of exact 1.0f -- what isplib/__init__.py:51-57 materialises for an unweighted graph -- is
+ *                         treated as NULL)
  *   isplib_graph_spmm     z = A (x) y for one of the four SpMM words; schedule by the measured rules: the stream
  *                         schedule where isplib_suggest_stream accepts the call (sum / mean), else isplib_suggest_slices
  *                         (or isplib_graph_set_slices: -1 rules, 0 plain kernel, 1..4096 task list)
@@ -486,6 +487,11 @@ int  isplib_suggest_slices(int64_t m, int64_t n, int64_t nnz, int64_t k, int min
 int  isplib_graph_create(int64_t m, int64_t n, int64_t nnz, const int64_t *rowptr, const int64_t *col,
                          const float *val, isplib_graph **out);
 int  isplib_graph_set_slices(isplib_graph *g, int slices);
+/* New weights for the same structure (val: [dev] nnz | NULL, borrowed like create's; also to be called when the
+ * CONTENTS of the array given before have changed): plans, packed column ids and the CSC structure stay; the
+ * unit-weight test, the stream plans' copies of the weights and the transposed weights of the backward are refreshed
+ * by the next call that needs them, on that call's stream.  Never synchronises, never frees. */
+int  isplib_graph_set_values(isplib_graph *g, const float *val);
 int  isplib_graph_spmm(isplib_graph *g, int32_t imessage, int64_t k, const float *y, int64_t ldy,
                        float *z, int64_t ldz, int64_t *z_arg, void *stream);
 int  isplib_graph_spmm_backward(isplib_graph *g, int mean, int64_t k, const float *dy, int64_t lddy,

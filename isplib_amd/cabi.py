@@ -49,7 +49,7 @@ EXPORTS = (
     "isplib_spmm_tasks_workspace_bytes", "fusedMM_csr_tasks_hip",
     "isplib_spmm_tasks_plan_workspace_bytes", "isplib_spmm_tasks_count_hip", "isplib_spmm_tasks_fill_hip",
     "isplib_sddmm_csr_tasks_hip", "fusedMM_csr_tasks_epilogue_hip", "fusedMM_csr_udef_hip", "fusedMM_csr_udef_tasks_hip", "isplib_pack_indices_hip",
-    "isplib_suggest_slices", "isplib_graph_create", "isplib_graph_set_slices", "isplib_graph_spmm", "isplib_graph_spmm_backward",
+    "isplib_suggest_slices", "isplib_graph_create", "isplib_graph_set_slices", "isplib_graph_set_values", "isplib_graph_spmm", "isplib_graph_spmm_backward",
     "isplib_graph_destroy", "isplib_suggest_slices_whole_rows", "isplib_graph_sddmm",
     "fusedMM_csr_sweep_hip", "isplib_spmm_sweep_workspace_bytes", "isplib_spmm_sweep_resident_waves",
     "fusedMM_csr_stream_hip", "isplib_spmm_stream_workspace_bytes", "isplib_spmm_stream_geometry", "isplib_suggest_stream", "isplib_stream_plan_build_hip", "isplib_stream_plan_set_values_hip", "isplib_stream_plan_free", "isplib_spmm_minmax_bw_det_hip", "isplib_spmm_minmax_bw_workspace_bytes",
@@ -157,6 +157,8 @@ def lib() -> ctypes.CDLL:
         L.isplib_graph_create.argtypes = [_i64, _i64, _i64, _vp, _vp, _vp, ctypes.POINTER(_vp)]
         L.isplib_graph_set_slices.restype = ctypes.c_int
         L.isplib_graph_set_slices.argtypes = [_vp, ctypes.c_int]
+        L.isplib_graph_set_values.restype = ctypes.c_int
+        L.isplib_graph_set_values.argtypes = [_vp, _vp]
         L.isplib_graph_spmm.restype = ctypes.c_int
         L.isplib_graph_spmm.argtypes = [_vp, _i32, _i64, _vp, _i64, _vp, _i64, _vp, _vp]
         L.isplib_graph_spmm_backward.restype = ctypes.c_int
@@ -699,6 +701,12 @@ class GraphHandle:
 
     def set_slices(self, slices: int) -> None:
         _check(lib().isplib_graph_set_slices(self._h, int(slices)), "isplib_graph_set_slices")
+
+    def set_values(self, val) -> None:
+        """New weights for the same structure (another array, the same one edited in place, or None = unit weights)."""
+        self.val = None if val is None else _dev(val, "val", torch.float32)
+        assert self.val is None or self.val.numel() == self.col.numel()
+        _check(lib().isplib_graph_set_values(self._h, _ptr(self.val)), "isplib_graph_set_values")
 
     def spmm(self, y: torch.Tensor, reduce: str = "sum"):
         y = _dev(y, "y", torch.float32)

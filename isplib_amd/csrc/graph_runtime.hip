@@ -39,7 +39,7 @@ struct Side {                    // A, or A^T, as CSR
    std::map<int, Plan> plans;
    // stream plans (sum / mean) per (streams, slices, chunk); the weights they were last given (the plans own a copy in
    // stream order: `val` of the side, or the mean backward's weights)
-   struct Stream { isplib_stream_plan plan; const float *vals_of = nullptr; bool has_vals = false; };
+   struct Stream { isplib_stream_plan plan; const float *vals_of = nullptr; bool has_vals = false; uint64_t gen = 0; };
    std::map<uint64_t, Stream> streams;
 };
 
@@ -84,6 +84,8 @@ struct isplib_graph {
    Side fwd, bwd;                // bwd = A^T, built on first backward call
    bool has_bwd = false;
    float *mean_val_t = nullptr;  // val[csr2csc] / max(deg(row),1): the mean backward's weights
+   uint64_t val_gen = 0;         // bumped by isplib_graph_set_values: copies of the weights older than this are stale
+   bool bwd_vals_stale = false;  // the transposed weights (bwd.val, mean_val_t) predate the last isplib_graph_set_values
    struct Work { void *ptr = nullptr; size_t bytes = 0; };
    std::map<hipStream_t, Work> works;   // one grow-only workspace per stream the handle has been used on
    int forced_slices = -1;       // -1: isplib_suggest_slices
@@ -158,6 +160,24 @@ extern "C" int isplib_graph_set_slices(isplib_graph *g, int slices) {
    if (!g) return fail(ISPLIB_FAIL, "isplib_graph_set_slices: null handle");
    if (slices < -1 || slices > ISPLIB_MAX_SLICES) return fail(ISPLIB_FAIL, "isplib_graph_set_slices: -1 (rule), 0 (plain) or 1..4096");
    g->forced_slices = slices;
+   return ISPLIB_SUCCESS;
+}
+
+extern "C" int isplib_graph_set_values(isplib_graph *g, const float *val) {
+   // New weights for the same structure (an optimiser stepped them in place, or the caller passes another tensor):
+   // everything keyed on (rowptr, col) -- task plans, stream plans' words, packed column ids, the CSC structure --
+   // stays; what is derived from the VALUES is refreshed lazily by the next call that needs it, on that call's
+   // stream: the unit-weight test, the stream plans' copies of the weights (one gather through the plan's
+   // permutation), the transposed weights of the backward (the two csr2csc passes again, into the same arrays).
+   clear_error();
+   if (!g) return fail(ISPLIB_FAIL, "isplib_graph_set_values: null handle");
+   g->fwd.val = val;
+   g->fwd.unit = -1;
+   g->val_gen++;
+   if (g->has_bwd) {
+      g->bwd.unit = -1;
+      g->bwd_vals_stale = true;
+   }
    return ISPLIB_SUCCESS;
 }
 
@@ -283,7 +303,7 @@ static int run_side(isplib_graph *g, Side &s, const float *val, int32_t imessage
          Side::Stream fresh;
          const int rc = isplib_stream_plan_build_hip(s.m, s.n, s.nnz, s.rowptr, s.col, val, st_streams, st_slices, st_chunk, 0, &fresh.plan, st);
          if (rc == ISPLIB_SUCCESS) {
-            fresh.vals_of = val; fresh.has_vals = val != nullptr;
+            fresh.vals_of = val; fresh.has_vals = val != nullptr; fresh.gen = g->val_gen;
             it = s.streams.emplace(key, fresh).first;
          } else if (rc != ISPLIB_NOT_ENOUGH_MEM) {
             return rc;
@@ -291,10 +311,11 @@ static int run_side(isplib_graph *g, Side &s, const float *val, int32_t imessage
       }
       if (it != s.streams.end()) {
          Side::Stream &sp = it->second;
-         if (sp.vals_of != val || sp.has_vals != (val != nullptr)) {       // other weights than last time (sum vs mean backward)
+         if (sp.vals_of != val || sp.has_vals != (val != nullptr) || (val && sp.gen != g->val_gen)) {
+            // other weights than last time (sum vs mean backward), or new contents (isplib_graph_set_values)
             const int rc = isplib_stream_plan_set_values_hip(&sp.plan, val, st);
             if (rc) return rc;
-            sp.vals_of = val; sp.has_vals = val != nullptr;
+            sp.vals_of = val; sp.has_vals = val != nullptr; sp.gen = g->val_gen;
          }
          const size_t need = isplib_spmm_stream_workspace_bytes(&sp.plan);
          isplib_graph::Work *w = nullptr;
@@ -357,8 +378,34 @@ extern "C" int isplib_graph_spmm(isplib_graph *g, int32_t imessage, int64_t k, c
    return run_side(g, g->fwd, g->fwd.val, imessage, k, y, ldy, z, ldz, z_arg, (hipStream_t)stream);
 }
 
+// the weights of A^T again after isplib_graph_set_values: the same two stable sorts, into the arrays the handle has
+static int refresh_transposed_values(isplib_graph *g, hipStream_t st) {
+   const Side &a = g->fwd;
+   Side &t = g->bwd;
+   const size_t e = (size_t)(a.nnz > 0 ? a.nnz : 1);
+   float *val_t = const_cast<float *>(t.val);
+   if (a.val && !val_t) {
+      TRY_ALLOC(val_t, e * sizeof(float));
+      t.val = val_t;
+   } else if (!a.val && val_t) {
+      ISPLIB_HIP_TRY(hipStreamSynchronize(st));          // an earlier backward on this stream may still read it
+      (void)hipFree(val_t);
+      t.val = val_t = nullptr;
+   }
+   const size_t ws_bytes = isplib_csr2csc_workspace_bytes(a.m, a.n, a.nnz);
+   isplib_graph::Work *w = nullptr;
+   int rc = ensure_work(g, ws_bytes, st, &w);
+   if (rc) return rc;
+   int64_t *colptr = const_cast<int64_t *>(t.rowptr), *row_t = const_cast<int64_t *>(t.col);
+   if (a.val) rc = isplib_csr2csc_hip(a.m, a.n, a.nnz, a.rowptr, a.col, a.val, 0, colptr, nullptr, row_t, val_t, w->ptr, w->bytes, st);
+   if (!rc) rc = isplib_csr2csc_hip(a.m, a.n, a.nnz, a.rowptr, a.col, a.val, 1, colptr, nullptr, row_t, g->mean_val_t, w->ptr, w->bytes, st);
+   if (rc) return rc;
+   g->bwd_vals_stale = false;
+   return ISPLIB_SUCCESS;
+}
+
 static int ensure_transpose(isplib_graph *g, hipStream_t st) {
-   if (g->has_bwd) return ISPLIB_SUCCESS;
+   if (g->has_bwd) return g->bwd_vals_stale ? refresh_transposed_values(g, st) : ISPLIB_SUCCESS;
    const Side &a = g->fwd;
    Side t;
    t.m = a.n; t.n = a.m; t.nnz = a.nnz;

@@ -112,10 +112,13 @@ static inline const int32_t *plan_col32(const Plan &p, const Tensor &col) {
 }
 // ---- per-graph handles for callers that pass no plan (the reference-schema operators) --------------------------
 // iSpLib's Python keeps its per-graph operands in dicts keyed by raw data pointers (isplib/__init__.py:35-40,50) and
-// calls the operators with just (rowptr, col, value, mat).  To give that caller the task-list schedule, the
-// operator library keeps one isplib_graph per (rowptr, col, value) triple it has seen -- keyed by the same
-// pointers, but every hit is checked against weak references to the very tensors (and their version counters),
-// so a freed-and-reused address can never serve a stale plan.  Small graphs (rule says 0 slices) never get here.
+// calls the operators with just (rowptr, col, value, mat).  To give that caller the fast schedules, the operator
+// library keeps one isplib_graph per STRUCTURE (rowptr, col, dense rows) it has seen -- keyed by the same pointers,
+// but every hit is checked against weak references to the very tensors (and their version counters), so a
+// freed-and-reused address can never serve a stale plan.  The weights are an argument of the call, not part of the
+// key: another `value` tensor, or the same one stepped in place by an optimiser (its version counter moves), keeps
+// the plans, the packed column ids and the CSC structure and only tells the handle that its copies of the weights
+// are stale (isplib_graph_set_values: no synchronisation, nothing freed).  Small graphs never get here.
 struct GraphCacheEntry {
    c10::weak_intrusive_ptr<c10::TensorImpl> rowptr, col, value;
    uint32_t v_rowptr = 0, v_col = 0, v_value = 0;
@@ -124,22 +127,27 @@ struct GraphCacheEntry {
    GraphCacheEntry(const Tensor &r, const Tensor &c, const Tensor &v)
        : rowptr(r.getIntrusivePtr()), col(c.getIntrusivePtr()), value(v.defined() ? v.getIntrusivePtr() : c.getIntrusivePtr()),
          v_rowptr(r._version()), v_col(c._version()), v_value(v.defined() ? v._version() : 0), has_value(v.defined()) {}
-   bool alive() const { return !rowptr.expired() && !col.expired() && !value.expired(); }
-   bool matches(const Tensor &r, const Tensor &c, const Tensor &v) const {
-      return rowptr.lock() == r.getIntrusivePtr() && col.lock() == c.getIntrusivePtr() && has_value == v.defined() &&
-             (!v.defined() || value.lock() == v.getIntrusivePtr()) && v_rowptr == r._version() && v_col == c._version() &&
-             (!v.defined() || v_value == v._version());
+   bool alive() const { return !rowptr.expired() && !col.expired(); }
+   bool same_structure(const Tensor &r, const Tensor &c) const {
+      return rowptr.lock() == r.getIntrusivePtr() && col.lock() == c.getIntrusivePtr() && v_rowptr == r._version() && v_col == c._version();
+   }
+   bool same_values(const Tensor &v) const {
+      return has_value == v.defined() && (!v.defined() || (value.lock() == v.getIntrusivePtr() && v_value == v._version()));
+   }
+   void remember_values(const Tensor &v, const Tensor &c) {
+      value = c10::weak_intrusive_ptr<c10::TensorImpl>(v.defined() ? v.getIntrusivePtr() : c.getIntrusivePtr());
+      v_value = v.defined() ? v._version() : 0;
+      has_value = v.defined();
    }
 };
 struct GraphKey {
-   const void *rowptr, *col, *value;
+   const void *rowptr, *col;
    int64_t n;
-   bool operator==(const GraphKey &o) const { return rowptr == o.rowptr && col == o.col && value == o.value && n == o.n; }
+   bool operator==(const GraphKey &o) const { return rowptr == o.rowptr && col == o.col && n == o.n; }
 };
 struct GraphKeyHash {
    size_t operator()(const GraphKey &k) const {
-      return std::hash<const void *>()(k.rowptr) ^ (std::hash<const void *>()(k.col) << 1) ^ (std::hash<const void *>()(k.value) << 2) ^
-             std::hash<int64_t>()(k.n);
+      return std::hash<const void *>()(k.rowptr) ^ (std::hash<const void *>()(k.col) << 1) ^ std::hash<int64_t>()(k.n);
    }
 };
 std::mutex g_graph_mutex;
@@ -157,13 +165,14 @@ void retire_handle_locked(isplib_graph *h) {
    }
 }
 
-// runs the SpMM through a cached handle; false = not applicable (caller falls through to the plain kernel)
-// the handle of (rowptr, col, value) with N dense rows; g_graph_mutex must be held
-isplib_graph *graph_handle_locked(const Tensor &rowptr, const Tensor &col, const Tensor &value, int64_t N) {
+// the handle of the structure (rowptr, col) with N dense rows; g_graph_mutex must be held.  with_values: the call is
+// going to read the weights (SpMM and its backward), so the handle must hold `value` as it is now; SDDMM does not
+// read them and takes the handle as it finds it.
+isplib_graph *graph_handle_locked(const Tensor &rowptr, const Tensor &col, const Tensor &value, int64_t N, bool with_values = true) {
    const int64_t M = rowptr.numel() - 1, nnz = col.numel();
-   const GraphKey key{rowptr.data_ptr(), col.data_ptr(), value.defined() ? value.data_ptr() : nullptr, N};
+   const GraphKey key{rowptr.data_ptr(), col.data_ptr(), N};
    auto it = g_graphs.find(key);
-   if (it != g_graphs.end() && !it->second.matches(rowptr, col, value)) {
+   if (it != g_graphs.end() && !it->second.same_structure(rowptr, col)) {
       retire_handle_locked(it->second.handle);
       g_graphs.erase(it);
       it = g_graphs.end();
@@ -177,11 +186,15 @@ isplib_graph *graph_handle_locked(const Tensor &rowptr, const Tensor &col, const
             ++dead;
          }
       }
-      GraphCacheEntry e(rowptr, col, value);
+      const Tensor first = with_values ? value : Tensor();
+      GraphCacheEntry e(rowptr, col, first);
       check_status(isplib_graph_create(M, N, nnz, rowptr.data_ptr<int64_t>(), col.data_ptr<int64_t>(),
-                                       value.defined() ? value.data_ptr<float>() : nullptr, &e.handle),
+                                       first.defined() ? first.data_ptr<float>() : nullptr, &e.handle),
                    "isplib_graph_create");
       it = g_graphs.emplace(key, std::move(e)).first;
+   } else if (with_values && !it->second.same_values(value)) {
+      check_status(isplib_graph_set_values(it->second.handle, value.defined() ? value.data_ptr<float>() : nullptr), "isplib_graph_set_values");
+      it->second.remember_values(value, col);
    }
    return it->second.handle;
 }
@@ -339,12 +352,12 @@ Tensor sddmm(const Tensor &rowptr, const Tensor &col, const Tensor &mat, const T
    const int64_t *rp = rowptr.data_ptr<int64_t>();
    // The dot product needs whole rows of y, so the SpMM's plan (sized for 64-column panels) is the wrong one here:
    // large graphs go through the graph's handle, which keeps a plan sized for whole rows (Reddit K=128: 3.7 ms with
-   // 16 slices, 4.6 ms on the SpMM's 8).  dA does not read the weights, and the weights tensor autograd hands back
-   // here is a different object from the forward's, so this handle is keyed by (rowptr, col) alone.
+   // 16 slices, 4.6 ms on the SpMM's 8).  dA does not read the weights (and the weights tensor autograd hands back
+   // here is a different object from the forward's): the structure's handle is used as it is.
    (void)value;
    if (K >= 4 && rowptr.is_contiguous() && col.is_contiguous() && isplib_suggest_slices_whole_rows(M, N, col.numel(), K) > 0) {
       std::lock_guard<std::mutex> lock(g_graph_mutex);
-      isplib_graph *handle = graph_handle_locked(rowptr, col, Tensor(), N);
+      isplib_graph *handle = graph_handle_locked(rowptr, col, Tensor(), N, /*with_values=*/false);
       const int st = isplib_graph_sddmm(handle, mean ? 1 : 0, K, y.data_ptr<float>(), K, g.data_ptr<float>(), K,
                                         dval.data_ptr<float>(), current_stream(y));
       if (st != ISPLIB_NOT_ENOUGH_MEM) {

@@ -317,7 +317,8 @@ class DistGraph:
 
 def _spmm_auto(self, x_local: torch.Tensor) -> torch.Tensor:
     """Sum-SpMM of this partition on unpadded local rows [x_rows, K]: pads into the shard pitch, then
-    ISPLIB_DIST_SCHEDULE = tasks (default: one all-gather, task-list SpMM) | overlap (local column slices
+    ISPLIB_DIST_SCHEDULE = tasks (default: one all-gather, then the stream schedule / task list / plain kernel by the
+    single-GPU rules applied to this rank's shard) | overlap (local column slices
     during the all-gather) | pipelined (two column panels, panel 2 travels while panel 1 is aggregated; on the stream
     schedule where isplib_suggest_stream accepts the panel, else on the task list) | direct
     (per-peer send / receive in ISPLIB_DIRECT_BATCHES groups, shards aggregated as they land).
@@ -341,11 +342,20 @@ def _spmm_auto(self, x_local: torch.Tensor) -> torch.Tensor:
             ops = self.pipeline_state(k, 2, "sum", stream=True)
             if ops is None and s > 0:
                 ops = self.pipeline_state(k, 2, "sum")
-        elif s > 0:
-            plans = self.__dict__.setdefault("_task_plans", {})
-            if s not in plans:
-                plans[s] = self.task_plan(s)
-            ops = None if plans[s] is None else (plans[s], plans[s].workspace("sum", k))
+        else:
+            # one all-gather, then the single-GPU rule on this rank's shard: stream schedule where isplib_suggest_stream
+            # accepts it, else the task list, else the plain kernel (the collective is the same in all three: ranks
+            # may decide differently)
+            geom = None if os.environ.get("ISPLIB_STREAM") == "0" else cabi.suggest_stream(self.rows, self.ncols_padded, self.nnz, k)
+            if geom is not None:
+                from .plan import build_stream_plan
+                sp = build_stream_plan(self.rowptr, self.col_padded, self.val, self.ncols_padded, geom[1], None, None, geom[0], geom[2])
+                ops = None if sp is None else (sp, sp.workspace())
+            if ops is None and s > 0:
+                plans = self.__dict__.setdefault("_task_plans", {})
+                if s not in plans:
+                    plans[s] = self.task_plan(s)
+                ops = None if plans[s] is None else (plans[s], plans[s].workspace("sum", k))
         if self.world > 1 and mode in ("pipelined", "direct"):
             # these two exchange X with other collectives than the one all-gather of the fallback: every rank must take
             # the same branch, and whether a plan exists is decided from the rank's own shard
@@ -365,7 +375,9 @@ def _spmm_auto(self, x_local: torch.Tensor) -> torch.Tensor:
     if ops is not None and mode == "pipelined" and k >= 32:
         return self.spmm_pipelined(shard, out, ops, "sum")
     self.all_gather(shard, buf)
-    if ops is not None:
+    if ops is not None and hasattr(ops[0], "words"):
+        cabi.fusedMM_csr_stream_hip(cabi.MSG_SPMM_SUM, self.rowptr, self.nnz, ops[0], buf, out, ops[1])
+    elif ops is not None:
         cabi.fusedMM_csr_tasks_hip(cabi.MSG_SPMM_SUM, self.rowptr, self.col_padded, self.val, ops[0], buf, out, None, ops[1])
     else:
         cabi.fusedMM_csr_hip(cabi.MSG_SPMM_SUM, self.rowptr, self.col_padded, self.val, buf, out)

@@ -146,10 +146,10 @@ def skew_adjusted(storage_or_rowptr, slices: int) -> int:
     return slices if cv2 >= 0.25 else min(64, int(1.5 * slices + 0.5))
 
 
-def choose_slices(storage: SparseStorage, rows: int, k: int, minmax: bool = False) -> int:
-    """Slice count for a graph held in `storage`: ISPLIB_SLICES=<n> (0 disables) > a count measured by
-    `iSpLibPlugin.autotune` for this graph and width (this process, or a loaded tuning file) > the
-    `suggest_slices` rule."""
+def choose_slices(storage: SparseStorage, rows: int, k: int, minmax: bool = False, transposed: bool = False) -> int:
+    """Slice count for a graph held in `storage` (transposed: for its A^T, the backward's operand; `rows` = rows of the
+    dense operand either way): ISPLIB_SLICES=<n> (0 disables) > a count measured by `iSpLibPlugin.autotune` for this
+    graph and width (this process, or a loaded tuning file) > the `suggest_slices` rule."""
     env = os.environ.get("ISPLIB_SLICES")
     if env is not None:
         n = int(env)
@@ -162,7 +162,10 @@ def choose_slices(storage: SparseStorage, rows: int, k: int, minmax: bool = Fals
         if tuned is not None:
             storage._tuned[(rows, k, minmax)] = int(tuned)
             return int(tuned)
-    m, nnz = storage._rowptr.numel() - 1, storage._col.numel()
+    ruled = storage._tuned.get((rows, k, minmax, transposed))          # the rule's answer for this side, from last time
+    if ruled is not None:
+        return ruled
+    m, nnz = storage.sparse_sizes()[1 if transposed else 0], storage._col.numel()
     s = skew_adjusted(storage, suggest_slices(m, rows, nnz, k, minmax))
     if s > 0:
         # the panel rule halves the slice count to make tasks long enough; on hub-dominated graphs they are long anyway
@@ -170,10 +173,10 @@ def choose_slices(storage: SparseStorage, rows: int, k: int, minmax: bool = Fals
         from . import cabi
         whole = int(cabi.lib().isplib_suggest_slices_whole_rows(m, rows, nnz, k))
         if whole > s:
-            plan_p = storage.plan(s) if rows == storage.sparse_sizes()[1] else storage.plan_t(s)
+            plan_p = storage.plan_t(s) if transposed else storage.plan(s)
             if plan_p and nnz / max(plan_p[0].numel(), 1) >= 120.0:
                 s = whole
-        storage._tuned[(rows, k, minmax)] = s
+        storage._tuned[(rows, k, minmax, transposed)] = s
     return s
 
 
@@ -225,7 +228,7 @@ def spmm_autotuned(src, other: torch.Tensor, reduce: str = "sum") -> torch.Tenso
             geom_t = choose_stream(s, mat.size(0), m_rows, k)
             plan_t = s.stream_plan(True, geom_t, "mean" if reduce == "mean" else "sum") if geom_t is not None else None
             if plan_t is None:
-                plan_t = s.plan_t(choose_slices(s, m_rows, k))
+                plan_t = s.plan_t(choose_slices(s, m_rows, k, transposed=True))
         if reduce == "mean":
             out = ops.fusedmm_spmm_mean_planned(rowptr, col, value, colptr, mat, row_t, val_t, plan, plan_t)
         else:

@@ -109,11 +109,17 @@ for red in ("sum", "mean", "max", "min"):
     want, want_arg = cabi.spmm_sliced(part.rowptr, part.col_padded, part.val, plan[1], plan[0], buf, red)
     for nb in sorted({{1, 2, max(world - 1, 1)}}):
         buf.fill_(float("nan"))                     # nothing may be read before it has landed
+        # world=4 failed here ONCE (('sum', 1): out != want) and passed before and after without a code change to the
+        # exchange.  Suspected, not confirmed: gloo's receive path for device tensors does not order itself behind this
+        # stream's fill, so the NaNs can land on top of a shard that has already arrived (a hazard of this test only;
+        # RCCL's collectives wait for the issuing stream).  The assertion below reports NaN / mismatch counts so that a
+        # recurrence says whether that was it (NaNs) or a wrong slice range (finite values).
+        torch.cuda.synchronize()
         out = torch.zeros((part.rows, 32), device=dev)
         arg = torch.zeros((part.rows, 32), dtype=torch.int64, device=dev) if red in ("max", "min") else None
         part.spmm_direct(shard, buf, out, (plan[0], plan[1], cabi.sliced_workspace(red, part.rows, 32, plan[0], dev)), red, arg, batches=nb)
         torch.cuda.synchronize()
-        assert torch.equal(out, want), (red, nb)
+        assert torch.equal(out, want), (red, nb, int(torch.isnan(out).sum()), int((out != want).sum()))
         if arg is not None:
             assert torch.equal(arg, want_arg), (red, nb)
         dist.barrier()

@@ -510,6 +510,50 @@ def test_graph_handle_runs_the_fast_path_for_torch_free_hosts(gpu, oracle_mod):
         cabi.GraphHandle(_t(rowptr, gpu), _t(col, gpu), None, 2 ** 31 + 5)
 
 
+def test_graph_handle_takes_new_weights_without_rebuilding(gpu, oracle_mod):
+    """isplib_graph_set_values on a graph large enough for the stream schedule (sum / mean forward and both backwards go
+    through stream plans that own a copy of the weights): another array, the same array edited in place, no weights at
+    all -- every call after it must see the new weights, forward and backward, with the plans kept."""
+    from isplib_amd import cabi
+    n, k = 20000, 32
+    rowptr, col = cases.random_csr(n, n, 230.0, seed=41, empty_rows=(7,), hub=(3, 15000))
+    assert col.size >= (1 << 22) and cabi.suggest_stream(n, n, col.size, k) is not None
+    x, g = cases.dense(n, k, 3), cases.dense(n, k, 5)
+    w1, w2 = cases.weights(col.size, 4), cases.weights(col.size, 9)
+    d_w = _t(w1, gpu)
+    h = cabi.GraphHandle(_t(rowptr, gpu), _t(col, gpu), d_w, n)
+
+    def check(w):
+        hv = np.ones(col.size, np.float32) if w is None else w
+        for red in ("sum", "mean", "max"):
+            out, arg = h.spmm(_t(x, gpu), red)
+            ref, ref_arg = oracle_mod.spmm_fw(rowptr, col, hv, x, red)
+            if red == "max":
+                assert np.array_equal(out.cpu().numpy(), ref) and np.array_equal(arg.cpu().numpy(), ref_arg)
+            else:
+                deg = np.maximum(np.diff(rowptr), 1)[:, None] if red == "mean" else 1
+                tol = cases.sum_tolerance(oracle_mod, rowptr, col, hv, x)
+                assert np.all(np.abs(out.cpu().numpy() - ref) <= tol / deg + 1e-12), red
+        dmag = oracle_mod.spmm_sum_bw(rowptr, col, np.abs(hv), n, np.abs(g))
+        dx = h.spmm_backward(_t(g, gpu)).cpu().numpy()
+        assert np.all(np.abs(dx - oracle_mod.spmm_sum_bw(rowptr, col, hv, n, g)) <= 1e-5 * dmag + 1e-30)
+        dxm = h.spmm_backward(_t(g, gpu), mean=True).cpu().numpy()
+        assert np.all(np.abs(dxm - oracle_mod.spmm_mean_bw(rowptr, col, hv, n, g)) <= 1e-5 * dmag + 1e-30)
+
+    check(w1)
+    d_w2 = _t(w2, gpu)
+    h.set_values(d_w2)                  # another array
+    check(w2)
+    d_w2.mul_(-0.5)                     # the same array, edited in place
+    h.set_values(d_w2)
+    check((w2 * np.float32(-0.5)).astype(np.float32))
+    h.set_values(None)                  # unit weights
+    check(None)
+    h.set_values(d_w)                   # and back
+    check(w1)
+    h.close()
+
+
 def test_reference_schema_ops_get_the_task_schedule_through_cached_handles(gpu, oracle_mod):
     """INTEGRATION.md option B: iSpLib's own Python calls torch.ops.isplib.fusedmm_spmm* with just the CSR arrays and
     its cached CSC operands.  On a graph large enough for the slice rule, the operator library serves it from a
@@ -537,25 +581,37 @@ def test_reference_schema_ops_get_the_task_schedule_through_cached_handles(gpu, 
         assert np.all(np.abs(out.detach().cpu().numpy() - ref) <= tol)
         assert np.all(np.abs(xs.grad.cpu().numpy() - dref) <= 1e-5 * dmag + 1e-30)
         assert ops.graph_cache_size() == 2, "one handle for A, one for the cached A^T operands; reused on the second pass"
-    # dA (the SDDMM the reference leaves commented out) runs off the same handle of A, on a plan sized for whole rows
+    # dA (the SDDMM the reference leaves commented out) runs off the same handle of A (its structure is the key; the
+    # weights are a per-call argument), on a plan sized for whole rows
     d_val.requires_grad_(True)
     out = ops.fusedmm_spmm(row, d_rowptr, d_col, d_val, colptr, perm, _t(x, gpu), val_t, row_t)
     out.backward(_t(g, gpu))
     assert np.allclose(d_val.grad.cpu().numpy(), oracle_mod.sddmm(rowptr, col, x, g), rtol=1e-5, atol=1e-4)
-    assert ops.graph_cache_size() == 3                                  # + the weight-free handle of (rowptr, col) for dA
-    out = ops.fusedmm_spmm(row, d_rowptr, d_col, d_val, colptr, perm, _t(x, gpu), val_t, row_t)
-    out.backward(_t(g, gpu))
-    assert ops.graph_cache_size() == 3                                  # and it is reused
-    d_val = d_val.detach()        # same storage, new tensor object: its stale handle is replaced, not added to
+    assert ops.graph_cache_size() == 2
+    d_val = d_val.detach()        # same storage, new tensor object: the handle is told about it, not replaced
     mx, arg = ops.fusedmm_spmm_max(d_rowptr, d_col, d_val, _t(x, gpu))
     rmx, rarg = oracle_mod.spmm_fw(rowptr, col, val, x, "max")
     assert np.array_equal(mx.cpu().numpy(), rmx) and np.array_equal(arg.cpu().numpy(), rarg)
-    assert ops.graph_cache_size() == 3                                   # the (rowptr, col, value) slot was re-used
-    # an in-place edit of the graph invalidates its handle (version counter), and the answer follows the edit
+    assert ops.graph_cache_size() == 2
+    # an in-place edit of the weights (an optimiser step: the version counter moves) keeps the handle and its plans;
+    # the answer follows the edit
     d_val.mul_(2.0)
     out2 = ops.fusedmm_spmm_max(d_rowptr, d_col, d_val, _t(x, gpu))[0]
     rmx2, _ = oracle_mod.spmm_fw(rowptr, col, (val * 2).astype(np.float32), x, "max")
     assert np.array_equal(out2.cpu().numpy(), rmx2)
+    out2 = ops.fusedmm_spmm(row, d_rowptr, d_col, d_val, colptr, perm, _t(x, gpu), val_t, row_t)
+    assert np.all(np.abs(out2.cpu().numpy() - 2 * ref) <= 2 * tol)
+    # another weights tensor altogether, then none at all (unit weights), on the same structure: still one handle of A
+    w3 = cases.weights(col.size, 21)
+    out3 = ops.fusedmm_spmm_min(d_rowptr, d_col, _t(w3, gpu), _t(x, gpu))[0]
+    assert np.array_equal(out3.cpu().numpy(), oracle_mod.spmm_fw(rowptr, col, w3, x, "min")[0])
+    assert ops.graph_cache_size() == 2
+    # an in-place edit of the STRUCTURE retires the handle (version counter of col), and the answer follows the edit
+    d_col.copy_((d_col + 1) % n)
+    col_now = d_col.cpu().numpy()
+    out4 = ops.fusedmm_spmm_max(d_rowptr, d_col, d_val, _t(x, gpu))[0]
+    rmx4, _ = oracle_mod.spmm_fw(rowptr, col_now, (val * 2).astype(np.float32), x, "max")
+    assert np.array_equal(out4.cpu().numpy(), rmx4)
     # graphs whose tensors are gone are dropped the next time a new graph arrives
     del d_rowptr, d_col, d_val, colptr, perm, row_t, val_t, row, out, xs
     r2, c2 = cases.random_csr(n, n, 300.0, seed=32)
