@@ -243,6 +243,28 @@ def extra_configs(dev, rowptr, col, n, with_cpu_epoch=True):
     return out
 
 
+def replicated_graph(make, dev, rank, world):
+    """(rowptr, col, n) on every rank: rank 0 generates, the others receive its copy -- the partition (row cuts, shard
+    pitch, collective sizes) can then never differ between ranks, and ranks that share a GPU (rehearsals) do not all
+    run the generator's sorts on it at once."""
+    if world == 1:
+        return make()
+    import torch.distributed as dist
+    if rank == 0:
+        rowptr, col, n = make()
+        shape = torch.tensor([rowptr.numel(), col.numel(), n], dtype=torch.int64, device=dev)
+    else:
+        shape = torch.zeros(3, dtype=torch.int64, device=dev)
+    dist.broadcast(shape, 0)
+    if rank != 0:
+        rowptr = torch.empty(int(shape[0]), dtype=torch.int64, device=dev)
+        col = torch.empty(int(shape[1]), dtype=torch.int64, device=dev)
+        n = int(shape[2])
+    dist.broadcast(rowptr, 0)
+    dist.broadcast(col, 0)
+    return rowptr, col, n
+
+
 def dist_extra_configs(dev, rank, world, rowptr, col, n):
     """The two configurations of BASELINE.json that exist only on several GPUs, run on the ranks of this job after the
     headline (outside its timed region): config 5 -- the 2-layer GCN epoch on the 1-D row-partitioned graph
@@ -303,9 +325,7 @@ def dist_extra_configs(dev, rank, world, rowptr, col, n):
 
     # config 4
     k = 256
-    p_rowptr, p_col, pn = synth.dataset_like("products", device=dev)
-    dist.broadcast(p_rowptr, 0)                              # same seed, same generator: rank 0's copy is authoritative anyway
-    dist.broadcast(p_col, 0)
+    p_rowptr, p_col, pn = replicated_graph(lambda: synth.dataset_like("products", device=dev), dev, rank, world)
     e = p_col.numel()
     part = RowPartition(p_rowptr, p_col, None, pn, rank, world)
     del p_rowptr, p_col
@@ -390,6 +410,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        # a rank stuck in a collective says where: every thread's Python stack on stderr after ISPLIB_BENCH_WATCHDOG
+        # seconds (default 240) without finishing, and again every so many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ.get("ISPLIB_BENCH_WATCHDOG", "240")), repeat=True, file=sys.stderr)
+
+    def note(msg):
+        if world > 1 and rank == 0:
+            print(f"[bench] {time.strftime('%H:%M:%S')} {msg}", file=sys.stderr, flush=True)
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or drop WORLD_SIZE and let bench.py start them)")
     # ISPLIB_BENCH_FORCE_DIST=1 under `torch.distributed.run --nproc-per-node 1` walks the N > 1 code (RCCL init,
@@ -418,23 +447,17 @@ def main():
 
     from isplib_amd import cabi, synth
     k = a.k or {"reddit": 128, "cora": 16, "products": 256}[a.workload]
-    if a.generator == "chunglu":
-        rowptr, col, n = synth.dataset_like(a.workload, device=dev, scale=a.scale)
-    else:
-        n, target = synth.SHAPES[a.workload][0], synth.SHAPES[a.workload][1]
-        n, target = max(64, int(n * a.scale)), int(target * a.scale) // 2 * 2
-        rowptr, col = (synth.rmat_csr if a.generator == "rmat" else synth.uniform_csr)(n, target, device=dev)
-    if world > 1:
-        # every rank generated the graph from the same seed; rank 0's copy is made authoritative anyway, so that
-        # the partition (row cuts, shard pitch, collective sizes) can never differ between ranks
-        shape = torch.tensor([rowptr.numel(), col.numel()], dtype=torch.int64, device=dev)
-        dist.broadcast(shape, 0)
-        if rank != 0 and (int(shape[0]) != rowptr.numel() or int(shape[1]) != col.numel()):
-            rowptr = torch.empty(int(shape[0]), dtype=torch.int64, device=dev)
-            col = torch.empty(int(shape[1]), dtype=torch.int64, device=dev)
-        dist.broadcast(rowptr, 0)
-        dist.broadcast(col, 0)
+    def make_graph():
+        if a.generator == "chunglu":
+            return synth.dataset_like(a.workload, device=dev, scale=a.scale)
+        n_, target = synth.SHAPES[a.workload][0], synth.SHAPES[a.workload][1]
+        n_, target = max(64, int(n_ * a.scale)), int(target * a.scale) // 2 * 2
+        r_, c_ = (synth.rmat_csr if a.generator == "rmat" else synth.uniform_csr)(n_, target, device=dev)
+        return r_, c_, n_
+
+    rowptr, col, n = replicated_graph(make_graph, dev, rank, world)
     nnz = col.numel()
+    note(f"graph ready on every rank (nnz={nnz})")
     x = synth.features(n, k, device=dev)
     val = synth.edge_weights(nnz, device=dev) if a.weighted else None
     msg = cabi.MESSAGE[a.reduce]
@@ -507,6 +530,7 @@ def main():
                 a.slices = whole
                 tplan = build_task_plan(l_rowptr, l_col, x_in.size(0), a.slices, a.chunk, a.short)
         twork = tplan.workspace(a.reduce, k)
+    note("plans built")
     if world > 1:
         # Which schedules exist is decided from this rank's shard (its row count, its degree skew); a schedule that one
         # rank has and another lacks would leave the ranks in different collectives below.  Keep what EVERY rank has.
@@ -554,6 +578,7 @@ def main():
             return bool(flag.item())
 
         def checked(name, fn, want_fn, exact=True):
+            note(f"checking schedule '{name}'")
             try:
                 want_fn()
                 want = out.clone()
@@ -647,7 +672,10 @@ def main():
             first = clocked(1)                # (also the warm-up; the same value on every rank, so is the branch below)
             return first if first > 250.0 else clocked(reps)      # a schedule this slow is not worth four more steps
 
-        times = {name: timed(fn) for name, fn in candidates.items()}
+        times = {}
+        for name, fn in candidates.items():
+            note(f"timing schedule '{name}'")
+            times[name] = timed(fn)
         chosen = min(times, key=times.get)
         use_tasks = tplan is not None and chosen != "overlapped sliced"
         use_stream = chosen == "gather+stream"
