@@ -865,6 +865,9 @@ def main():
     if multi:
         dist.barrier()
         dist.destroy_process_group()
+    if world > 1:
+        import faulthandler
+        faulthandler.cancel_dump_traceback_later()
 
 
 if __name__ == "__main__":
