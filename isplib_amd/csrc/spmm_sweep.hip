@@ -60,6 +60,9 @@ struct SweepArgs {
    const float *vals;              // [steps][G] weights in the same order, or null (unit weights)
    const int64_t *wave_step_off;   // [waves + 1] first step of a wave
    unsigned null_word;
+#ifdef ISPLIB_EXP_WAVE_TIMES
+   unsigned long long *dbg;        // experiment (scripts/exp_wave_times.py): [wave][4] s_memtime at start / loop entry / loop exit / end
+#endif
    float *part_val;                // [n_parts][k]
    int *part_idx;                  // [n_parts][k] row-relative edge ids (max/min)
    const int32_t *hub_row, *hub_off;
@@ -317,6 +320,9 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, NVMAX, WGS>())) void s
    const int wl = (int)blockIdx.x * WAVES + wave;
    if (wl >= a.wave_count) return;                       // no barrier anywhere below
    const int64_t w = (int64_t)a.wave_base + wl;
+#ifdef ISPLIB_EXP_WAVE_TIMES
+   const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#endif
    float *my = s_all + wave * WAVE_FLOATS;
    for (int i = lane * 4; i < WAVE_FLOATS; i += 256)
       *reinterpret_cast<float4 *>(my + i) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -382,6 +388,9 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, NVMAX, WGS>())) void s
       *p = o;
    };
    const int64_t nb = (nwords + 64 * NBW - 1) / (64 * NBW);
+#ifdef ISPLIB_EXP_WAVE_TIMES
+   const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
+#endif
    for (int64_t b = 0; b < nb; b++) {
       // the U gathers of batch b are in flight; each one consumed is replaced by the same step of batch b + 1
 #pragma unroll
@@ -403,6 +412,9 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, NVMAX, WGS>())) void s
       load_batch((b + 3) * 64 * NBW, w2, v2);
    }
    flush();
+#ifdef ISPLIB_EXP_WAVE_TIMES
+   const unsigned long long t_loop_end = __builtin_amdgcn_s_memtime();
+#endif
    // write-out: slot q owns the local rows [q * PER, (q + 1) * PER); its LPR lanes hold one row of the panel
 #pragma unroll 1
    for (int jj = 0; jj < PER; jj++) {
@@ -422,6 +434,14 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, NVMAX, WGS>())) void s
       finish_row<OP_ADD>(a, row, c, v, bi, arg);
       store_tail<4>(a.z + (size_t)row * (size_t)a.ldz + c, v, vfirst);
    }
+#ifdef ISPLIB_EXP_WAVE_TIMES
+   if (a.dbg && lane == 0) {
+      a.dbg[(size_t)wl * 4 + 0] = t_start;
+      a.dbg[(size_t)wl * 4 + 1] = t_loop;
+      a.dbg[(size_t)wl * 4 + 2] = t_loop_end;
+      a.dbg[(size_t)wl * 4 + 3] = __builtin_amdgcn_s_memtime();
+   }
+#endif
 }
 
 template <int OP, int LPR, int ADDR>
@@ -471,8 +491,16 @@ static int stream_resident_waves(int streams, int cus) {
    return cus * wgs * 4;
 }
 
+#ifdef ISPLIB_EXP_WAVE_TIMES
+static unsigned long long *g_dbg = nullptr;      // set by isplib_debug_wave_times; one slab per launch, four launches
+static int g_dbg_launch = 0;
+#endif
 template <int LPR, bool HAS_VAL>
-static int launch_stream(const SweepArgs &a, hipStream_t st) {
+static int launch_stream(const SweepArgs &a_in, hipStream_t st) {
+   SweepArgs a = a_in;
+#ifdef ISPLIB_EXP_WAVE_TIMES
+   a.dbg = g_dbg ? g_dbg + (size_t)(g_dbg_launch++ % 4) * (size_t)a.wave_count * 4 : nullptr;
+#endif
    const unsigned blocks = (unsigned)((a.wave_count + 3) / 4);
    if (blocks == 0) return ISPLIB_SUCCESS;
    if constexpr (LPR == 32) hipLaunchKernelGGL((spmm_stream_kernel<32, HAS_VAL, 32, 1, 2>), dim3(blocks), dim3(256), 0, st, a);
@@ -725,3 +753,8 @@ extern "C" int fusedMM_csr_stream_hip(int32_t imessage, int64_t m, int64_t n, in
    }
    return ISPLIB_SUCCESS;
 }
+
+#ifdef ISPLIB_EXP_WAVE_TIMES
+// experiment builds only (scripts/exp_wave_times.py; not declared in include/isplib_hip.h)
+extern "C" void isplib_debug_wave_times(unsigned long long *buf) { isplib::g_dbg = buf; isplib::g_dbg_launch = 0; }
+#endif

@@ -1,4 +1,4 @@
-"""Experiment (library built with -DISPLIB_EXP_WAVE_TIMES: the instrumentation is not in the tree): when do the waves of a stream dispatch start, enter their loop,
+"""Experiment (library built with -DISPLIB_EXP_WAVE_TIMES, e.g. scripts/exp_build_variants.sh "python3 scripts/exp_wave_times.py" "-DISPLIB_EXP_WAVE_TIMES=1"): when do the waves of a stream dispatch start, enter their loop,
 leave it and finish?  Prints, per dispatch of one K=128 launch, the spread of those four times over the 2,048 waves
 (s_memtime ticks of 10 ns).  What it answers: how much of a dispatch is ramp / tail rather than steady gathering."""
 import ctypes
