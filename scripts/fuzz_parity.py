@@ -17,7 +17,7 @@ import torch  # noqa: E402
 
 import oracle  # noqa: E402
 from isplib_amd import cabi  # noqa: E402
-from isplib_amd.plan import build_task_plan  # noqa: E402
+from isplib_amd.plan import build_stream_plan, build_sweep_plan, build_task_plan  # noqa: E402
 from tests import cases  # noqa: E402
 
 
@@ -60,10 +60,24 @@ def main():
         row_ids = np.repeat(np.arange(m), np.diff(rowptr))
         ref64 = np.zeros((m, k))
         np.add.at(ref64, row_ids, hv.astype(np.float64)[:, None] * x.astype(np.float64)[col])
+        # round-2 schedules: rows resident in LDS.  sweep (all four reductions) and stream (sum / mean; the plan owns the
+        # edges and the weights), the latter from either builder (torch / native) with random geometry
+        splan = wplan = None
+        native = False
+        if k >= 4 and col.size:
+            streams = int(rng.choice([2, 4, 8]))
+            s_geom = (int(rng.choice([1, 2, 5, 9, 16])), int(rng.integers(1, 9)), int(rng.choice([64, 300, 2048])))   # slices, waves/gen, chunk
+            native = bool(rng.random() < 0.5)
+            if native:
+                splan = cabi.NativeStreamPlan(d_rowptr, d_col, d_val, n, streams, s_geom[0], s_geom[2], s_geom[1])
+            else:
+                splan = build_stream_plan(d_rowptr, d_col, d_val, n, s_geom[0], s_geom[1], None, streams, s_geom[2])
+            if k % 4 == 0 and ld % 4 == 0:
+                wplan = build_sweep_plan(d_rowptr, d_col, n, s_geom[0], s_geom[1], int(rng.choice([8, 16])), s_geom[2], int(rng.choice([1, 8])))
         for red in cases.REDUCES:
             ref, ref_arg = oracle.spmm_fw(rowptr, col, hv, x, red)
             outs = {}
-            for name in ("plain", "sliced", "tasks"):
+            for name in ("plain", "sliced", "tasks", "stream", "sweep"):
                 out = torch.full((m, ld), 7.0, device=dev)[:, :k]
                 arg = torch.full((m, ld), -5, dtype=torch.int64, device=dev)[:, :k] if red in ("max", "min") else None
                 if name == "plain":
@@ -71,8 +85,12 @@ def main():
                 elif name == "sliced":
                     cabi.fusedMM_csr_sliced_hip(cabi.MESSAGE[red], d_rowptr, d_col, d_val, table, slices, d_x, out, arg,
                                                 cabi.sliced_workspace(red, m, k, slices, dev))
-                elif plan is not None:
+                elif name == "tasks" and plan is not None:
                     cabi.fusedMM_csr_tasks_hip(cabi.MESSAGE[red], d_rowptr, d_col, d_val, plan, d_x, out, arg, plan.workspace(red, k))
+                elif name == "stream" and splan is not None and red in ("sum", "mean"):
+                    cabi.fusedMM_csr_stream_hip(cabi.MESSAGE[red], d_rowptr, col.size, splan, d_x, out, splan.workspace())
+                elif name == "sweep" and wplan is not None:
+                    cabi.fusedMM_csr_sweep_hip(cabi.MESSAGE[red], d_rowptr, d_col, d_val, wplan, d_x, out, arg, wplan.workspace(red, k))
                 else:
                     continue
                 outs[name] = (out.cpu().numpy(), None if arg is None else arg.cpu().numpy())
@@ -90,7 +108,10 @@ def main():
                 if not ok:
                     bad += 1
                     print(f"MISMATCH case {case}: {name}/{red} m={m} n={n} k={k} ld={ld} deg={deg} hub={hub} slices={slices} "
-                          f"chunk={chunk} short={short} unit={unit} integer={integer}", flush=True)
+                          f"chunk={chunk} short={short} unit={unit} integer={integer}"
+                          + (f" streams={streams} stream geometry={s_geom} native={native}" if name in ("stream", "sweep") else ""), flush=True)
+        if native and splan is not None:
+            splan.close()
         # ---- the backward side on the same graph: transpose operands, dX of sum / mean, SDDMM dA, max/min scatter ----
         if a.backward and col.size:
             g = cases.dense(m, k, int(rng.integers(1 << 30)), "integer" if integer else "uniform")
@@ -125,6 +146,11 @@ def main():
             lim_v = 1e-5 * np.abs(gv_h).max() + 1e-6 if gv_h.size else 0
             checks.append(("minmax_bw/dval", bool(np.all(np.abs(gv.cpu().numpy() - gv_h) <= lim_v))))
             checks.append(("minmax_bw/dmat", bool(np.all(np.abs(gm.cpu().numpy() - gm_h) <= 1e-5 * np.abs(gm_h).max() + 1e-6))))
+            gv2, gm2 = cabi.spmm_minmax_bw(d_col, None if unit else t(val), d_xc, t(arg_h), d_g, deterministic=True)
+            gv3, gm3 = cabi.spmm_minmax_bw(d_col, None if unit else t(val), d_xc, t(arg_h), d_g, deterministic=True)
+            checks.append(("minmax_bw_det/dval", bool(np.all(np.abs(gv2.cpu().numpy() - gv_h) <= lim_v))))
+            checks.append(("minmax_bw_det/dmat", bool(np.all(np.abs(gm2.cpu().numpy() - gm_h) <= 1e-5 * np.abs(gm_h).max() + 1e-6))))
+            checks.append(("minmax_bw_det/reproducible", bool(torch.equal(gv2, gv3) and torch.equal(gm2, gm3))))
             for name, ok in checks:
                 if not ok:
                     bad += 1
