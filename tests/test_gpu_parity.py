@@ -114,6 +114,38 @@ def test_reference_known_answers(gpu, oracle_mod):
     assert np.array_equal(out.cpu().numpy(), e)
 
 
+def test_reference_known_answers_on_every_schedule(gpu):
+    """The two inputs of the reference tree whose answers can be derived by hand through the planned
+    schedules as well -- task list, sweep, stream (torch-built and native plan): the README case with its columns
+    repeated four times (columns of an SpMM are independent, so the known answer repeats with them; k = 12 is inside
+    every entry's domain), and gpu/fusedmm.cu's 16 x 16 case as it is.  All values are small integers: exact."""
+    from isplib_amd import cabi
+    from isplib_amd.plan import build_stream_plan, build_sweep_plan, build_task_plan
+    rowptr, col, val, x, e_sum, e_max, e_arg = cases.readme_case()
+    toy = cases.gpu_toy_case()
+    inputs = [(rowptr, col, val, np.tile(x, (1, 4)), np.tile(e_sum, (1, 4)), np.tile(e_max, (1, 4)), np.tile(e_arg, (1, 4))),
+              (toy[0], toy[1], toy[2], toy[3], toy[4], toy[4], np.tile(np.arange(16)[:, None], (1, 16)))]
+    for rp, cl, vl, xx, w_sum, w_max, w_arg in inputs:
+        n, k = xx.shape
+        d_rp, d_cl, d_vl, d_x = _t(rp, gpu), _t(cl, gpu), _t(vl, gpu), _t(xx, gpu)
+        tplan = build_task_plan(d_rp, d_cl, n, 2, 64, 0)
+        out, _ = cabi.spmm_tasks(d_rp, d_cl, d_vl, tplan, d_x, "sum")
+        assert np.array_equal(out.cpu().numpy(), w_sum)
+        out, arg = cabi.spmm_tasks(d_rp, d_cl, d_vl, tplan, d_x, "max")
+        assert np.array_equal(out.cpu().numpy(), w_max) and np.array_equal(arg.cpu().numpy(), w_arg)
+        wplan = build_sweep_plan(d_rp, d_cl, n, 2, 2, 8, 2, 1)
+        out, _ = cabi.spmm_sweep(d_rp, d_cl, d_vl, wplan, d_x, "sum")
+        assert np.array_equal(out.cpu().numpy(), w_sum)
+        out, arg = cabi.spmm_sweep(d_rp, d_cl, d_vl, wplan, d_x, "max")
+        assert np.array_equal(out.cpu().numpy(), w_max) and np.array_equal(arg.cpu().numpy(), w_arg)
+        for streams in (2, 4, 8):
+            splan = build_stream_plan(d_rp, d_cl, d_vl, n, 2, 2, None, streams, 2)
+            assert np.array_equal(cabi.spmm_stream(d_rp, cl.size, splan, d_x, "sum").cpu().numpy(), w_sum)
+            nat = cabi.NativeStreamPlan(d_rp, d_cl, d_vl, n, streams, 2, 2, 2)
+            assert np.array_equal(cabi.spmm_stream(d_rp, cl.size, nat, d_x, "sum").cpu().numpy(), w_sum)
+            nat.close()
+
+
 def test_strided_operands_through_leading_dimensions(gpu, oracle_mod):
     from isplib_amd import cabi
     rowptr, col = cases.random_csr(90, 80, 7.0, seed=21)
