@@ -110,6 +110,35 @@ static inline const int32_t *plan_col32(const Plan &p, const Tensor &col) {
                "isplib: the plan's packed column ids do not match col");
    return p[5].data_ptr<int32_t>();
 }
+// the C struct of a stream plan handed over as a tensor list (is_stream_plan), checked against its own meta
+static isplib_stream_plan stream_plan_of(const Plan &plan) {
+   const Tensor &words = plan[0], &vals = plan[1], &step_off = plan[2], &wave_row = plan[3], &wave_part = plan[4],
+                &hub_row = plan[5], &hub_off = plan[6], &meta = plan[7];
+   TORCH_CHECK(!meta.is_cuda() && meta.scalar_type() == at::kLong && meta.numel() == 10, "isplib: stream plan meta must be 10 host int64");
+   TORCH_CHECK(words.is_cuda() && words.scalar_type() == at::kInt && step_off.scalar_type() == at::kLong &&
+                   wave_row.scalar_type() == at::kInt && wave_part.scalar_type() == at::kInt &&
+                   hub_row.scalar_type() == at::kInt && hub_off.scalar_type() == at::kInt &&
+                   (vals.numel() == 0 || (vals.scalar_type() == at::kFloat && vals.numel() == words.numel())),
+               "isplib: malformed stream plan");
+   const int64_t *mt = meta.data_ptr<int64_t>();
+   isplib_stream_plan sp;
+   sp.rows = mt[0]; sp.cols = mt[1]; sp.slices = (int32_t)mt[2]; sp.gens = (int32_t)mt[3]; sp.waves_per_gen = (int32_t)mt[4];
+   sp.rows_per_wave = (int32_t)mt[5]; sp.streams = (int32_t)mt[6]; sp.reserved = 0; sp.n_steps = mt[7]; sp.n_parts = mt[8]; sp.n_hub = mt[9];
+   TORCH_CHECK(words.numel() == sp.n_steps * sp.streams && step_off.numel() == (int64_t)sp.gens * sp.waves_per_gen + 1 &&
+                   wave_row.numel() == (int64_t)sp.gens * sp.waves_per_gen * sp.rows_per_wave && wave_part.numel() == wave_row.numel() &&
+                   hub_row.numel() == sp.n_hub && hub_off.numel() == sp.n_hub + 1,
+               "isplib: stream plan arrays do not match its meta");
+   sp.words = words.data_ptr<int32_t>();
+   sp.vals = vals.numel() ? vals.data_ptr<float>() : nullptr;
+   sp.wave_step_off = step_off.data_ptr<int64_t>();
+   sp.wave_row = wave_row.data_ptr<int32_t>();
+   sp.wave_part = wave_part.data_ptr<int32_t>();
+   sp.hub_row = sp.n_hub ? hub_row.data_ptr<int32_t>() : nullptr;
+   sp.hub_off = hub_off.data_ptr<int32_t>();
+   sp.perm = nullptr;
+   return sp;
+}
+
 // ---- per-graph handles for callers that pass no plan (the reference-schema operators) --------------------------
 // iSpLib's Python keeps its per-graph operands in dicts keyed by raw data pointers (isplib/__init__.py:35-40,50) and
 // calls the operators with just (rowptr, col, value, mat).  To give that caller the fast schedules, the operator
@@ -241,30 +270,7 @@ std::tuple<Tensor, Tensor> spmm_fw(const Tensor &rowptr_, const Tensor &col_, co
    if (is_stream_plan(plan) && M > 0 && K > 0) {
       // the plan carries the edges (and the weights) in its own order: `col` / `value` are not read
       TORCH_CHECK(reduction == R_SUM || reduction == R_MEAN, "isplib: a stream plan serves sum and mean only");
-      const Tensor &words = plan[0], &vals = plan[1], &step_off = plan[2], &wave_row = plan[3], &wave_part = plan[4],
-                   &hub_row = plan[5], &hub_off = plan[6], &meta = plan[7];
-      TORCH_CHECK(!meta.is_cuda() && meta.scalar_type() == at::kLong && meta.numel() == 10, "isplib: stream plan meta must be 10 host int64");
-      TORCH_CHECK(words.is_cuda() && words.scalar_type() == at::kInt && step_off.scalar_type() == at::kLong &&
-                      wave_row.scalar_type() == at::kInt && wave_part.scalar_type() == at::kInt &&
-                      hub_row.scalar_type() == at::kInt && hub_off.scalar_type() == at::kInt &&
-                      (vals.numel() == 0 || (vals.scalar_type() == at::kFloat && vals.numel() == words.numel())),
-                  "isplib: malformed stream plan");
-      const int64_t *mt = meta.data_ptr<int64_t>();
-      isplib_stream_plan sp;
-      sp.rows = mt[0]; sp.cols = mt[1]; sp.slices = (int32_t)mt[2]; sp.gens = (int32_t)mt[3]; sp.waves_per_gen = (int32_t)mt[4];
-      sp.rows_per_wave = (int32_t)mt[5]; sp.streams = (int32_t)mt[6]; sp.reserved = 0; sp.n_steps = mt[7]; sp.n_parts = mt[8]; sp.n_hub = mt[9];
-      TORCH_CHECK(words.numel() == sp.n_steps * sp.streams && step_off.numel() == (int64_t)sp.gens * sp.waves_per_gen + 1 &&
-                      wave_row.numel() == (int64_t)sp.gens * sp.waves_per_gen * sp.rows_per_wave && wave_part.numel() == wave_row.numel() &&
-                      hub_row.numel() == sp.n_hub && hub_off.numel() == sp.n_hub + 1,
-                  "isplib: stream plan arrays do not match its meta");
-      sp.words = words.data_ptr<int32_t>();
-      sp.vals = vals.numel() ? vals.data_ptr<float>() : nullptr;
-      sp.wave_step_off = step_off.data_ptr<int64_t>();
-      sp.wave_row = wave_row.data_ptr<int32_t>();
-      sp.wave_part = wave_part.data_ptr<int32_t>();
-      sp.hub_row = sp.n_hub ? hub_row.data_ptr<int32_t>() : nullptr;
-      sp.hub_off = hub_off.data_ptr<int32_t>();
-      sp.perm = nullptr;
+      const isplib_stream_plan sp = stream_plan_of(plan);
       const size_t ws = isplib_spmm_stream_workspace_bytes(&sp);
       Tensor work = at::empty({(int64_t)ws}, mat.options().dtype(at::kByte));
       const int st = fusedMM_csr_stream_hip(msg, M, N, K, nnz, rp, rp + 1, &sp, mat.data_ptr<float>(), K, out.data_ptr<float>(), K,
@@ -387,6 +393,33 @@ Tensor epilogue_spmm(const Tensor &rowptr, const Tensor &col, const Plan &plan, 
    const Tensor y = y_.contiguous();
    const int64_t M = rowptr.numel() - 1, N = y.size(0), K = y.size(1), nnz = col.numel();
    const bool tasks_fit = is_task_plan(plan) && K >= 4 && M > 0 && (double)N * (double)K * 4.0 <= 3.5 * 1073741824.0;
+   if (is_stream_plan(plan) && M > 0 && K >= 4) {
+      // the stream kernel applies the same epilogue when it writes a finished row (hub rows: in their fold)
+      c10::DeviceGuard guard(y.device());
+      const Tensor self = self_.defined() ? self_.contiguous() : Tensor();
+      const Tensor rs = row_scale.defined() ? row_scale.contiguous() : Tensor();
+      const Tensor bs = bias.defined() ? bias.contiguous() : Tensor();
+      if (self.defined()) TORCH_CHECK(self.size(0) == M && self.size(1) == K, "isplib: `self` must be [M, K]");
+      if (rs.defined()) TORCH_CHECK(rs.numel() == M, "isplib: `row_scale` must have M entries");
+      if (bs.defined()) TORCH_CHECK(bs.numel() == K, "isplib: `bias` must have K entries");
+      const isplib_stream_plan sp = stream_plan_of(plan);
+      TORCH_CHECK(sp.vals == nullptr, "isplib: the fused epilogue is defined for unit weights");
+      const Tensor rp_c = rowptr.contiguous();
+      Tensor out = at::empty({M, K}, y.options());
+      const size_t ws = isplib_spmm_stream_workspace_bytes(&sp);
+      Tensor work = at::empty({(int64_t)ws}, y.options().dtype(at::kByte));
+      isplib_epilogue ep;
+      ep.row_scale = rs.defined() ? rs.data_ptr<float>() : nullptr;
+      ep.self = self.defined() ? self.data_ptr<float>() : nullptr;
+      ep.ld_self = K;
+      ep.bias = bs.defined() ? bs.data_ptr<float>() : nullptr;
+      ep.relu = relu ? 1 : 0;
+      const int64_t *rp = rp_c.data_ptr<int64_t>();
+      const int st = fusedMM_csr_stream_hip(ISPLIB_MSG_SPMM_SUM, M, N, K, nnz, rp, rp + 1, &sp, y.data_ptr<float>(), K, out.data_ptr<float>(), K,
+                                            work.data_ptr(), ws, &ep, current_stream(y));
+      check_status(st, "fusedMM_csr_stream_hip");
+      return out;
+   }
    if (!tasks_fit) {
       Tensor out = std::get<0>(spmm_fw(rowptr, col, c10::nullopt, y, R_SUM, plan));
       if (self_.defined()) out = out + self_;

@@ -282,14 +282,24 @@ def gcn_norm_matmul(src, other: torch.Tensor, bias: Optional[torch.Tensor] = Non
     if s._sparse_sizes[0] != s._sparse_sizes[1]:
         raise ValueError("gcn_norm_matmul needs a square adjacency")
     k = other.size(1)
-    n_sl = choose_slices(s, other.size(0), k)
+    n = other.size(0)
     needs_grad = torch.is_grad_enabled() and other.requires_grad
+    # the same schedule rule as matmul: stream plans (unit weights; the kernel applies the epilogue when it writes a
+    # finished row) where isplib_suggest_stream accepts the shape, else the task list
+    geom = choose_stream(s, n, n, k)
+    plan = s.stream_plan(False, geom) if geom is not None else None
+    n_sl = None
+    if plan is None:
+        n_sl = choose_slices(s, n, k)
+        plan = s.plan(n_sl)
     colptr = row_t = None
     plan_t = []
     if needs_grad:
-        colptr, row_t, plan_t = s.colptr(), s.row_t(), s.plan_t(n_sl)
-    return torch.ops.isplib.gcn_norm_spmm(s._rowptr, s._col, other, s.gcn_dinv(), colptr, row_t, s.plan(n_sl), plan_t,
-                                          bias, relu)
+        colptr, row_t = s.colptr(), s.row_t()
+        plan_t = s.stream_plan(True, geom, "sum") if geom is not None else None
+        if plan_t is None:
+            plan_t = s.plan_t(choose_slices(s, n, k, transposed=True) if n_sl is None else n_sl)
+    return torch.ops.isplib.gcn_norm_spmm(s._rowptr, s._col, other, s.gcn_dinv(), colptr, row_t, plan, plan_t, bias, relu)
 
 
 class iSpLibPlugin:

@@ -452,6 +452,36 @@ def test_fused_gcn_normalised_aggregation(gpu, oracle_mod, monkeypatch, forced):
             _close(bs.grad, dz.sum(0), rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize("geom", ("4:3:64", "8:2:300", "2:5:2048"))
+def test_fused_gcn_normalised_aggregation_on_the_stream_schedule(gpu, oracle_mod, monkeypatch, geom):
+    """The same fused layer where the stream rule accepts the graph (forced here through ISPLIB_STREAM_GEOM: the rule
+    declines graphs this small): the stream kernel applies row scale, self term, bias and ReLU when it writes a finished
+    row -- hub rows (one is cut into virtual rows here) in their fold -- forward on A, backward on A^T."""
+    import isplib_amd
+    monkeypatch.delenv("ISPLIB_SLICES", raising=False)
+    monkeypatch.setenv("ISPLIB_STREAM_GEOM", geom)
+    n, k = 300, 40
+    rowptr, col = cases.random_csr(n, n, 50.0, seed=19, empty_rows=(4,), hub=(9, 280))
+    x, g = cases.dense(n, k, 3), cases.dense(n, k, 5)
+    bias = cases.dense(1, k, 7)[0]
+    adj = isplib_amd.SparseTensor.from_csr(_t(rowptr, gpu), _t(col, gpu), None, (n, n))
+    for use_bias, relu in ((False, False), (True, True)):
+        xs = _t(x, gpu).requires_grad_(True)
+        bs = _t(bias, gpu).requires_grad_(True) if use_bias else None
+        out = isplib_amd.gcn_norm_matmul(adj, xs, bs, relu)
+        out.backward(_t(g, gpu))
+        ref, dinv = _gcn_reference(oracle_mod, rowptr, col, x, bias if use_bias else None, relu)
+        _close(out, ref, rtol=1e-5, atol=1e-5)
+        dz = g * (ref > 0) if relu else g
+        gy = (dz * dinv[:, None]).astype(np.float32)
+        dref = (oracle_mod.spmm_sum_bw(rowptr, col, np.ones(col.size, np.float32), n, gy) + gy) * dinv[:, None]
+        _close(xs.grad, dref, rtol=1e-5, atol=1e-5)
+        if use_bias:
+            _close(bs.grad, dz.sum(0), rtol=1e-5, atol=1e-4)
+    assert any(key[0] is False for key in adj.storage._streams) and any(key[0] is True for key in adj.storage._streams), \
+        "both directions must have run on stream plans"
+
+
 def test_task_epilogue_entry_point(gpu, oracle_mod):
     from isplib_amd import cabi
     from isplib_amd.plan import build_task_plan
