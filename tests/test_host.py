@@ -237,6 +237,48 @@ def test_row_partition_equivalence_gloo(tmp_path, world):
         assert f"rank {r} ok" in o
 
 
+_REPL_WORKER = r"""
+import importlib.util, os, sys
+sys.path.insert(0, {root!r})
+import torch, torch.distributed as dist
+spec = importlib.util.spec_from_file_location("bench_mod", os.path.join({root!r}, "bench.py"))
+bench = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(bench)
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+calls = []
+def make():
+    calls.append(1)
+    g = torch.Generator().manual_seed(1234)                    # only rank 0 may get here
+    rowptr = torch.cumsum(torch.cat([torch.zeros(1, dtype=torch.int64), torch.randint(0, 9, (50,), generator=g)]), 0)
+    return rowptr, torch.randint(0, 50, (int(rowptr[-1]),), generator=g), 50
+rowptr, col, n = bench.replicated_graph(make, torch.device("cpu"), rank, world)
+assert (len(calls) == 1) == (rank == 0), "rank 0 generates, the others receive"
+g = torch.Generator().manual_seed(1234)
+want_rowptr = torch.cumsum(torch.cat([torch.zeros(1, dtype=torch.int64), torch.randint(0, 9, (50,), generator=g)]), 0)
+want_col = torch.randint(0, 50, (int(want_rowptr[-1]),), generator=g)
+assert n == 50 and torch.equal(rowptr, want_rowptr) and torch.equal(col, want_col)
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_bench_graph_is_generated_once_and_replicated_gloo(tmp_path):
+    """bench.py at N > 1: rank 0 generates the graph, every other rank receives its copy (sizes first), so the partition
+    can never differ between ranks."""
+    world = 3
+    script = tmp_path / "worker.py"
+    script.write_text(_REPL_WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29561", WORLD_SIZE=str(world), OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{o}"
+        assert f"rank {r} ok" in o
+
+
 def test_nnz_balanced_cuts():
     from isplib_amd.dist import nnz_balanced_cuts
     rowptr, _ = cases.random_csr(1000, 1000, 20.0, seed=1, hub=(10, 5000))
