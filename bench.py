@@ -136,7 +136,13 @@ def extra_configs(dev, rowptr, col, n, with_cpu_epoch=True):
         arg = torch.empty((n, k), dtype=torch.int64, device=dev) if red in ("max", "min") else None
         msg = cabi.MESSAGE[red]
         geom = cabi.suggest_stream(n, n, nnz, k) if red in ("sum", "mean") else None
-        if geom is not None:
+        geom_mm = cabi.suggest_stream_minmax(n, n, nnz, k) if red in ("max", "min") else None
+        mplan = None if geom_mm is None else build_stream_plan(rowptr, col, val, n, geom_mm[0], None, None, 4, geom_mm[1], minmax=True)
+        if mplan is not None:
+            ws = mplan.workspace(minmax=True)
+            ms = _time_launches(lambda: cabi.fusedMM_csr_stream_minmax_hip(msg, rowptr, nnz, mplan, x, z, arg, ws))
+            sched = f"stream (max / min kernel), {mplan.slices} slices, {mplan.gens} generation(s)"
+        elif geom is not None:
             plan = build_stream_plan(rowptr, col, val, n, geom[1], None, None, geom[0], geom[2])
             ws = plan.workspace()
             ms = _time_launches(lambda: cabi.fusedMM_csr_stream_hip(msg, rowptr, nnz, plan, x, z, ws))

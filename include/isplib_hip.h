@@ -359,7 +359,8 @@ typedef struct isplib_stream_plan {
    const int32_t *hub_row;          /* [dev] n_hub */
    const int32_t *hub_off;          /* [dev] n_hub + 1 */
    const int32_t *perm;             /* [dev] n_steps*streams: CSR position of every word, -1 = padding (for re-gathering
-                                       weights); NULL in plans that do not carry it -- the kernel never reads it */
+                                       weights; the arg candidates of max / min); NULL in plans that do not carry it -- the
+                                       sum / mean kernel never reads it */
 } isplib_stream_plan;
 /* Native plan builder (the same construction as isplib_amd/plan.py, on the device with rocPRIM sorts): allocates the
  * plan's device arrays -- release them with isplib_stream_plan_free -- and synchronises `stream` (twice: the sizes of
@@ -375,6 +376,28 @@ int    isplib_spmm_stream_geometry(int streams, int *rows_per_wave /*out*/, int 
 /* the measured rule: nonzero when the stream schedule is expected to beat the task list for an m x n, nnz-entry SpMM
  * over k columns (sum / mean), with the plan parameters to build it with (streams, column slices, hub-row chunk) */
 int    isplib_suggest_stream(int64_t m, int64_t n, int64_t nnz, int64_t k, int *streams, int *slices, int *chunk);
+/* max / min on the stream schedule, for graphs whose rows are column-sorted (ascending, duplicates allowed).  The
+ * running sum becomes the best value so far and the WORD INDEX at which it was met; a second LDS plane keeps those
+ * indices beside the values, and only a strictly better candidate replaces the one held.  The plan walks a row's edges
+ * slice by slice and, inside a slice, in CSR order -- for a column-sorted row that IS its CSR order, so the candidate
+ * that stays among equals is the one at the lowest CSR position, the reference's tie rule (csrc/fusedmm.cpp:170-178 +
+ * SURVEY.md row K3).  No position travels with the gathers: only the M x K winners are translated to CSR positions,
+ * through the plan's `perm` (required), when a row is written out; hub rows cut into virtual rows carry (value, CSR
+ * position) pairs into their fold.  One geometry: 64-column slots (streams = 4) with half the rows per wave of the sum
+ * kernel, so max / min plans are built for isplib_spmm_stream_minmax_geometry -- isplib_stream_plan_build_minmax_hip
+ * does that and returns ISPLIB_FAIL for a graph with an unsorted row (use the task list) -- and are not interchangeable
+ * with sum plans.  nnz < 2^31.  z_arg (may be NULL): [m][ldz] int64 CSR positions, nnz = empty row. */
+int    isplib_spmm_stream_minmax_geometry(int *streams /*out*/, int *rows_per_wave /*out*/, int *waves_resident /*out*/);
+int    isplib_suggest_stream_minmax(int64_t m, int64_t n, int64_t nnz, int64_t k, int *slices, int *chunk);
+int    isplib_stream_plan_build_minmax_hip(int64_t m, int64_t n, int64_t nnz, const int64_t *rowptr, const int64_t *col,
+                                           const float *val, int slices, int chunk, int waves_per_gen,
+                                           isplib_stream_plan *out /*host*/, void *stream);
+size_t isplib_spmm_stream_minmax_workspace_bytes(const isplib_stream_plan *plan);
+int    fusedMM_csr_stream_minmax_hip(int32_t imessage /* ISPLIB_MSG_SPMM_MAX | _MIN */, int64_t m, int64_t n, int64_t k,
+                                     int64_t nnz, const int64_t *pntrb, const int64_t *pntre,
+                                     const isplib_stream_plan *plan /*host*/,
+                                     const float *y, int64_t ldy, float *z, int64_t ldz, int64_t *z_arg,
+                                     void *workspace, size_t workspace_bytes, void *stream);
 size_t isplib_spmm_stream_workspace_bytes(const isplib_stream_plan *plan);
 int    fusedMM_csr_stream_hip(int32_t imessage /* ISPLIB_MSG_SPMM_SUM | _MEAN */, int64_t m, int64_t n, int64_t k,
                               int64_t nnz, const int64_t *pntrb, const int64_t *pntre,

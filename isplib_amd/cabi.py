@@ -52,7 +52,7 @@ EXPORTS = (
     "isplib_suggest_slices", "isplib_graph_create", "isplib_graph_set_slices", "isplib_graph_set_values", "isplib_graph_spmm", "isplib_graph_spmm_backward",
     "isplib_graph_destroy", "isplib_suggest_slices_whole_rows", "isplib_graph_sddmm",
     "fusedMM_csr_sweep_hip", "isplib_spmm_sweep_workspace_bytes", "isplib_spmm_sweep_resident_waves",
-    "fusedMM_csr_stream_hip", "isplib_spmm_stream_workspace_bytes", "isplib_spmm_stream_geometry", "isplib_suggest_stream", "isplib_stream_plan_build_hip", "isplib_stream_plan_set_values_hip", "isplib_stream_plan_free", "isplib_spmm_minmax_bw_det_hip", "isplib_spmm_minmax_bw_workspace_bytes",
+    "fusedMM_csr_stream_hip", "isplib_spmm_stream_workspace_bytes", "isplib_spmm_stream_geometry", "isplib_suggest_stream", "isplib_stream_plan_build_hip", "isplib_stream_plan_build_minmax_hip", "fusedMM_csr_stream_minmax_hip", "isplib_spmm_stream_minmax_geometry", "isplib_suggest_stream_minmax", "isplib_spmm_stream_minmax_workspace_bytes", "isplib_stream_plan_set_values_hip", "isplib_stream_plan_free", "isplib_spmm_minmax_bw_det_hip", "isplib_spmm_minmax_bw_workspace_bytes",
 )
 
 _i64, _f32, _vp, _i32 = ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_int32
@@ -178,6 +178,18 @@ def lib() -> ctypes.CDLL:
         L.isplib_stream_plan_build_hip.restype = ctypes.c_int
         L.isplib_stream_plan_build_hip.argtypes = [_i64, _i64, _i64, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                    ctypes.POINTER(StreamPlanStruct), _vp]
+        L.isplib_stream_plan_build_minmax_hip.restype = ctypes.c_int
+        L.isplib_stream_plan_build_minmax_hip.argtypes = [_i64, _i64, _i64, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                          ctypes.POINTER(StreamPlanStruct), _vp]
+        L.isplib_spmm_stream_minmax_geometry.restype = ctypes.c_int
+        L.isplib_spmm_stream_minmax_geometry.argtypes = [ctypes.POINTER(ctypes.c_int)] * 3
+        L.isplib_suggest_stream_minmax.restype = ctypes.c_int
+        L.isplib_suggest_stream_minmax.argtypes = [_i64, _i64, _i64, _i64, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+        L.isplib_spmm_stream_minmax_workspace_bytes.restype = ctypes.c_size_t
+        L.isplib_spmm_stream_minmax_workspace_bytes.argtypes = [ctypes.POINTER(StreamPlanStruct)]
+        L.fusedMM_csr_stream_minmax_hip.restype = ctypes.c_int
+        L.fusedMM_csr_stream_minmax_hip.argtypes = [_i32, _i64, _i64, _i64, _i64, _vp, _vp, ctypes.POINTER(StreamPlanStruct), _vp, _i64,
+                                                    _vp, _i64, _vp, _vp, ctypes.c_size_t, _vp]
         L.isplib_stream_plan_set_values_hip.restype = ctypes.c_int
         L.isplib_stream_plan_set_values_hip.argtypes = [ctypes.POINTER(StreamPlanStruct), _vp, _vp]
         L.isplib_stream_plan_free.restype = None
@@ -610,6 +622,50 @@ def spmm_stream(rowptr, nnz: int, plan, y, reduce: str = "sum", workspace=None, 
     return out
 
 
+def fusedMM_csr_stream_minmax_hip(imessage: int, rowptr, nnz: int, plan, y, z, z_arg=None, workspace=None, check: bool = True) -> int:
+    """Raw boundary call of the stream-form SpMM for max / min; ``plan`` must be built for stream_minmax_geometry()."""
+    assert y.is_cuda and y.dtype == torch.float32 and y.dim() == 2 and y.stride(1) == 1
+    m, n, k = rowptr.numel() - 1, y.size(0), y.size(1)
+    rp = rowptr.data_ptr()
+    ps = plan.struct()
+    with torch.cuda.device(y.device):
+        st = lib().fusedMM_csr_stream_minmax_hip(int(imessage), m, n, k, int(nnz), ctypes.c_void_p(rp), ctypes.c_void_p(rp + 8),
+                                                 ctypes.byref(ps), _ptr(y), y.stride(0) if n > 1 else max(k, y.stride(0)), _ptr(z),
+                                                 z.stride(0) if m > 1 else max(k, z.stride(0)), _ptr(z_arg), _ptr(workspace),
+                                                 0 if workspace is None else workspace.numel(), _stream(y.device))
+    if check:
+        _check(st, "fusedMM_csr_stream_minmax_hip")
+    return st
+
+
+def spmm_stream_minmax(rowptr, nnz: int, plan, y, reduce: str = "max", workspace=None, want_arg: bool = True):
+    """Allocate the outputs (+ workspace) and call the max / min stream boundary; returns (out, arg)."""
+    rowptr = _dev(rowptr, "rowptr", torch.int64)
+    y = y.contiguous()
+    m, k = rowptr.numel() - 1, y.size(1)
+    out = torch.empty((m, k), dtype=torch.float32, device=y.device)
+    arg = torch.empty((m, k), dtype=torch.int64, device=y.device) if want_arg else None
+    if workspace is None:
+        workspace = plan.workspace(minmax=True)
+    fusedMM_csr_stream_minmax_hip(MESSAGE[reduce], rowptr, nnz, plan, y, out, arg, workspace)
+    return out, arg
+
+
+def suggest_stream_minmax(m: int, n: int, nnz: int, k: int):
+    """(slices, chunk) when the stream schedule is expected to win for max / min on this shape, else None."""
+    sl, ch = ctypes.c_int(0), ctypes.c_int(0)
+    if not lib().isplib_suggest_stream_minmax(int(m), int(n), int(nnz), int(k), ctypes.byref(sl), ctypes.byref(ch)):
+        return None
+    return sl.value, ch.value
+
+
+def stream_minmax_geometry():
+    """(streams, rows per wave, resident waves) of the max / min stream kernel (isplib_spmm_stream_minmax_geometry)."""
+    st, rpw, res = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    _check(lib().isplib_spmm_stream_minmax_geometry(ctypes.byref(st), ctypes.byref(rpw), ctypes.byref(res)), "isplib_spmm_stream_minmax_geometry")
+    return st.value, rpw.value, res.value
+
+
 def suggest_stream(m: int, n: int, nnz: int, k: int):
     """(streams, slices, chunk) when the stream schedule is expected to win for this shape, else None (isplib_suggest_stream)."""
     st, sl, ch = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
@@ -629,22 +685,29 @@ class NativeStreamPlan:
     """A stream plan built by the C library (isplib_stream_plan_build_hip) -- the torch-free host's counterpart of
     isplib_amd.plan.build_stream_plan; same interface as plan.StreamPlan for the boundary wrappers."""
 
-    def __init__(self, rowptr, col, val, ncols: int, streams: int, slices: int, chunk: int, waves_per_gen: int = 0):
+    def __init__(self, rowptr, col, val, ncols: int, streams: int, slices: int, chunk: int, waves_per_gen: int = 0,
+                 minmax: bool = False):
         self._s = StreamPlanStruct()
         self.device = col.device
         m = rowptr.numel() - 1
         with torch.cuda.device(col.device):
-            _check(lib().isplib_stream_plan_build_hip(m, int(ncols), col.numel(), _ptr(rowptr), _ptr(col), _ptr(val), int(streams),
-                                                      int(slices), int(chunk), int(waves_per_gen), ctypes.byref(self._s),
-                                                      _stream(col.device)), "isplib_stream_plan_build_hip")
+            if minmax:
+                _check(lib().isplib_stream_plan_build_minmax_hip(m, int(ncols), col.numel(), _ptr(rowptr), _ptr(col), _ptr(val),
+                                                                 int(slices), int(chunk), int(waves_per_gen), ctypes.byref(self._s),
+                                                                 _stream(col.device)), "isplib_stream_plan_build_minmax_hip")
+            else:
+                _check(lib().isplib_stream_plan_build_hip(m, int(ncols), col.numel(), _ptr(rowptr), _ptr(col), _ptr(val), int(streams),
+                                                          int(slices), int(chunk), int(waves_per_gen), ctypes.byref(self._s),
+                                                          _stream(col.device)), "isplib_stream_plan_build_hip")
         for name in ("rows", "cols", "slices", "gens", "waves_per_gen", "rows_per_wave", "streams", "n_steps", "n_parts", "n_hub"):
             setattr(self, name, int(getattr(self._s, name)))
 
     def struct(self):
         return self._s
 
-    def workspace(self):
-        nbytes = lib().isplib_spmm_stream_workspace_bytes(ctypes.byref(self._s))
+    def workspace(self, minmax: bool = False):
+        L = lib()
+        nbytes = (L.isplib_spmm_stream_minmax_workspace_bytes if minmax else L.isplib_spmm_stream_workspace_bytes)(ctypes.byref(self._s))
         return torch.empty(nbytes, dtype=torch.uint8, device=self.device)
 
     def set_values(self, val):

@@ -41,6 +41,7 @@ struct Side {                    // A, or A^T, as CSR
    // stream order: `val` of the side, or the mean backward's weights)
    struct Stream { isplib_stream_plan plan; const float *vals_of = nullptr; bool has_vals = false; uint64_t gen = 0; };
    std::map<uint64_t, Stream> streams;
+   bool minmax_stream_refused = false;   // the max / min stream builder declined this side (rows not column-sorted): task list
 };
 
 __global__ __launch_bounds__(256) void not_all_ones_kernel(int64_t nnz, const float *__restrict__ val, int *__restrict__ flag) {
@@ -322,6 +323,40 @@ static int run_side(isplib_graph *g, Side &s, const float *val, int32_t imessage
          const int rc = ensure_work(g, need, st, &w);
          if (rc) return rc;
          return fusedMM_csr_stream_hip(imessage, s.m, s.n, k, s.nnz, s.rowptr, s.rowptr + 1, &sp.plan, y, ldy, z, ldz, w->ptr, w->bytes, nullptr, st);
+      }
+   }
+   // max / min on such graphs: the stream schedule's own kernel and plan geometry, for column-sorted rows
+   int mm_slices = 0, mm_chunk = 0;
+   if (minmax && g->forced_slices < 0 && !s.minmax_stream_refused && ldy < (1LL << 22) &&
+       isplib_suggest_stream_minmax(s.m, s.n, s.nnz, k, &mm_slices, &mm_chunk)) {
+      const uint64_t key = (1ULL << 63) | ((uint64_t)mm_slices << 32) | (uint64_t)(uint32_t)mm_chunk;
+      auto it = s.streams.find(key);
+      if (it == s.streams.end()) {
+         Side::Stream fresh;
+         const int rc = isplib_stream_plan_build_minmax_hip(s.m, s.n, s.nnz, s.rowptr, s.col, val, mm_slices, mm_chunk, 0, &fresh.plan, st);
+         if (rc == ISPLIB_SUCCESS) {
+            fresh.vals_of = val; fresh.has_vals = val != nullptr; fresh.gen = g->val_gen;
+            it = s.streams.emplace(key, fresh).first;
+         } else if (rc == ISPLIB_FAIL) {
+            s.minmax_stream_refused = true;           // unsorted rows (or outside the builder's domain): not an error of this call
+            clear_error();
+         } else if (rc != ISPLIB_NOT_ENOUGH_MEM) {
+            return rc;
+         }
+      }
+      if (it != s.streams.end()) {
+         Side::Stream &sp = it->second;
+         if (sp.vals_of != val || sp.has_vals != (val != nullptr) || (val && sp.gen != g->val_gen)) {
+            const int rc = isplib_stream_plan_set_values_hip(&sp.plan, val, st);
+            if (rc) return rc;
+            sp.vals_of = val; sp.has_vals = val != nullptr; sp.gen = g->val_gen;
+         }
+         const size_t need = isplib_spmm_stream_minmax_workspace_bytes(&sp.plan);
+         isplib_graph::Work *w = nullptr;
+         const int rc = ensure_work(g, need, st, &w);
+         if (rc) return rc;
+         return fusedMM_csr_stream_minmax_hip(imessage, s.m, s.n, k, s.nnz, s.rowptr, s.rowptr + 1, &sp.plan, y, ldy, z, ldz, z_arg, w->ptr,
+                                              w->bytes, st);
       }
    }
    int slices = g->forced_slices >= 0 ? g->forced_slices : isplib_suggest_slices(s.m, s.n, s.nnz, k, minmax);

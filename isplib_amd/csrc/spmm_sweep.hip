@@ -34,6 +34,16 @@
 #ifndef ISPLIB_STREAM_WGS4
 #define ISPLIB_STREAM_WGS4 2
 #endif
+// the same for max / min (64-column slots; a second LDS plane holds the winners' positions: half the rows per wave)
+#ifndef ISPLIB_STREAM_MM_NV
+#define ISPLIB_STREAM_MM_NV 32
+#endif
+#ifndef ISPLIB_STREAM_MM_NBW
+#define ISPLIB_STREAM_MM_NBW 2
+#endif
+#ifndef ISPLIB_STREAM_MM_WGS
+#define ISPLIB_STREAM_MM_WGS 2
+#endif
 
 namespace isplib {
 
@@ -60,6 +70,8 @@ struct SweepArgs {
    const float *vals;              // [steps][G] weights in the same order, or null (unit weights)
    const int64_t *wave_step_off;   // [waves + 1] first step of a wave
    unsigned null_word;
+   const int32_t *ids;             // stream form, max / min: [steps][G] CSR position of every word (the plan's perm), -1 = padding
+   int abs_ids;                    // part_idx holds absolute CSR positions (stream form) instead of row-relative ones
 #ifdef ISPLIB_EXP_WAVE_TIMES
    unsigned long long *dbg;        // experiment (scripts/exp_wave_times.py): [wave][4] s_memtime at start / loop entry / loop exit / end
 #endif
@@ -105,7 +117,7 @@ __device__ __forceinline__ void finish_row(const SweepArgs &a, int row, int c, f
 #pragma unroll
       for (int i = 0; i < 4; i++) {
          if (deg <= 0) v[i] = 0.0f;
-         arg[i] = bi[i] == INT_MAX ? a.nnz : rb + (int64_t)bi[i];
+         arg[i] = bi[i] == INT_MAX ? a.nnz : (a.abs_ids ? (int64_t)bi[i] : rb + (int64_t)bi[i]);
       }
    }
 }
@@ -277,7 +289,7 @@ __global__ __launch_bounds__(256) void sweep_hub_fold_kernel(const SweepArgs a) 
             if (a.ep_relu) v[0] = v[0] > 0.0f ? v[0] : 0.0f;
          } else {
             if (deg <= 0) v[0] = 0.0f;
-            arg[0] = bi[0] == INT_MAX ? a.nnz : rb + (int64_t)bi[0];
+            arg[0] = bi[0] == INT_MAX ? a.nnz : (a.abs_ids ? (int64_t)bi[0] : rb + (int64_t)bi[0]);
          }
          a.z[(size_t)row * (size_t)a.ldz + c] = v[0];
       }
@@ -444,6 +456,157 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, NVMAX, WGS>())) void s
 #endif
 }
 
+// max / min on the stream schedule.  The running sum becomes the best value so far and the WORD INDEX (position in the
+// wave's stream) at which it was met; a second LDS plane keeps those indices beside the values.  "Strictly better
+// wins" in stream order: the plan walks the edges of a row slice by slice and, inside a slice, in CSR order, so for rows
+// whose columns ascend the stream order of a row IS its CSR order and the first of equal candidates -- the lowest CSR
+// position, the reference's tie rule -- is the one that stays (the plan builders refuse graphs with unsorted rows for
+// this kernel).  No position travels with the gathers: the word index is arithmetic (batch, step, slot), and only the
+// M x K winners are translated to CSR positions, through the plan's `perm`, when a row is written out.  Padding words
+// (column n: the gather returns 0, which could beat negative values) are steered to a spare LDS row of the wave.
+template <int OP, bool HAS_VAL, int NVMAX, int NBW, int WGS>
+__global__ __launch_bounds__(256, (stream_wgs_per_cu<16, 2 * (NVMAX + 1), WGS>())) void spmm_stream_minmax_kernel(const SweepArgs a) {
+   constexpr int LPR = 16, WAVES = 4, G = 64 / LPR, PANEL = LPR * 4, U = 64 * NBW / G;
+   constexpr int PER = NVMAX / G;
+   constexpr int WAVE_FLOATS = (NVMAX + 1) * PANEL;       // + the spare row of the padding words
+   __shared__ __attribute__((aligned(16))) float s_all[2 * WAVES * WAVE_FLOATS];
+   const int lane = threadIdx.x & 63;
+   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+   const int g = lane / LPR, lc = lane % LPR;
+   const int wl = (int)blockIdx.x * WAVES + wave;
+   if (wl >= a.wave_count) return;                       // no barrier anywhere below
+   const int64_t w = (int64_t)a.wave_base + wl;
+   float *my = s_all + wave * WAVE_FLOATS;
+   int *my_idx = reinterpret_cast<int *>(s_all + WAVES * WAVE_FLOATS) + wave * WAVE_FLOATS;
+   for (int i = lane * 4; i < WAVE_FLOATS; i += 256) {
+      *reinterpret_cast<float4 *>(my + i) = make_float4(identity<OP>(), identity<OP>(), identity<OP>(), identity<OP>());
+      *reinterpret_cast<int4 *>(my_idx + i) = make_int4(INT_MAX, INT_MAX, INT_MAX, INT_MAX);
+   }
+   __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.y), 0, (int)a.ybytes, 0x00020000);
+   const bool cok = lc * 4 < a.k;
+   int ccol = lc * 4, vfirst = 0;
+   if (cok && ccol + 4 > (int)a.k) { vfirst = ccol + 4 - (int)a.k; ccol = (int)a.k - 4; }
+   const unsigned cbyte = (unsigned)ccol * 4u, poison = cok ? 0u : BUF_OOB;
+   float *lane_base = my + lc * 4;
+   int *lane_idx = my_idx + lc * 4;
+   const int64_t s0 = a.wave_step_off[w], s1 = a.wave_step_off[w + 1];
+   const int64_t nwords = (s1 - s0) * G;
+   const int32_t *wp = a.words + s0 * G;
+   const float *vp = HAS_VAL ? a.vals + s0 * G : nullptr;
+   const unsigned ldyb = (unsigned)a.ldy * 4u;
+   const unsigned pad_word = ((unsigned)((lane % G) * PER) << 24) | a.null_word;
+   auto load_batch = [&](int64_t first, unsigned (&word)[NBW], float (&val)[NBW]) {
+#pragma unroll
+      for (int q = 0; q < NBW; q++) {
+         const int64_t i = first + q * 64 + lane;
+         word[q] = pad_word;
+         val[q] = 0.0f;
+         if (i < nwords) {
+            word[q] = (unsigned)wp[i];
+            if (HAS_VAL) val[q] = vp[i];
+         }
+      }
+   };
+   unsigned w1[NBW], w2[NBW];
+   float v0[NBW], v1[NBW], v2[NBW];                      // the weights of the batch being consumed, of the next, of the one after
+   v4i_t t[U];
+   unsigned la[U];
+   // (a weight is fetched from its batch register when its gather is consumed, one step ahead -- a ring of U weights
+   // beside the U gathers in flight does not fit the register file)
+   auto issue = [&](int u, const unsigned (&word_l)[NBW]) {
+      const unsigned word = (unsigned)__shfl((int)word_l[(u * G) / 64], (u * G) % 64 + g);
+      const unsigned colw = word & 0xFFFFFFu;
+      const unsigned o = (__umul24(colw, ldyb) + cbyte) | poison;
+      la[u] = colw == a.null_word ? (unsigned)(NVMAX * PANEL) : (word >> 24) * (unsigned)PANEL;     // padding: the spare row
+      t[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)o, 0, 0);
+   };
+   load_batch(0, w1, v0);
+#pragma unroll
+   for (int u = 0; u < U; u++) issue(u, w1);
+   load_batch(64 * NBW, w1, v1);
+   load_batch(128 * NBW, w2, v2);
+   unsigned cur = (unsigned)(g * PER * PANEL);
+   float acc[4];
+   int bi[4];
+#pragma unroll
+   for (int v = 0; v < 4; v++) { acc[v] = identity<OP>(); bi[v] = INT_MAX; }
+   // the registers hold LATER stream positions than the LDS row they are merged into: the row's entry stays on a tie
+   auto flush = [&]() {
+      float4 *p = reinterpret_cast<float4 *>(lane_base + cur);
+      int4 *pi = reinterpret_cast<int4 *>(lane_idx + cur);
+      float4 o = *p;
+      int4 oi = *pi;
+      bool tk;
+      tk = OP == OP_MAX ? acc[0] > o.x : acc[0] < o.x; o.x = tk ? acc[0] : o.x; oi.x = tk ? bi[0] : oi.x;
+      tk = OP == OP_MAX ? acc[1] > o.y : acc[1] < o.y; o.y = tk ? acc[1] : o.y; oi.y = tk ? bi[1] : oi.y;
+      tk = OP == OP_MAX ? acc[2] > o.z : acc[2] < o.z; o.z = tk ? acc[2] : o.z; oi.z = tk ? bi[2] : oi.z;
+      tk = OP == OP_MAX ? acc[3] > o.w : acc[3] < o.w; o.w = tk ? acc[3] : o.w; oi.w = tk ? bi[3] : oi.w;
+      *p = o;
+      *pi = oi;
+   };
+   const int64_t nb = (nwords + 64 * NBW - 1) / (64 * NBW);
+   for (int64_t b = 0; b < nb; b++) {
+      const int widx0 = (int)(b * (64 * NBW)) + g;        // word index of this lane's slot at step 0 of the batch
+      float vnext = HAS_VAL ? __shfl(v0[0], g) : 0.0f;
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+         const float vcur = vnext;
+         if (HAS_VAL && u + 1 < U) vnext = __shfl(v0[((u + 1) * G) / 64], ((u + 1) * G) % 64 + g);
+         if (la[u] != cur) {
+            flush();
+            cur = la[u];
+#pragma unroll
+            for (int v = 0; v < 4; v++) { acc[v] = identity<OP>(); bi[v] = INT_MAX; }
+         }
+         const int widx = widx0 + u * G;
+#pragma unroll
+         for (int v = 0; v < 4; v++) {
+            const float x = __int_as_float(t[u][v]);
+            const float tt = HAS_VAL ? vcur * x : x;
+            const bool win = OP == OP_MAX ? tt > acc[v] : tt < acc[v];      // NaN never wins, as in the oracle
+            acc[v] = win ? tt : acc[v];
+            bi[v] = win ? widx : bi[v];
+         }
+         issue(u, w1);
+      }
+#pragma unroll
+      for (int q = 0; q < NBW; q++) { w1[q] = w2[q]; v0[q] = v1[q]; v1[q] = v2[q]; }
+      load_batch((b + 3) * 64 * NBW, w2, v2);
+   }
+   flush();
+   // write-out: the winners' word indices become CSR positions through the plan's permutation
+   const int32_t *ids = a.ids + s0 * G;
+#pragma unroll 1
+   for (int jj = 0; jj < PER; jj++) {
+      const int lrow = g * PER + jj;
+      const int row = a.wave_row[(size_t)w * NVMAX + lrow];
+      if (row < 0 || !cok) continue;
+      const int part = a.wave_part[(size_t)w * NVMAX + lrow];
+      const float4 t4 = *reinterpret_cast<const float4 *>(lane_base + lrow * PANEL);
+      const int4 i4 = *reinterpret_cast<const int4 *>(lane_idx + lrow * PANEL);
+      float v[4] = {t4.x, t4.y, t4.z, t4.w};
+      int best[4] = {i4.x, i4.y, i4.z, i4.w};
+#pragma unroll
+      for (int i = 0; i < 4; i++) best[i] = best[i] == INT_MAX ? INT_MAX : ids[best[i]];
+      const int c = ccol;
+      if (part >= 0) {
+         const size_t po = (size_t)part * (size_t)a.k + c;
+         store_tail<4>(a.part_val + po, v, vfirst);
+#pragma unroll
+         for (int i = 0; i < 4; i++) if (i >= vfirst) a.part_idx[po + i] = best[i];
+         continue;
+      }
+      int64_t arg[4];
+      finish_row<OP>(a, row, c, v, best, arg);
+      store_tail<4>(a.z + (size_t)row * (size_t)a.ldz + c, v, vfirst);
+      if (a.z_arg) {
+         int64_t *ar = a.z_arg + (size_t)row * (size_t)a.ldz + c;
+#pragma unroll
+         for (int i = 0; i < 4; i++) if (i >= vfirst) ar[i] = arg[i];
+      }
+   }
+}
+
 template <int OP, int LPR, int ADDR>
 static int launch_sweep_nv(const SweepArgs &a, int nvmax, hipStream_t st) {
    const unsigned blocks = (unsigned)((a.wave_count + 3) / 4);
@@ -476,16 +639,17 @@ static int sweep_resident_waves(bool add, int64_t pk, int nvmax, int cus) {
 // the one geometry per slot width (lanes per row slot = 64 / streams) that the entry launches: rows per wave, batch
 // registers and workgroups per CU (measured on the Reddit shape, K = 128 in 64-column panels)
 struct StreamGeom { int nvmax, nbw, wgs; };
-static StreamGeom stream_geom(int streams) {
+static StreamGeom stream_geom(int streams, bool minmax = false) {
+   if (minmax) return {ISPLIB_STREAM_MM_NV, ISPLIB_STREAM_MM_NBW, ISPLIB_STREAM_MM_WGS};   // 64-column slots only
    if (streams == 2) return {32, 1, 2};     // 128-column panels: U = 32 gathers of 1 KiB per wave
    if (streams == 4) return {ISPLIB_STREAM_NV4, ISPLIB_STREAM_NBW4, ISPLIB_STREAM_WGS4};
    return {64, 2, 3};                       // 32-column panels: U = 16
 }
 
-static int stream_resident_waves(int streams, int cus) {
-   const StreamGeom ge = stream_geom(streams);
+static int stream_resident_waves(int streams, int cus, bool minmax = false) {
+   const StreamGeom ge = stream_geom(streams, minmax);
    const int lpr = 64 / streams;
-   const int lds = 4 * ge.nvmax * lpr * 4 * 4;
+   const int lds = minmax ? 2 * 4 * (ge.nvmax + 1) * lpr * 4 * 4 : 4 * ge.nvmax * lpr * 4 * 4;
    int wgs = 163840 / lds;
    if (wgs > ge.wgs) wgs = ge.wgs;
    return cus * wgs * 4;
@@ -507,6 +671,14 @@ static int launch_stream(const SweepArgs &a_in, hipStream_t st) {
    else if constexpr (LPR == 16) hipLaunchKernelGGL((spmm_stream_kernel<16, HAS_VAL, ISPLIB_STREAM_NV4, ISPLIB_STREAM_NBW4, ISPLIB_STREAM_WGS4>), dim3(blocks), dim3(256), 0, st, a);
    else hipLaunchKernelGGL((spmm_stream_kernel<8, HAS_VAL, 64, 2, 3>), dim3(blocks), dim3(256), 0, st, a);
    return check_launch("spmm_stream_kernel");
+}
+
+template <int OP, bool HAS_VAL>
+static int launch_stream_minmax(const SweepArgs &a, hipStream_t st) {
+   const unsigned blocks = (unsigned)((a.wave_count + 3) / 4);
+   if (blocks == 0) return ISPLIB_SUCCESS;
+   hipLaunchKernelGGL((spmm_stream_minmax_kernel<OP, HAS_VAL, ISPLIB_STREAM_MM_NV, ISPLIB_STREAM_MM_NBW, ISPLIB_STREAM_MM_WGS>), dim3(blocks), dim3(256), 0, st, a);
+   return check_launch("spmm_stream_minmax_kernel");
 }
 
 int g_sweep_panel = 64;     // tuning knob (isplib_hip_tune(9, w)): column-panel width of the sweep schedule, 32 / 64 / 128
@@ -571,7 +743,7 @@ extern "C" int fusedMM_csr_sweep_hip(int32_t imessage, int64_t m, int64_t n, int
       if (!workspace || workspace_bytes < need) return fail(ISPLIB_NOT_ENOUGH_MEM, "fusedMM_csr_sweep_hip: workspace too small");
       if (((uintptr_t)workspace & 255) != 0) return fail(ISPLIB_FAIL, "fusedMM_csr_sweep_hip: workspace must be 256-byte aligned");
    }
-   SweepArgs a;
+   SweepArgs a = {};
    a.k = k; a.nnz = nnz; a.val = val; a.indx = indx; a.indx32 = indx32; a.pntrb = pntrb; a.pntre = pntre;
    a.y = y; a.ldy = ldy; a.ybytes = (unsigned)yb; a.z = z; a.ldz = ldz; a.z_arg = z_arg;
    a.mean = (vsc == ISPLIB_VSC_MEAN) ? 1 : 0;
@@ -630,17 +802,44 @@ extern "C" int fusedMM_csr_sweep_hip(int32_t imessage, int64_t m, int64_t n, int
 }
 
 // ---- stream form: entry ---------------------------------------------------------------------------------------------
-extern "C" int isplib_spmm_stream_geometry(int streams, int *rows_per_wave, int *waves_resident) {
-   clear_error();
-   if (streams != 2 && streams != 4 && streams != 8) return fail(ISPLIB_FAIL, "isplib_spmm_stream_geometry: streams must be 2, 4 or 8");
+static int device_cus() {
    int dev = 0, cus = 0;
    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
       (void)hipGetLastError();
       cus = 256;                                          // MI355X
    }
+   return cus;
+}
+
+extern "C" int isplib_spmm_stream_geometry(int streams, int *rows_per_wave, int *waves_resident) {
+   clear_error();
+   if (streams != 2 && streams != 4 && streams != 8) return fail(ISPLIB_FAIL, "isplib_spmm_stream_geometry: streams must be 2, 4 or 8");
    if (rows_per_wave) *rows_per_wave = stream_geom(streams).nvmax;
-   if (waves_resident) *waves_resident = stream_resident_waves(streams, cus);
+   if (waves_resident) *waves_resident = stream_resident_waves(streams, device_cus());
    return ISPLIB_SUCCESS;
+}
+
+extern "C" int isplib_spmm_stream_minmax_geometry(int *streams, int *rows_per_wave, int *waves_resident) {
+   clear_error();
+   if (streams) *streams = 4;
+   if (rows_per_wave) *rows_per_wave = stream_geom(4, true).nvmax;
+   if (waves_resident) *waves_resident = stream_resident_waves(4, device_cus(), true);
+   return ISPLIB_SUCCESS;
+}
+
+static int suggest_stream_geom(int64_t m, int64_t n, int64_t nnz, int st, int rpw, int resident, double slice_bytes, double chunk_div,
+                               int *slices, int *chunk) {
+   const int64_t per_gen = (int64_t)rpw * resident;
+   const int64_t gens = (m + per_gen - 1) / per_gen;
+   if ((double)nnz / (double)gens / 8.0 < 8.0 * (double)n) return 0;
+   const double panel_bytes = 1024.0 / st;
+   int sl = (int)((double)n * panel_bytes / slice_bytes + 0.5);
+   sl = sl < 1 ? 1 : (sl > 512 ? 512 : sl);
+   int64_t ch = (int64_t)((double)nnz / ((double)gens * resident * st) / chunk_div);
+   ch = ch < 256 ? 256 : (ch > (1 << 20) ? (1 << 20) : ch);
+   if (slices) *slices = sl;
+   if (chunk) *chunk = (int)ch;
+   return 1;
 }
 
 extern "C" int isplib_suggest_stream(int64_t m, int64_t n, int64_t nnz, int64_t k, int *streams, int *slices, int *chunk) {
@@ -658,18 +857,21 @@ extern "C" int isplib_suggest_stream(int64_t m, int64_t n, int64_t nnz, int64_t 
    const int st = k <= 32 ? 8 : (k <= 64 ? 4 : (k < 128 ? 2 : 4));
    int rpw = 0, resident = 0;
    if (isplib_spmm_stream_geometry(st, &rpw, &resident) != ISPLIB_SUCCESS || rpw <= 0 || resident <= 0) return 0;
-   const int64_t per_gen = (int64_t)rpw * resident;
-   const int64_t gens = (m + per_gen - 1) / per_gen;
-   if ((double)nnz / (double)gens / 8.0 < 8.0 * (double)n) return 0;
-   const double panel_bytes = 1024.0 / st;
-   int sl = (int)((double)n * panel_bytes / 1.9e6 + 0.5);
-   sl = sl < 1 ? 1 : (sl > 512 ? 512 : sl);
-   int64_t ch = (int64_t)((double)nnz / ((double)gens * resident * st) / 3.4);
-   ch = ch < 256 ? 256 : (ch > (1 << 20) ? (1 << 20) : ch);
+   if (!suggest_stream_geom(m, n, nnz, st, rpw, resident, 1.9e6, 3.4, slices, chunk)) return 0;
    if (streams) *streams = st;
-   if (slices) *slices = sl;
-   if (chunk) *chunk = (int)ch;
    return 1;
+}
+
+extern "C" int isplib_suggest_stream_minmax(int64_t m, int64_t n, int64_t nnz, int64_t k, int *slices, int *chunk) {
+   // max / min: one geometry (64-column slots); the same reuse rule; rows must be column-sorted.  Measured on the Reddit
+   // shape (K = 64): slices of ~5 MB (8-12 slices: 1.82 ms; 16: 1.88; 31, the sum kernel's count: 2.2 -- every change of
+   // row costs this kernel a read-compare-write of two LDS planes, and more slices mean more changes) and rows cut at
+   // ~0.6 of a stream's share (chunk 2048: 1.82 ms, 1028: 1.92, 4096: 1.96); task list: 2.04 ms
+   clear_error();
+   if (m <= 0 || n <= 0 || nnz <= 0 || k < 4 || n >= (1LL << 24) || nnz < (1LL << 22) || nnz >= (1LL << 31)) return 0;
+   int st = 0, rpw = 0, resident = 0;
+   if (isplib_spmm_stream_minmax_geometry(&st, &rpw, &resident) != ISPLIB_SUCCESS || rpw <= 0 || resident <= 0) return 0;
+   return suggest_stream_geom(m, n, nnz, st, rpw, resident, 5.0e6, 1.7, slices, chunk);
 }
 
 extern "C" size_t isplib_spmm_stream_workspace_bytes(const isplib_stream_plan *plan) {
@@ -678,13 +880,17 @@ extern "C" size_t isplib_spmm_stream_workspace_bytes(const isplib_stream_plan *p
    return ((size_t)plan->n_parts * pk * sizeof(float) + 255) & ~(size_t)255;
 }
 
-extern "C" int fusedMM_csr_stream_hip(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t nnz,
-                                      const int64_t *pntrb, const int64_t *pntre, const isplib_stream_plan *plan,
-                                      const float *y, int64_t ldy, float *z, int64_t ldz, void *workspace,
-                                      size_t workspace_bytes, const isplib_epilogue *ep, void *stream) {
+extern "C" size_t isplib_spmm_stream_minmax_workspace_bytes(const isplib_stream_plan *plan) {
+   return 2 * isplib_spmm_stream_workspace_bytes(plan);   // values, then CSR positions
+}
+
+static int stream_run(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t nnz, const int64_t *pntrb, const int64_t *pntre,
+                      const isplib_stream_plan *plan, const float *y, int64_t ldy, float *z, int64_t ldz, int64_t *z_arg,
+                      void *workspace, size_t workspace_bytes, const isplib_epilogue *ep, void *stream) {
    clear_error();
-   if (imessage != ISPLIB_MSG_SPMM_SUM && imessage != ISPLIB_MSG_SPMM_MEAN)
-      return fail(ISPLIB_NO_OPT_IMPL, "fusedMM_csr_stream_hip: sum and mean only (max / min: fusedMM_csr_tasks_hip)");
+   const bool mm = imessage == ISPLIB_MSG_SPMM_MAX || imessage == ISPLIB_MSG_SPMM_MIN;
+   if (imessage != ISPLIB_MSG_SPMM_SUM && imessage != ISPLIB_MSG_SPMM_MEAN && !mm)
+      return fail(ISPLIB_NO_OPT_IMPL, "fusedMM_csr_stream_hip: message outside the SpMM set");
    if (m < 0 || n < 0 || k < 0 || nnz < 0) return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: negative dimension");
    if (m == 0 || k == 0) return ISPLIB_SUCCESS;
    if (!plan) return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: plan is required");
@@ -692,8 +898,12 @@ extern "C" int fusedMM_csr_stream_hip(int32_t imessage, int64_t m, int64_t n, in
    if (n >= (1LL << 24) || ldy >= (1LL << 22)) return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: n must be < 2^24 and ldy < 2^22 (24-bit address arithmetic)");
    if (plan->streams != 2 && plan->streams != 4 && plan->streams != 8)
       return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: bad plan geometry (streams 2, 4 or 8)");
-   if (plan->gens < 1 || plan->waves_per_gen < 1 || plan->rows_per_wave != stream_geom(plan->streams).nvmax)
-      return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: bad plan geometry (rows_per_wave must be what isplib_spmm_stream_geometry reports)");
+   if (mm && plan->streams != 4) return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: max / min run on 4-stream plans (isplib_spmm_stream_minmax_geometry)");
+   if (plan->gens < 1 || plan->waves_per_gen < 1 || plan->rows_per_wave != stream_geom(plan->streams, mm).nvmax)
+      return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: bad plan geometry (rows_per_wave must be what isplib_spmm_stream_geometry / _minmax_geometry reports)");
+   if (mm && plan->n_steps > 0 && !plan->perm) return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: max / min need the plan's perm array (the winners' CSR positions)");
+   if (mm && nnz >= (1LL << 31)) return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: max / min need nnz < 2^31");
+   if (mm && ep) return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: the epilogue is defined for sum / mean only");
    if (k < 4) return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: k >= 4 required (use fusedMM_csr_hip)");
    if (ldy < k || ldz < k) return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: leading dimension smaller than k");
    const unsigned long long yb = (unsigned long long)n * (unsigned long long)ldy * 4ull;
@@ -702,17 +912,19 @@ extern "C" int fusedMM_csr_stream_hip(int32_t imessage, int64_t m, int64_t n, in
        (plan->n_steps > 0 && !plan->words) || (plan->n_hub > 0 && (!plan->hub_row || !plan->hub_off)))
       return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: null operand");
    if (plan->n_parts > 0) {
-      if (!workspace || workspace_bytes < isplib_spmm_stream_workspace_bytes(plan)) return fail(ISPLIB_NOT_ENOUGH_MEM, "fusedMM_csr_stream_hip: workspace too small");
+      if (!workspace || workspace_bytes < (mm ? 2 : 1) * isplib_spmm_stream_workspace_bytes(plan)) return fail(ISPLIB_NOT_ENOUGH_MEM, "fusedMM_csr_stream_hip: workspace too small");
       if (((uintptr_t)workspace & 255) != 0) return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: workspace must be 256-byte aligned");
    }
    SweepArgs a = {};
    a.k = k; a.nnz = nnz; a.pntrb = pntrb; a.pntre = pntre;
-   a.y = y; a.ldy = ldy; a.ybytes = (unsigned)yb; a.z = z; a.ldz = ldz; a.z_arg = nullptr;
+   a.y = y; a.ldy = ldy; a.ybytes = (unsigned)yb; a.z = z; a.ldz = ldz; a.z_arg = z_arg;
    a.mean = imessage == ISPLIB_MSG_SPMM_MEAN ? 1 : 0;
+   a.ids = plan->perm; a.abs_ids = 1;
    a.wave_row = plan->wave_row; a.wave_part = plan->wave_part;
    a.words = plan->words; a.vals = plan->vals; a.wave_step_off = plan->wave_step_off; a.null_word = (unsigned)n;
    a.hub_row = plan->hub_row; a.hub_off = plan->hub_off; a.n_hub = plan->n_hub;
-   a.part_val = (float *)workspace; a.part_idx = nullptr;
+   a.part_val = (float *)workspace;
+   a.part_idx = mm && workspace ? (int *)((char *)workspace + isplib_spmm_stream_workspace_bytes(plan)) : nullptr;
    if (ep) {
       if (ep->self && ep->ld_self < k) return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: ld_self smaller than k");
       a.ep_row_scale = ep->row_scale; a.ep_self = ep->self; a.ep_ld_self = ep->ld_self; a.ep_bias = ep->bias;
@@ -731,12 +943,15 @@ extern "C" int fusedMM_csr_stream_hip(int32_t imessage, int64_t m, int64_t n, in
       p.z = z + c0;
       p.ep_self = a.ep_self ? a.ep_self + c0 : nullptr;
       p.ep_bias = a.ep_bias ? a.ep_bias + c0 : nullptr;
+      p.z_arg = z_arg ? z_arg + c0 : nullptr;
       p.ybytes = (unsigned)(yb - (unsigned long long)c0 * 4ull);
       for (int gen = 0; gen < plan->gens; gen++) {
          p.wave_base = gen * plan->waves_per_gen;
          p.wave_count = plan->waves_per_gen;
          int rc;
-         if (plan->streams == 2) rc = plan->vals ? launch_stream<32, true>(p, st) : launch_stream<32, false>(p, st);
+         if (imessage == ISPLIB_MSG_SPMM_MAX) rc = plan->vals ? launch_stream_minmax<OP_MAX, true>(p, st) : launch_stream_minmax<OP_MAX, false>(p, st);
+         else if (imessage == ISPLIB_MSG_SPMM_MIN) rc = plan->vals ? launch_stream_minmax<OP_MIN, true>(p, st) : launch_stream_minmax<OP_MIN, false>(p, st);
+         else if (plan->streams == 2) rc = plan->vals ? launch_stream<32, true>(p, st) : launch_stream<32, false>(p, st);
          else if (plan->streams == 4) rc = plan->vals ? launch_stream<16, true>(p, st) : launch_stream<16, false>(p, st);
          else rc = plan->vals ? launch_stream<8, true>(p, st) : launch_stream<8, false>(p, st);
          if (rc) return rc;
@@ -745,13 +960,41 @@ extern "C" int fusedMM_csr_stream_hip(int32_t imessage, int64_t m, int64_t n, in
          const bool v4 = (p.k % 4) == 0 && (p.ldz % 4) == 0 && ((uintptr_t)p.z & 15) == 0 && (!p.ep_self || ((p.ep_ld_self % 4) == 0 && ((uintptr_t)p.ep_self & 15) == 0));
          int64_t blocks = (plan->n_hub * (v4 ? p.k / 4 : p.k) + 255) / 256;
          if (blocks > 4096) blocks = 4096;
-         if (v4) hipLaunchKernelGGL((sweep_hub_fold_kernel<OP_ADD, 4>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+         if (imessage == ISPLIB_MSG_SPMM_MAX) {
+            if (v4) hipLaunchKernelGGL((sweep_hub_fold_kernel<OP_MAX, 4>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((sweep_hub_fold_kernel<OP_MAX, 1>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+         } else if (imessage == ISPLIB_MSG_SPMM_MIN) {
+            if (v4) hipLaunchKernelGGL((sweep_hub_fold_kernel<OP_MIN, 4>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((sweep_hub_fold_kernel<OP_MIN, 1>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+         } else if (v4) hipLaunchKernelGGL((sweep_hub_fold_kernel<OP_ADD, 4>), dim3((unsigned)blocks), dim3(256), 0, st, p);
          else hipLaunchKernelGGL((sweep_hub_fold_kernel<OP_ADD, 1>), dim3((unsigned)blocks), dim3(256), 0, st, p);
          const int rc = check_launch("sweep_hub_fold_kernel");
          if (rc) return rc;
       }
    }
    return ISPLIB_SUCCESS;
+}
+
+extern "C" int fusedMM_csr_stream_hip(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t nnz,
+                                      const int64_t *pntrb, const int64_t *pntre, const isplib_stream_plan *plan,
+                                      const float *y, int64_t ldy, float *z, int64_t ldz, void *workspace,
+                                      size_t workspace_bytes, const isplib_epilogue *ep, void *stream) {
+   if (imessage != ISPLIB_MSG_SPMM_SUM && imessage != ISPLIB_MSG_SPMM_MEAN) {
+      clear_error();
+      return fail(ISPLIB_NO_OPT_IMPL, "fusedMM_csr_stream_hip: sum and mean only (max / min: fusedMM_csr_stream_minmax_hip)");
+   }
+   return stream_run(imessage, m, n, k, nnz, pntrb, pntre, plan, y, ldy, z, ldz, nullptr, workspace, workspace_bytes, ep, stream);
+}
+
+extern "C" int fusedMM_csr_stream_minmax_hip(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t nnz,
+                                             const int64_t *pntrb, const int64_t *pntre, const isplib_stream_plan *plan,
+                                             const float *y, int64_t ldy, float *z, int64_t ldz, int64_t *z_arg,
+                                             void *workspace, size_t workspace_bytes, void *stream) {
+   if (imessage != ISPLIB_MSG_SPMM_MAX && imessage != ISPLIB_MSG_SPMM_MIN) {
+      clear_error();
+      return fail(ISPLIB_NO_OPT_IMPL, "fusedMM_csr_stream_minmax_hip: max and min only");
+   }
+   return stream_run(imessage, m, n, k, nnz, pntrb, pntre, plan, y, ldy, z, ldz, z_arg, workspace, workspace_bytes, nullptr, stream);
 }
 
 #ifdef ISPLIB_EXP_WAVE_TIMES

@@ -240,17 +240,14 @@ extern "C" int isplib_stream_plan_set_values_hip(isplib_stream_plan *plan, const
    return ISPLIB_SUCCESS;
 }
 
-extern "C" int isplib_stream_plan_build_hip(int64_t m, int64_t n, int64_t nnz, const int64_t *rowptr, const int64_t *col,
-                                            const float *val, int streams, int slices, int chunk, int waves_per_gen,
-                                            isplib_stream_plan *out, void *stream) {
-   clear_error();
+static int stream_plan_build(int64_t m, int64_t n, int64_t nnz, const int64_t *rowptr, const int64_t *col, const float *val,
+                             int streams, int rpw, int resident, int slices, int chunk, int waves_per_gen,
+                             isplib_stream_plan *out, void *stream) {
    if (!out) return fail(ISPLIB_FAIL, "isplib_stream_plan_build_hip: out is NULL");
    memset(out, 0, sizeof(*out));
    if (m <= 0 || n <= 0 || nnz < 0 || !rowptr || (nnz > 0 && !col)) return fail(ISPLIB_FAIL, "isplib_stream_plan_build_hip: bad operand");
    if (n >= (1LL << 24) || nnz >= (1LL << 31) || m >= (1LL << 31)) return fail(ISPLIB_FAIL, "isplib_stream_plan_build_hip: n < 2^24, nnz < 2^31, m < 2^31 required");
    if (slices < 1 || slices > 4096 || chunk < 1 || chunk >= (1 << 24)) return fail(ISPLIB_FAIL, "isplib_stream_plan_build_hip: slices in [1, 4096], chunk in [1, 2^24)");
-   int rpw = 0, resident = 0;
-   if (isplib_spmm_stream_geometry(streams, &rpw, &resident) != ISPLIB_SUCCESS) return ISPLIB_FAIL;
    if (waves_per_gen <= 0) waves_per_gen = resident;
    const int per = rpw / streams;
    hipStream_t st = (hipStream_t)stream;
@@ -402,4 +399,50 @@ extern "C" int isplib_stream_plan_build_hip(int64_t m, int64_t n, int64_t nnz, c
    out->rows_per_wave = rpw; out->streams = streams; out->reserved = chunk;
    out->n_steps = n_steps; out->n_parts = n_parts; out->n_hub = n_hub;
    return ISPLIB_SUCCESS;
+}
+
+extern "C" int isplib_stream_plan_build_hip(int64_t m, int64_t n, int64_t nnz, const int64_t *rowptr, const int64_t *col,
+                                            const float *val, int streams, int slices, int chunk, int waves_per_gen,
+                                            isplib_stream_plan *out, void *stream) {
+   clear_error();
+   int rpw = 0, resident = 0;
+   if (isplib_spmm_stream_geometry(streams, &rpw, &resident) != ISPLIB_SUCCESS) return ISPLIB_FAIL;
+   return stream_plan_build(m, n, nnz, rowptr, col, val, streams, rpw, resident, slices, chunk, waves_per_gen, out, stream);
+}
+
+// 1 if some row's columns do not ascend (duplicates are fine)
+__global__ __launch_bounds__(256) void sp_unsorted_kernel(int64_t m, int64_t nnz, const int64_t *__restrict__ rowptr,
+                                                          const int64_t *__restrict__ col, int *__restrict__ flag) {
+   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+   bool bad = false;
+   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1; e < nnz; e += stride)
+      if (col[e] < col[e - 1] && e > rowptr[sp_row_of(e, m, rowptr)]) bad = true;
+   if (bad) atomicOr(flag, 1);
+}
+
+extern "C" int isplib_stream_plan_build_minmax_hip(int64_t m, int64_t n, int64_t nnz, const int64_t *rowptr, const int64_t *col,
+                                                   const float *val, int slices, int chunk, int waves_per_gen,
+                                                   isplib_stream_plan *out, void *stream) {
+   clear_error();
+   int streams = 0, rpw = 0, resident = 0;
+   if (isplib_spmm_stream_minmax_geometry(&streams, &rpw, &resident) != ISPLIB_SUCCESS) return ISPLIB_FAIL;
+   if (out) memset(out, 0, sizeof(*out));
+   if (m <= 0 || nnz < 0 || !rowptr || (nnz > 0 && !col)) return fail(ISPLIB_FAIL, "isplib_stream_plan_build_minmax_hip: bad operand");
+   // the kernel's tie rule (first strictly better candidate in stream order = lowest CSR position) holds for rows whose
+   // columns ascend: anything else is refused here and stays on the task list
+   if (nnz > 1) {
+      int *flag = nullptr, host = 1;
+      if (hipMalloc((void **)&flag, 256) != hipSuccess) { (void)hipGetLastError(); return fail(ISPLIB_NOT_ENOUGH_MEM, "isplib_stream_plan_build_minmax_hip: device allocation failed"); }
+      hipStream_t st = (hipStream_t)stream;
+      bool ok = hipMemsetAsync(flag, 0, sizeof(int), st) == hipSuccess;
+      if (ok) {
+         hipLaunchKernelGGL(sp_unsorted_kernel, dim3(sp_grid(nnz)), dim3(256), 0, st, m, nnz, rowptr, col, flag);
+         ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(&host, flag, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess &&
+              hipStreamSynchronize(st) == hipSuccess;
+      }
+      (void)hipFree(flag);
+      if (!ok) return hip_fail(hipGetLastError(), "isplib_stream_plan_build_minmax_hip: sortedness check");
+      if (host) return fail(ISPLIB_FAIL, "isplib_stream_plan_build_minmax_hip: rows are not column-sorted (use the task list)");
+   }
+   return stream_plan_build(m, n, nnz, rowptr, col, val, streams, rpw, resident, slices, chunk, waves_per_gen, out, stream);
 }

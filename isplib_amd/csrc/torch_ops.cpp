@@ -99,7 +99,7 @@ using Plan = std::vector<Tensor>;
 static inline bool is_task_plan(const Plan &p) { return p.size() == 5 || p.size() == 6; }
 // stream plan (sum / mean; isplib_stream_plan) = {words, vals (empty = unit weights), wave_step_off, wave_row, wave_part,
 // hub_row, hub_off, meta (host int64: rows, cols, slices, gens, waves_per_gen, rows_per_wave, streams, n_steps, n_parts, n_hub)}
-static inline bool is_stream_plan(const Plan &p) { return p.size() == 8; }
+static inline bool is_stream_plan(const Plan &p) { return p.size() == 8 || p.size() == 9; }   // 9: + perm (max / min)
 // what the reference-schema operators pass: "no plan was given, choose for me" (one undefined tensor), as opposed
 // to the empty plan of the *_planned operators, which means "the plain kernel, please"
 static inline Plan auto_plan() { return Plan{Tensor()}; }
@@ -136,6 +136,10 @@ static isplib_stream_plan stream_plan_of(const Plan &plan) {
    sp.hub_row = sp.n_hub ? hub_row.data_ptr<int32_t>() : nullptr;
    sp.hub_off = hub_off.data_ptr<int32_t>();
    sp.perm = nullptr;
+   if (plan.size() == 9) {
+      TORCH_CHECK(plan[8].is_cuda() && plan[8].scalar_type() == at::kInt && plan[8].numel() == words.numel(), "isplib: stream plan perm must be int32, one per word");
+      sp.perm = plan[8].data_ptr<int32_t>();
+   }
    return sp;
 }
 
@@ -269,8 +273,16 @@ std::tuple<Tensor, Tensor> spmm_fw(const Tensor &rowptr_, const Tensor &col_, co
    const bool tasks_fit = K >= 4 && (double)N * (double)K * 4.0 <= 3.5 * 1073741824.0;
    if (is_stream_plan(plan) && M > 0 && K > 0) {
       // the plan carries the edges (and the weights) in its own order: `col` / `value` are not read
-      TORCH_CHECK(reduction == R_SUM || reduction == R_MEAN, "isplib: a stream plan serves sum and mean only");
       const isplib_stream_plan sp = stream_plan_of(plan);
+      if (reduction == R_MAX || reduction == R_MIN) {
+         TORCH_CHECK(sp.perm != nullptr, "isplib: max / min on a stream plan need its permutation (a 9-element plan)");
+         const size_t ws = isplib_spmm_stream_minmax_workspace_bytes(&sp);
+         Tensor work = at::empty({(int64_t)ws}, mat.options().dtype(at::kByte));
+         const int st = fusedMM_csr_stream_minmax_hip(msg, M, N, K, nnz, rp, rp + 1, &sp, mat.data_ptr<float>(), K, out.data_ptr<float>(), K,
+                                                      arg.data_ptr<int64_t>(), work.data_ptr(), ws, current_stream(mat));
+         check_status(st, "fusedMM_csr_stream_minmax_hip");
+         return std::make_tuple(out, arg);
+      }
       const size_t ws = isplib_spmm_stream_workspace_bytes(&sp);
       Tensor work = at::empty({(int64_t)ws}, mat.options().dtype(at::kByte));
       const int st = fusedMM_csr_stream_hip(msg, M, N, K, nnz, rp, rp + 1, &sp, mat.data_ptr<float>(), K, out.data_ptr<float>(), K,

@@ -241,10 +241,11 @@ class StreamPlan:
                                      p(self.wave_step_off), p(self.wave_row), p(self.wave_part), p(self.hub_row), p(self.hub_off),
                                      p(self.perm) if self.perm.dtype == torch.int32 else None)
 
-    def workspace(self) -> torch.Tensor:
+    def workspace(self, minmax: bool = False) -> torch.Tensor:
         import ctypes
         ps = self.struct()
-        nbytes = cabi.lib().isplib_spmm_stream_workspace_bytes(ctypes.byref(ps))
+        L = cabi.lib()
+        nbytes = (L.isplib_spmm_stream_minmax_workspace_bytes if minmax else L.isplib_spmm_stream_workspace_bytes)(ctypes.byref(ps))
         return torch.empty(nbytes, dtype=torch.uint8, device=self.words.device)
 
     def set_values(self, val: Optional[torch.Tensor]) -> None:
@@ -346,13 +347,24 @@ def stream_plan_arrays(rowptr: torch.Tensor, col: torch.Tensor, ncols: int, slic
 
 def build_stream_plan(rowptr: torch.Tensor, col: torch.Tensor, val: Optional[torch.Tensor], ncols: int, slices: int,
                       waves_per_gen: Optional[int] = None, rows_per_wave: Optional[int] = None, streams: int = 4,
-                      chunk: int = 512) -> Optional[StreamPlan]:
+                      chunk: int = 512, minmax: bool = False) -> Optional[StreamPlan]:
     """Stream plan of a graph on the device.  rows_per_wave / waves_per_gen default to what the kernel of this slot
-    width is built for (isplib_spmm_stream_geometry).  None when n >= 2^24.  (Rows need not be column-sorted: the
-    stream order -- slice, row, CSR position -- is the plan's own.)"""
+    width is built for (isplib_spmm_stream_geometry; minmax: isplib_spmm_stream_minmax_geometry, whose plans are their
+    own).  None when n >= 2^24.  (Rows need not be column-sorted: the stream order -- slice, row, CSR position -- is the
+    plan's own.)"""
     if ncols >= (1 << 24):
         return None
-    rpw, resident = cabi.stream_geometry(streams)
+    if minmax:
+        # the kernel's tie rule (first strictly better candidate in stream order = lowest CSR position) holds for rows
+        # whose columns ascend; anything else stays on the task list
+        if col.numel() > 1:
+            starts = torch.zeros(col.numel(), dtype=torch.bool, device=col.device)
+            starts[rowptr[:-1][rowptr[:-1] < col.numel()]] = True
+            if bool(((col[1:] < col[:-1]) & ~starts[1:]).any()):
+                return None
+        streams, rpw, resident = cabi.stream_minmax_geometry()
+    else:
+        rpw, resident = cabi.stream_geometry(streams)
     rows_per_wave = rpw if rows_per_wave is None else rows_per_wave
     waves_per_gen = resident if waves_per_gen is None else waves_per_gen
     plan = StreamPlan(**stream_plan_arrays(rowptr, col, ncols, slices, waves_per_gen, rows_per_wave, streams, chunk))

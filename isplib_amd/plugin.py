@@ -194,6 +194,22 @@ def choose_stream(storage: SparseStorage, m: int, n: int, k: int):
     return cabi.suggest_stream(m, n, storage._col.numel(), k)
 
 
+def choose_stream_minmax(storage: SparseStorage, m: int, n: int, k: int):
+    """(4, slices, chunk) when max / min of this shape should run on the stream schedule (column-sorted rows; the plan
+    builder has the last word), else None.  Same switches as choose_stream."""
+    if os.environ.get("ISPLIB_STREAM", "1") == "0" or os.environ.get("ISPLIB_SLICES") is not None:
+        return None
+    if k < 4 or n >= (1 << 24) or storage._col.numel() >= (1 << 31):
+        return None
+    forced = os.environ.get("ISPLIB_STREAM_MINMAX_GEOM")   # "slices:chunk": tests and experiments
+    if forced:
+        sl, ch = (int(v) for v in forced.split(":"))
+        return 4, sl, ch
+    from . import cabi
+    geom = cabi.suggest_stream_minmax(m, n, storage._col.numel(), k)
+    return None if geom is None else (4,) + tuple(geom)
+
+
 def spmm_autotuned(src, other: torch.Tensor, reduce: str = "sum") -> torch.Tensor:
     """``torch_sparse.matmul(src, other, reduce)`` on the HIP path (isplib/__init__.py:48-157)."""
     if reduce not in ("sum", "add", "mean", "max", "min"):
@@ -214,8 +230,12 @@ def spmm_autotuned(src, other: torch.Tensor, reduce: str = "sum") -> torch.Tenso
     m_rows = rowptr.numel() - 1
     # sum / mean on graphs with work for the whole chip: the stream schedule (rows resident in LDS, the plan's own copy
     # of the edges; include/isplib_hip.h: fusedMM_csr_stream_hip) -- measured 15-18 % ahead of the task list
-    geom = choose_stream(s, m_rows, mat.size(0), k) if reduce in ("sum", "add", "mean") else None
-    plan = s.stream_plan(False, geom) if geom is not None else None
+    if reduce in ("sum", "add", "mean"):
+        geom = choose_stream(s, m_rows, mat.size(0), k)
+        plan = s.stream_plan(False, geom) if geom is not None else None
+    else:                                                            # max / min: its own kernel geometry, sorted rows only
+        geom = choose_stream_minmax(s, m_rows, mat.size(0), k)
+        plan = s.stream_plan(False, geom, "minmax") if geom is not None else None
     if plan is None:
         n_sl = choose_slices(s, mat.size(0), k, reduce in ("max", "min"))
         plan = s.plan(n_sl)                                          # per-graph, built once on the device

@@ -144,16 +144,19 @@ class SparseStorage:
         """Operands of the stream schedule for the `_planned` operators: [words, vals, wave_step_off, wave_row, wave_part,
         hub_row, hub_off, meta_cpu] for A (or A^T), `geom` = (streams, slices, chunk) from ``cabi.suggest_stream``.
         `kind`: which weights ride in the plan -- "sum": value (A) / value[csr2csc] (A^T); "mean" (A^T only): the mean
-        backward's value[csr2csc] / max(deg, 1).  The structure is built once per graph and geometry; the weights are
+        backward's value[csr2csc] / max(deg, 1); "minmax" (A only): value, on a plan of the max / min kernel's geometry
+        with the permutation appended (geom = (4, slices, chunk) from ``cabi.suggest_stream_minmax``).  The structure is built once per graph and geometry; the weights are
         re-gathered through the plan's permutation whenever `value` was replaced or written in place."""
         from .plan import build_stream_plan
-        key = (bool(transposed),) + tuple(int(v) for v in geom)
-        plan = self._streams.get(key)
-        if plan is None:
+        minmax = kind == "minmax"       # (A only) the max / min kernel's own geometry; None when rows are not column-sorted
+        key = (bool(transposed),) + tuple(int(v) for v in geom) + (("minmax",) if minmax else ())
+        plan = self._streams.get(key, False)
+        if plan is False:
             if transposed:
                 plan = build_stream_plan(self.colptr(), self.row_t(), None, self._sparse_sizes[0], geom[1], None, None, geom[0], geom[2])
             else:
-                plan = build_stream_plan(self._rowptr, self._col, None, self._sparse_sizes[1], geom[1], None, None, geom[0], geom[2])
+                plan = build_stream_plan(self._rowptr, self._col, None, self._sparse_sizes[1], geom[1], None, None, geom[0], geom[2],
+                                         minmax=minmax)
             self._streams[key] = plan
             if plan is not None:
                 plan.meta = torch.tensor([plan.rows, plan.cols, plan.slices, plan.gens, plan.waves_per_gen, plan.rows_per_wave,
@@ -162,7 +165,7 @@ class SparseStorage:
             return None
         vals = torch.empty(0, dtype=torch.float32, device=plan.words.device)
         if self._value is not None or (transposed and kind == "mean"):
-            vkey = key + (kind,)
+            vkey = key + ("sum" if minmax else kind,)
             state = self._value_state()
             hit = self._stream_vals.get(vkey)
             if hit is None or hit[0] != state:
@@ -176,7 +179,12 @@ class SparseStorage:
                 self._stream_vals[vkey] = (state, vals)
             else:
                 vals = hit[1]
-        return [plan.words, vals, plan.wave_step_off, plan.wave_row, plan.wave_part, plan.hub_row, plan.hub_off, plan.meta]
+        ops = [plan.words, vals, plan.wave_step_off, plan.wave_row, plan.wave_part, plan.hub_row, plan.hub_off, plan.meta]
+        if minmax:                      # the winners' word indices become CSR positions through the permutation
+            if plan.perm.dtype != torch.int32:
+                return None
+            ops.append(plan.perm)
+        return ops
 
     def gcn_dinv(self) -> torch.Tensor:
         """(deg + 1)^-1/2 per row: the D^-1/2 of GCN's normalisation with self loops, unit weights."""

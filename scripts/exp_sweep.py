@@ -74,6 +74,29 @@ for sg in filter(None, sgeoms.split(",")):
           f"{t:.3f} ms  {nnz / t / 1e6:.2f} Gedges/s  maxdiff vs tasks {err:.2e}", flush=True)
     del plan, ws
 
+# max / min on the stream form: MMSTREAMS=slices:chunk,...
+if red in ("max", "min"):
+    ref_arg = arg.clone() if ref is not None else None
+    for sg in filter(None, os.environ.get("MMSTREAMS", "16:0,32:0").split(",")):
+        S, chunk = (int(v) for v in sg.split(":"))
+        streams, rpw, wpg = cabi.stream_minmax_geometry()
+        wpg = int(os.environ.get("WPG", wpg))
+        if chunk <= 0:                                     # the rule of isplib_suggest_stream
+            gens_est = -(-n // (rpw * wpg))
+            chunk = max(256, int(nnz / (gens_est * wpg * streams) / 3.4))
+        torch.cuda.synchronize()
+        plan = build_stream_plan(rowptr, col, None, n, S, wpg, rpw, streams, chunk, minmax=True)
+        ws = plan.workspace(minmax=True)
+        cabi.fusedMM_csr_stream_minmax_hip(msg, rowptr, nnz, plan, x, out, arg, ws)
+        torch.cuda.synchronize()
+        same = bool(torch.equal(out, ref) and torch.equal(arg, ref_arg)) if ref is not None else None
+        t = timeit(lambda: cabi.fusedMM_csr_stream_minmax_hip(msg, rowptr, nnz, plan, x, out, arg, ws))
+        t0 = timeit(lambda: cabi.fusedMM_csr_stream_minmax_hip(msg, rowptr, nnz, plan, x, out, None, ws))
+        print(f"stream {red} S={S:3d} rows/wave={rpw:2d} chunk={chunk} gens={plan.gens} waves/gen={wpg} steps={plan.n_steps} "
+              f"(padding {plan.n_steps * streams / nnz - 1:.3%}) hub parts={plan.n_parts}: {t:.3f} ms ({t0:.3f} without arg)  "
+              f"{nnz / t / 1e6:.2f} Gedges/s  identical to tasks: {same}", flush=True)
+        del plan, ws
+
 
 geoms = os.environ.get("GEOMS")
 if geoms == "none":

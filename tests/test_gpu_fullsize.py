@@ -256,6 +256,33 @@ def test_config3_reddit_k64_default_plan_and_torch_arbiter(gpu, reddit, reddit_s
             assert np.array_equal(got.cpu().numpy(), third), f"{name} vs torch.sparse.mm amin"
 
 
+@pytest.mark.parametrize("red", ("max", "min"))
+def test_config3_reddit_k64_minmax_on_the_stream_schedule(gpu, reddit, oracle_mod, red):
+    """max / min, K=64, weighted, on the default schedule of round 2 for column-sorted graphs (the stream schedule's
+    max / min kernel with the plan of isplib_suggest_stream_minmax, both plan builders): values and arg bit for bit
+    against the oracle and against torch.sparse.mm's amax / amin on the CPU; integer X makes ties the rule."""
+    from isplib_amd import cabi, synth
+    from isplib_amd.plan import build_stream_plan
+    rowptr, col, n, _ = reddit
+    k = 64
+    geom = cabi.suggest_stream_minmax(n, n, col.numel(), k)
+    assert geom is not None
+    x = synth.features(n, k, device=gpu, integer=True)
+    w = synth.edge_weights(col.numel(), device=gpu)
+    plan = build_stream_plan(rowptr, col, w, n, geom[0], None, None, 4, geom[1], minmax=True)
+    assert plan is not None
+    out, arg = cabi.spmm_stream_minmax(rowptr, col.numel(), plan, x, red)
+    nat = cabi.NativeStreamPlan(rowptr, col, w, n, 0, geom[0], geom[1], minmax=True)
+    out2, arg2 = cabi.spmm_stream_minmax(rowptr, col.numel(), nat, x, red)
+    nat.close()
+    assert torch.equal(out, out2) and torch.equal(arg, arg2), "the two plan builders must agree"
+    rp, cl, ww, xx = _host(rowptr, col, w, x)
+    ref, ref_arg = oracle_mod.spmm_fw(rp, cl, ww, xx, red)
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), ref.view(np.uint32)), "values must be bit-exact"
+    assert np.array_equal(arg.cpu().numpy(), ref_arg), "arg indices must be bit-exact"
+    assert np.array_equal(out.cpu().numpy(), _torch_cpu_spmm(rp, cl, ww, xx, red)), "vs torch.sparse.mm"
+
+
 def test_config2_sum_k128_stream_sweep_and_torch_arbiter(gpu, reddit, reddit_sweep, reddit_stream, oracle_mod):
     """The headline workload through the stream schedule (bench.py's default) and the sweep schedule: bitwise
     reproducible, within the bound of the oracle, and within twice the bound of torch.sparse.mm on the CPU (two fp32

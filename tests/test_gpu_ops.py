@@ -736,6 +736,41 @@ def test_backward_sees_edge_weights_updated_in_place(gpu, oracle_mod):
             value.copy_(_t(val1, gpu))              # what optimizer.step() does to a trainable weight vector
 
 
+@pytest.mark.parametrize("geom", ("3:64", "1:2048", "7:300"))
+def test_plugin_runs_max_and_min_on_the_stream_schedule(gpu, oracle_mod, monkeypatch, geom):
+    """The plug-in's default for max / min on large graphs with column-sorted rows, forced onto a small one
+    (ISPLIB_STREAM_MINMAX_GEOM): values and arg bit for bit (integer operands: ties everywhere, a hub row cut into virtual
+    rows), the backward scatter through the returned arg, weights replaced in place picked up by the plan; an unsorted
+    graph quietly stays on the task list."""
+    import isplib_amd
+    monkeypatch.setenv("ISPLIB_STREAM_MINMAX_GEOM", geom)
+    rowptr, col = cases.random_csr(150, 110, 30.0, seed=43, empty_rows=(5,), hub=(9, 900), duplicates=True)
+    x, g = cases.dense(110, 40, 3, "integer"), cases.dense(150, 40, 5)
+    val0, val1 = cases.weights(col.size, 4, "signed_int"), cases.weights(col.size, 98, "signed_int")
+    for weighted in (True, False):
+        value = _t(val0, gpu) if weighted else None
+        adj = isplib_amd.SparseTensor.from_csr(_t(rowptr, gpu), _t(col, gpu), value, (150, 110))
+        for cur in ((val0, val1) if weighted else (np.ones(col.size, np.float32),)):
+            for red in ("max", "min"):
+                xs = _t(x, gpu).requires_grad_(True)
+                out = isplib_amd.matmul(adj, xs, red)
+                out.backward(_t(g, gpu))
+                ref, ref_arg = oracle_mod.spmm_fw(rowptr, col, cur, x, red)
+                assert np.array_equal(out.detach().cpu().numpy().view(np.uint32), ref.view(np.uint32)), (red, weighted)
+                _, gm = oracle_mod.spmm_minmax_bw(col, cur, x, ref_arg, g)
+                _close(xs.grad, gm, rtol=1e-5, atol=1e-5)
+            if weighted:
+                value.copy_(_t(val1, gpu))
+        assert any(k[-1] == "minmax" and adj.storage._streams[k] is not None for k in adj.storage._streams), "the max / min stream plan was not used"
+    # rows that are not column-sorted: the plan builder declines, the call runs on the task list / plain kernel
+    rowptr, col = cases.random_csr(150, 110, 30.0, seed=44, sort_cols=False)
+    adj = isplib_amd.SparseTensor.from_csr(_t(rowptr, gpu), _t(col, gpu), None, (150, 110), validate=False)
+    out = isplib_amd.matmul(adj, _t(x, gpu), "max")
+    ref, _ = oracle_mod.spmm_fw(rowptr, col, np.ones(col.size, np.float32), x, "max")
+    assert np.array_equal(out.cpu().numpy(), ref)
+    assert all(adj.storage._streams[k] is None for k in adj.storage._streams if k[-1] == "minmax")
+
+
 @pytest.mark.parametrize("geom", ("4:3:64", "8:2:100000", "2:5:300"))
 def test_plugin_runs_sum_and_mean_on_the_stream_schedule(gpu, oracle_mod, monkeypatch, geom):
     """The plug-in's default for sum / mean on large graphs, forced onto a small one (ISPLIB_STREAM_GEOM): forward through

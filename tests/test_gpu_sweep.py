@@ -283,3 +283,83 @@ def test_native_stream_plan_equals_the_torch_built_one(gpu, oracle_mod, geom):
         _check(oracle_mod, rowptr, col, np.ones_like(val), x, "sum", cabi.spmm_stream(d_rowptr, col.size, nat, d_x, "sum"), None)
     finally:
         nat.close()
+
+
+# ---- max / min on the stream schedule (fusedMM_csr_stream_minmax_hip): (value, CSR position) pairs --------------------
+
+def _stream_minmax_all(gpu, oracle, rowptr, col, val, x, unit=False, geoms=((8, 16, 64), (5, 6, 2048), (3, 3, 300)), native=False):
+    """geoms: (slices, waves_per_gen, chunk); streams and rows per wave are the kernel's (isplib_spmm_stream_minmax_geometry)"""
+    from isplib_amd import cabi
+    from isplib_amd.plan import build_stream_plan
+    d_rowptr, d_col, d_x = _t(rowptr, gpu), _t(col, gpu), _t(x, gpu)
+    d_val = None if unit else _t(val, gpu)
+    for (s, wpg, chunk) in geoms:
+        if native:
+            plan = cabi.NativeStreamPlan(d_rowptr, d_col, d_val, x.shape[0], 0, s, chunk, wpg, minmax=True)
+        else:
+            plan = build_stream_plan(d_rowptr, d_col, d_val, x.shape[0], s, wpg, None, 4, chunk, minmax=True)
+        assert plan.streams == cabi.stream_minmax_geometry()[0] and plan.rows_per_wave == cabi.stream_minmax_geometry()[1]
+        for red in ("max", "min"):
+            out, arg = cabi.spmm_stream_minmax(d_rowptr, col.size, plan, d_x, red)
+            torch.cuda.synchronize()
+            _check(oracle, rowptr, col, val, x, red, out, arg)
+            out2, none = cabi.spmm_stream_minmax(d_rowptr, col.size, plan, d_x, red, want_arg=False)
+            assert none is None and torch.equal(out.view(torch.int32), out2.view(torch.int32))
+        if native:
+            plan.close()
+
+
+@pytest.mark.parametrize("k", (4, 5, 16, 41, 64, 67, 100, 128, 256, 602))
+def test_stream_minmax_widths_weighted(gpu, oracle_mod, k):
+    rowptr, col = cases.random_csr(300, 257, 9.0, seed=10 + k, empty_rows=(0, 150, 299))
+    val = cases.weights(col.size, 4)
+    x = cases.dense(257, k, 3)
+    _stream_minmax_all(gpu, oracle_mod, rowptr, col, val, x)
+
+
+@pytest.mark.parametrize("kind", ("integer", "constant", "signed_zero", "nonfinite", "denormal"))
+def test_stream_minmax_ties_and_nonfinite(gpu, oracle_mod, kind):
+    """Ties must go to the lowest CSR position: the stream meets a column-sorted row's edges slice by slice, which is
+    its CSR order, and only a strictly better candidate replaces the one held (duplicates=True: equal neighbours inside
+    rows; integer / constant operands: ties everywhere); NaN candidates never win, as in the oracle."""
+    rowptr, col = cases.random_csr(128, 96, 20.0, seed=5, empty_rows=(3,), duplicates=True)
+    val = cases.weights(col.size, 4, "signed_int" if kind != "constant" else "unit")
+    x = cases.dense(96, 64, 3, kind)
+    _stream_minmax_all(gpu, oracle_mod, rowptr, col, val, x, unit=(kind == "constant"))
+
+
+@pytest.mark.parametrize("k", (32, 41, 128))
+def test_stream_minmax_hub_row(gpu, oracle_mod, k):
+    """A row of 12,345 edges cut into virtual rows on different waves: partial (value, position) pairs, folded by
+    sweep_hub_fold_kernel; integer X makes every max / min a tie across chunks."""
+    rowptr, col = cases.random_csr(64, 400, 6.0, seed=9, empty_rows=(0, 63), hub=(17, 12345), duplicates=True)
+    val = cases.weights(col.size, 4, "signed_int")
+    x = cases.dense(400, k, 3, "integer")
+    _stream_minmax_all(gpu, oracle_mod, rowptr, col, val, x)
+    _stream_minmax_all(gpu, oracle_mod, rowptr, col, val, x, native=True, geoms=((8, 16, 64),))
+
+
+def test_stream_minmax_refuses_unsorted_rows(gpu):
+    """The tie rule needs rows whose columns ascend: both plan builders decline anything else (-> task list)."""
+    from isplib_amd import cabi
+    from isplib_amd.plan import build_stream_plan
+    rowptr, col = cases.random_csr(60, 50, 8.0, seed=3, sort_cols=False)
+    d_rowptr, d_col = _t(rowptr, gpu), _t(col, gpu)
+    assert build_stream_plan(d_rowptr, d_col, None, 50, 2, 4, None, 4, 64, minmax=True) is None
+    assert build_stream_plan(d_rowptr, d_col, None, 50, 2, 4, None, 4, 64) is not None          # sum / mean do not care
+    with pytest.raises(RuntimeError, match="column-sorted"):
+        cabi.NativeStreamPlan(d_rowptr, d_col, None, 50, 0, 2, 64, 4, minmax=True)
+
+
+def test_stream_minmax_status_codes(gpu):
+    from isplib_amd import cabi
+    from isplib_amd.plan import build_stream_plan
+    rowptr, col = cases.random_csr(40, 40, 5.0, seed=1)
+    d_rowptr, d_col = _t(rowptr, gpu), _t(col, gpu)
+    sum_plan = build_stream_plan(d_rowptr, d_col, None, 40, 2, 4, None, 4)
+    mm_plan = build_stream_plan(d_rowptr, d_col, None, 40, 2, 4, None, 4, minmax=True)
+    x, z = torch.zeros((40, 8), device=gpu), torch.zeros((40, 8), device=gpu)
+    assert cabi.fusedMM_csr_stream_minmax_hip(cabi.MSG_SPMM_SUM, d_rowptr, col.size, mm_plan, x, z, check=False) == 128   # max / min only
+    if sum_plan.rows_per_wave != mm_plan.rows_per_wave:                                                                    # a sum plan is not a max plan
+        assert cabi.fusedMM_csr_stream_minmax_hip(cabi.MSG_SPMM_MAX, d_rowptr, col.size, sum_plan, x, z, check=False) == 1
+    assert cabi.fusedMM_csr_stream_minmax_hip(cabi.MSG_SPMM_MAX, d_rowptr, col.size, mm_plan, x, z, check=False) == 0
