@@ -868,7 +868,9 @@ extern "C" int isplib_suggest_stream_minmax(int64_t m, int64_t n, int64_t nnz, i
    // row costs this kernel a read-compare-write of two LDS planes, and more slices mean more changes) and rows cut at
    // ~0.6 of a stream's share (chunk 2048: 1.82 ms, 1028: 1.92, 4096: 1.96); task list: 2.04 ms
    clear_error();
-   if (m <= 0 || n <= 0 || nnz <= 0 || k < 4 || n >= (1LL << 24) || nnz < (1LL << 22) || nnz >= (1LL << 31)) return 0;
+   // ... where rows are wider than 32 columns: the kernel has 16-lane slots only, and a K=32 call leaves half of every
+   // gather's lanes idle (1.65 ms against 1.20 ms on the task list; K=41: 1.80 against 2.05, K=128: 3.58 against 3.98)
+   if (m <= 0 || n <= 0 || nnz <= 0 || k <= 32 || n >= (1LL << 24) || nnz < (1LL << 22) || nnz >= (1LL << 31)) return 0;
    int st = 0, rpw = 0, resident = 0;
    if (isplib_spmm_stream_minmax_geometry(&st, &rpw, &resident) != ISPLIB_SUCCESS || rpw <= 0 || resident <= 0) return 0;
    return suggest_stream_geom(m, n, nnz, st, rpw, resident, 5.0e6, 1.7, slices, chunk);

@@ -540,14 +540,16 @@ def test_graph_handle_runs_the_fast_path_for_torch_free_hosts(gpu, oracle_mod):
         cabi.GraphHandle(_t(rowptr, gpu), _t(col, gpu), None, 2 ** 31 + 5)
 
 
-def test_graph_handle_takes_new_weights_without_rebuilding(gpu, oracle_mod):
+@pytest.mark.parametrize("k", (32, 48))
+def test_graph_handle_takes_new_weights_without_rebuilding(gpu, oracle_mod, k):
     """isplib_graph_set_values on a graph large enough for the stream schedule (sum / mean forward and both backwards go
-    through stream plans that own a copy of the weights): another array, the same array edited in place, no weights at
-    all -- every call after it must see the new weights, forward and backward, with the plans kept."""
+    through stream plans that own a copy of the weights; at k = 48 so does max): another array, the same array edited in
+    place, no weights at all -- every call after it must see the new weights, forward and backward, with the plans kept."""
     from isplib_amd import cabi
-    n, k = 20000, 32
+    n = 20000
     rowptr, col = cases.random_csr(n, n, 230.0, seed=41, empty_rows=(7,), hub=(3, 15000))
     assert col.size >= (1 << 22) and cabi.suggest_stream(n, n, col.size, k) is not None
+    assert (cabi.suggest_stream_minmax(n, n, col.size, k) is not None) == (k > 32)     # k = 48: max rides a stream plan too
     x, g = cases.dense(n, k, 3), cases.dense(n, k, 5)
     w1, w2 = cases.weights(col.size, 4), cases.weights(col.size, 9)
     d_w = _t(w1, gpu)
