@@ -137,7 +137,7 @@ def extra_configs(dev, rowptr, col, n, with_cpu_epoch=True):
         msg = cabi.MESSAGE[red]
         geom = cabi.suggest_stream(n, n, nnz, k) if red in ("sum", "mean") else None
         geom_mm = cabi.suggest_stream_minmax(n, n, nnz, k) if red in ("max", "min") else None
-        mplan = None if geom_mm is None else build_stream_plan(rowptr, col, val, n, geom_mm[0], None, None, 4, geom_mm[1], minmax=True)
+        mplan = None if geom_mm is None else build_stream_plan(rowptr, col, val, n, geom_mm[1], None, None, geom_mm[0], geom_mm[2], minmax=True)
         if mplan is not None:
             ws = mplan.workspace(minmax=True)
             ms = _time_launches(lambda: cabi.fusedMM_csr_stream_minmax_hip(msg, rowptr, nnz, mplan, x, z, arg, ws))

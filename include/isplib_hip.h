@@ -383,14 +383,14 @@ int    isplib_suggest_stream(int64_t m, int64_t n, int64_t nnz, int64_t k, int *
  * that stays among equals is the one at the lowest CSR position, the reference's tie rule (csrc/fusedmm.cpp:170-178 +
  * SURVEY.md row K3).  No position travels with the gathers: only the M x K winners are translated to CSR positions,
  * through the plan's `perm` (required), when a row is written out; hub rows cut into virtual rows carry (value, CSR
- * position) pairs into their fold.  One geometry: 64-column slots (streams = 4) with half the rows per wave of the sum
- * kernel, so max / min plans are built for isplib_spmm_stream_minmax_geometry -- isplib_stream_plan_build_minmax_hip
+ * position) pairs into their fold.  Slots of 64 columns (streams = 4) or, for k <= 32, of 32 columns (streams = 8), with
+ * half the rows per wave of the sum kernel, so max / min plans are built for isplib_spmm_stream_minmax_geometry -- isplib_stream_plan_build_minmax_hip
  * does that and returns ISPLIB_FAIL for a graph with an unsorted row (use the task list) -- and are not interchangeable
  * with sum plans.  nnz < 2^31.  z_arg (may be NULL): [m][ldz] int64 CSR positions, nnz = empty row. */
-int    isplib_spmm_stream_minmax_geometry(int *streams /*out*/, int *rows_per_wave /*out*/, int *waves_resident /*out*/);
-int    isplib_suggest_stream_minmax(int64_t m, int64_t n, int64_t nnz, int64_t k, int *slices, int *chunk);
+int    isplib_spmm_stream_minmax_geometry(int streams /* 4 | 8 */, int *rows_per_wave /*out*/, int *waves_resident /*out*/);
+int    isplib_suggest_stream_minmax(int64_t m, int64_t n, int64_t nnz, int64_t k, int *streams, int *slices, int *chunk);
 int    isplib_stream_plan_build_minmax_hip(int64_t m, int64_t n, int64_t nnz, const int64_t *rowptr, const int64_t *col,
-                                           const float *val, int slices, int chunk, int waves_per_gen,
+                                           const float *val, int streams, int slices, int chunk, int waves_per_gen,
                                            isplib_stream_plan *out /*host*/, void *stream);
 size_t isplib_spmm_stream_minmax_workspace_bytes(const isplib_stream_plan *plan);
 int    fusedMM_csr_stream_minmax_hip(int32_t imessage /* ISPLIB_MSG_SPMM_MAX | _MIN */, int64_t m, int64_t n, int64_t k,

@@ -179,12 +179,12 @@ def lib() -> ctypes.CDLL:
         L.isplib_stream_plan_build_hip.argtypes = [_i64, _i64, _i64, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                    ctypes.POINTER(StreamPlanStruct), _vp]
         L.isplib_stream_plan_build_minmax_hip.restype = ctypes.c_int
-        L.isplib_stream_plan_build_minmax_hip.argtypes = [_i64, _i64, _i64, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+        L.isplib_stream_plan_build_minmax_hip.argtypes = [_i64, _i64, _i64, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                           ctypes.POINTER(StreamPlanStruct), _vp]
         L.isplib_spmm_stream_minmax_geometry.restype = ctypes.c_int
-        L.isplib_spmm_stream_minmax_geometry.argtypes = [ctypes.POINTER(ctypes.c_int)] * 3
+        L.isplib_spmm_stream_minmax_geometry.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
         L.isplib_suggest_stream_minmax.restype = ctypes.c_int
-        L.isplib_suggest_stream_minmax.argtypes = [_i64, _i64, _i64, _i64, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+        L.isplib_suggest_stream_minmax.argtypes = [_i64, _i64, _i64, _i64, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
         L.isplib_spmm_stream_minmax_workspace_bytes.restype = ctypes.c_size_t
         L.isplib_spmm_stream_minmax_workspace_bytes.argtypes = [ctypes.POINTER(StreamPlanStruct)]
         L.fusedMM_csr_stream_minmax_hip.restype = ctypes.c_int
@@ -652,18 +652,18 @@ def spmm_stream_minmax(rowptr, nnz: int, plan, y, reduce: str = "max", workspace
 
 
 def suggest_stream_minmax(m: int, n: int, nnz: int, k: int):
-    """(slices, chunk) when the stream schedule is expected to win for max / min on this shape, else None."""
-    sl, ch = ctypes.c_int(0), ctypes.c_int(0)
-    if not lib().isplib_suggest_stream_minmax(int(m), int(n), int(nnz), int(k), ctypes.byref(sl), ctypes.byref(ch)):
+    """(streams, slices, chunk) when the stream schedule is expected to win for max / min on this shape, else None."""
+    st, sl, ch = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    if not lib().isplib_suggest_stream_minmax(int(m), int(n), int(nnz), int(k), ctypes.byref(st), ctypes.byref(sl), ctypes.byref(ch)):
         return None
-    return sl.value, ch.value
+    return st.value, sl.value, ch.value
 
 
-def stream_minmax_geometry():
-    """(streams, rows per wave, resident waves) of the max / min stream kernel (isplib_spmm_stream_minmax_geometry)."""
-    st, rpw, res = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
-    _check(lib().isplib_spmm_stream_minmax_geometry(ctypes.byref(st), ctypes.byref(rpw), ctypes.byref(res)), "isplib_spmm_stream_minmax_geometry")
-    return st.value, rpw.value, res.value
+def stream_minmax_geometry(streams: int = 4):
+    """(rows per wave, resident waves) of the max / min stream kernel for `streams` = 4 (64-column slots) or 8 (32-column)."""
+    rpw, res = ctypes.c_int(0), ctypes.c_int(0)
+    _check(lib().isplib_spmm_stream_minmax_geometry(int(streams), ctypes.byref(rpw), ctypes.byref(res)), "isplib_spmm_stream_minmax_geometry")
+    return rpw.value, res.value
 
 
 def suggest_stream(m: int, n: int, nnz: int, k: int):
@@ -693,7 +693,7 @@ class NativeStreamPlan:
         with torch.cuda.device(col.device):
             if minmax:
                 _check(lib().isplib_stream_plan_build_minmax_hip(m, int(ncols), col.numel(), _ptr(rowptr), _ptr(col), _ptr(val),
-                                                                 int(slices), int(chunk), int(waves_per_gen), ctypes.byref(self._s),
+                                                                 int(streams), int(slices), int(chunk), int(waves_per_gen), ctypes.byref(self._s),
                                                                  _stream(col.device)), "isplib_stream_plan_build_minmax_hip")
             else:
                 _check(lib().isplib_stream_plan_build_hip(m, int(ncols), col.numel(), _ptr(rowptr), _ptr(col), _ptr(val), int(streams),

@@ -326,14 +326,14 @@ static int run_side(isplib_graph *g, Side &s, const float *val, int32_t imessage
       }
    }
    // max / min on such graphs: the stream schedule's own kernel and plan geometry, for column-sorted rows
-   int mm_slices = 0, mm_chunk = 0;
+   int mm_streams = 0, mm_slices = 0, mm_chunk = 0;
    if (minmax && g->forced_slices < 0 && !s.minmax_stream_refused && ldy < (1LL << 22) &&
-       isplib_suggest_stream_minmax(s.m, s.n, s.nnz, k, &mm_slices, &mm_chunk)) {
-      const uint64_t key = (1ULL << 63) | ((uint64_t)mm_slices << 32) | (uint64_t)(uint32_t)mm_chunk;
+       isplib_suggest_stream_minmax(s.m, s.n, s.nnz, k, &mm_streams, &mm_slices, &mm_chunk)) {
+      const uint64_t key = (1ULL << 63) | ((uint64_t)mm_streams << 48) | ((uint64_t)mm_slices << 32) | (uint64_t)(uint32_t)mm_chunk;
       auto it = s.streams.find(key);
       if (it == s.streams.end()) {
          Side::Stream fresh;
-         const int rc = isplib_stream_plan_build_minmax_hip(s.m, s.n, s.nnz, s.rowptr, s.col, val, mm_slices, mm_chunk, 0, &fresh.plan, st);
+         const int rc = isplib_stream_plan_build_minmax_hip(s.m, s.n, s.nnz, s.rowptr, s.col, val, mm_streams, mm_slices, mm_chunk, 0, &fresh.plan, st);
          if (rc == ISPLIB_SUCCESS) {
             fresh.vals_of = val; fresh.has_vals = val != nullptr; fresh.gen = g->val_gen;
             it = s.streams.emplace(key, fresh).first;

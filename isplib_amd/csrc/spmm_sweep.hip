@@ -34,7 +34,8 @@
 #ifndef ISPLIB_STREAM_WGS4
 #define ISPLIB_STREAM_WGS4 2
 #endif
-// the same for max / min (64-column slots; a second LDS plane holds the winners' positions: half the rows per wave)
+// the same for max / min (a second LDS plane holds the winners' positions: half the rows per wave of the sum kernel);
+// 64-column slots, and 32-column slots (k <= 32: eight rows per gather, 32 gathers in flight from four batch registers)
 #ifndef ISPLIB_STREAM_MM_NV
 #define ISPLIB_STREAM_MM_NV 32
 #endif
@@ -43,6 +44,15 @@
 #endif
 #ifndef ISPLIB_STREAM_MM_WGS
 #define ISPLIB_STREAM_MM_WGS 2
+#endif
+#ifndef ISPLIB_STREAM_MM8_NV
+#define ISPLIB_STREAM_MM8_NV 64
+#endif
+#ifndef ISPLIB_STREAM_MM8_NBW
+#define ISPLIB_STREAM_MM8_NBW 4
+#endif
+#ifndef ISPLIB_STREAM_MM8_WGS
+#define ISPLIB_STREAM_MM8_WGS 2
 #endif
 
 namespace isplib {
@@ -464,9 +474,9 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, NVMAX, WGS>())) void s
 // this kernel).  No position travels with the gathers: the word index is arithmetic (batch, step, slot), and only the
 // M x K winners are translated to CSR positions, through the plan's `perm`, when a row is written out.  Padding words
 // (column n: the gather returns 0, which could beat negative values) are steered to a spare LDS row of the wave.
-template <int OP, bool HAS_VAL, int NVMAX, int NBW, int WGS>
-__global__ __launch_bounds__(256, (stream_wgs_per_cu<16, 2 * (NVMAX + 1), WGS>())) void spmm_stream_minmax_kernel(const SweepArgs a) {
-   constexpr int LPR = 16, WAVES = 4, G = 64 / LPR, PANEL = LPR * 4, U = 64 * NBW / G;
+template <int OP, int LPR, bool HAS_VAL, int NVMAX, int NBW, int WGS>
+__global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, 2 * (NVMAX + 1), WGS>())) void spmm_stream_minmax_kernel(const SweepArgs a) {
+   constexpr int WAVES = 4, G = 64 / LPR, PANEL = LPR * 4, U = 64 * NBW / G;
    constexpr int PER = NVMAX / G;
    constexpr int WAVE_FLOATS = (NVMAX + 1) * PANEL;       // + the spare row of the padding words
    __shared__ __attribute__((aligned(16))) float s_all[2 * WAVES * WAVE_FLOATS];
@@ -495,20 +505,23 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<16, 2 * (NVMAX + 1), WGS>()
    const float *vp = HAS_VAL ? a.vals + s0 * G : nullptr;
    const unsigned ldyb = (unsigned)a.ldy * 4u;
    const unsigned pad_word = ((unsigned)((lane % G) * PER) << 24) | a.null_word;
-   auto load_batch = [&](int64_t first, unsigned (&word)[NBW], float (&val)[NBW]) {
+   auto load_words = [&](int64_t first, unsigned (&word)[NBW]) {
 #pragma unroll
       for (int q = 0; q < NBW; q++) {
          const int64_t i = first + q * 64 + lane;
-         word[q] = pad_word;
-         val[q] = 0.0f;
-         if (i < nwords) {
-            word[q] = (unsigned)wp[i];
-            if (HAS_VAL) val[q] = vp[i];
-         }
+         word[q] = i < nwords ? (unsigned)wp[i] : pad_word;
+      }
+   };
+   auto load_vals = [&](int64_t first, float (&val)[NBW]) {
+#pragma unroll
+      for (int q = 0; q < NBW; q++) {
+         const int64_t i = first + q * 64 + lane;
+         val[q] = HAS_VAL && i < nwords ? vp[i] : 0.0f;
       }
    };
    unsigned w1[NBW], w2[NBW];
-   float v0[NBW], v1[NBW], v2[NBW];                      // the weights of the batch being consumed, of the next, of the one after
+   float v0[NBW], v1[NBW];                               // the weights of the batch being consumed and of the next: a weight is
+                                                         // needed one batch later than its word, so it is loaded one batch later
    v4i_t t[U];
    unsigned la[U];
    // (a weight is fetched from its batch register when its gather is consumed, one step ahead -- a ring of U weights
@@ -520,11 +533,13 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<16, 2 * (NVMAX + 1), WGS>()
       la[u] = colw == a.null_word ? (unsigned)(NVMAX * PANEL) : (word >> 24) * (unsigned)PANEL;     // padding: the spare row
       t[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)o, 0, 0);
    };
-   load_batch(0, w1, v0);
+   load_words(0, w1);
+   load_vals(0, v0);
 #pragma unroll
    for (int u = 0; u < U; u++) issue(u, w1);
-   load_batch(64 * NBW, w1, v1);
-   load_batch(128 * NBW, w2, v2);
+   load_words(64 * NBW, w1);
+   load_vals(64 * NBW, v1);
+   load_words(128 * NBW, w2);
    unsigned cur = (unsigned)(g * PER * PANEL);
    float acc[4];
    int bi[4];
@@ -570,8 +585,9 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<16, 2 * (NVMAX + 1), WGS>()
          issue(u, w1);
       }
 #pragma unroll
-      for (int q = 0; q < NBW; q++) { w1[q] = w2[q]; v0[q] = v1[q]; v1[q] = v2[q]; }
-      load_batch((b + 3) * 64 * NBW, w2, v2);
+      for (int q = 0; q < NBW; q++) { w1[q] = w2[q]; v0[q] = v1[q]; }
+      load_words((b + 3) * 64 * NBW, w2);
+      load_vals((b + 2) * 64 * NBW, v1);
    }
    flush();
    // write-out: the winners' word indices become CSR positions through the plan's permutation
@@ -640,7 +656,8 @@ static int sweep_resident_waves(bool add, int64_t pk, int nvmax, int cus) {
 // registers and workgroups per CU (measured on the Reddit shape, K = 128 in 64-column panels)
 struct StreamGeom { int nvmax, nbw, wgs; };
 static StreamGeom stream_geom(int streams, bool minmax = false) {
-   if (minmax) return {ISPLIB_STREAM_MM_NV, ISPLIB_STREAM_MM_NBW, ISPLIB_STREAM_MM_WGS};   // 64-column slots only
+   if (minmax) return streams == 8 ? StreamGeom{ISPLIB_STREAM_MM8_NV, ISPLIB_STREAM_MM8_NBW, ISPLIB_STREAM_MM8_WGS}
+                                   : StreamGeom{ISPLIB_STREAM_MM_NV, ISPLIB_STREAM_MM_NBW, ISPLIB_STREAM_MM_WGS};
    if (streams == 2) return {32, 1, 2};     // 128-column panels: U = 32 gathers of 1 KiB per wave
    if (streams == 4) return {ISPLIB_STREAM_NV4, ISPLIB_STREAM_NBW4, ISPLIB_STREAM_WGS4};
    return {64, 2, 3};                       // 32-column panels: U = 16
@@ -674,10 +691,11 @@ static int launch_stream(const SweepArgs &a_in, hipStream_t st) {
 }
 
 template <int OP, bool HAS_VAL>
-static int launch_stream_minmax(const SweepArgs &a, hipStream_t st) {
+static int launch_stream_minmax(const SweepArgs &a, hipStream_t st, int streams) {
    const unsigned blocks = (unsigned)((a.wave_count + 3) / 4);
    if (blocks == 0) return ISPLIB_SUCCESS;
-   hipLaunchKernelGGL((spmm_stream_minmax_kernel<OP, HAS_VAL, ISPLIB_STREAM_MM_NV, ISPLIB_STREAM_MM_NBW, ISPLIB_STREAM_MM_WGS>), dim3(blocks), dim3(256), 0, st, a);
+   if (streams == 8) hipLaunchKernelGGL((spmm_stream_minmax_kernel<OP, 8, HAS_VAL, ISPLIB_STREAM_MM8_NV, ISPLIB_STREAM_MM8_NBW, ISPLIB_STREAM_MM8_WGS>), dim3(blocks), dim3(256), 0, st, a);
+   else hipLaunchKernelGGL((spmm_stream_minmax_kernel<OP, 16, HAS_VAL, ISPLIB_STREAM_MM_NV, ISPLIB_STREAM_MM_NBW, ISPLIB_STREAM_MM_WGS>), dim3(blocks), dim3(256), 0, st, a);
    return check_launch("spmm_stream_minmax_kernel");
 }
 
@@ -819,11 +837,11 @@ extern "C" int isplib_spmm_stream_geometry(int streams, int *rows_per_wave, int 
    return ISPLIB_SUCCESS;
 }
 
-extern "C" int isplib_spmm_stream_minmax_geometry(int *streams, int *rows_per_wave, int *waves_resident) {
+extern "C" int isplib_spmm_stream_minmax_geometry(int streams, int *rows_per_wave, int *waves_resident) {
    clear_error();
-   if (streams) *streams = 4;
-   if (rows_per_wave) *rows_per_wave = stream_geom(4, true).nvmax;
-   if (waves_resident) *waves_resident = stream_resident_waves(4, device_cus(), true);
+   if (streams != 4 && streams != 8) return fail(ISPLIB_FAIL, "isplib_spmm_stream_minmax_geometry: streams must be 4 (64-column slots) or 8 (32-column slots)");
+   if (rows_per_wave) *rows_per_wave = stream_geom(streams, true).nvmax;
+   if (waves_resident) *waves_resident = stream_resident_waves(streams, device_cus(), true);
    return ISPLIB_SUCCESS;
 }
 
@@ -862,18 +880,20 @@ extern "C" int isplib_suggest_stream(int64_t m, int64_t n, int64_t nnz, int64_t 
    return 1;
 }
 
-extern "C" int isplib_suggest_stream_minmax(int64_t m, int64_t n, int64_t nnz, int64_t k, int *slices, int *chunk) {
-   // max / min: one geometry (64-column slots); the same reuse rule; rows must be column-sorted.  Measured on the Reddit
-   // shape (K = 64): slices of ~5 MB (8-12 slices: 1.82 ms; 16: 1.88; 31, the sum kernel's count: 2.2 -- every change of
-   // row costs this kernel a read-compare-write of two LDS planes, and more slices mean more changes) and rows cut at
-   // ~0.6 of a stream's share (chunk 2048: 1.82 ms, 1028: 1.92, 4096: 1.96); task list: 2.04 ms
+extern "C" int isplib_suggest_stream_minmax(int64_t m, int64_t n, int64_t nnz, int64_t k, int *streams, int *slices, int *chunk) {
+   // max / min: 32-column slots up to k = 32, 64-column slots above; the same reuse rule; rows must be column-sorted.
+   // Measured on the Reddit shape (K = 64): slices of ~5 MB (8-12 slices: 1.82 ms; 16: 1.88; 31, the sum kernel's count:
+   // 2.2 -- every change of row costs this kernel a read-compare-write of two LDS planes, and more slices mean more
+   // changes) and rows cut at ~0.6 of a stream's share (chunk 2048: 1.82 ms, 1028: 1.92, 4096: 1.96); task list: 2.04 ms
+   // (K=41: 1.80 against 2.05, K=128: 3.58 against 3.98)
    clear_error();
-   // ... where rows are wider than 32 columns: the kernel has 16-lane slots only, and a K=32 call leaves half of every
-   // gather's lanes idle (1.65 ms against 1.20 ms on the task list; K=41: 1.80 against 2.05, K=128: 3.58 against 3.98)
-   if (m <= 0 || n <= 0 || nnz <= 0 || k <= 32 || n >= (1LL << 24) || nnz < (1LL << 22) || nnz >= (1LL << 31)) return 0;
-   int st = 0, rpw = 0, resident = 0;
-   if (isplib_spmm_stream_minmax_geometry(&st, &rpw, &resident) != ISPLIB_SUCCESS || rpw <= 0 || resident <= 0) return 0;
-   return suggest_stream_geom(m, n, nnz, st, rpw, resident, 5.0e6, 1.7, slices, chunk);
+   if (m <= 0 || n <= 0 || nnz <= 0 || k < 4 || n >= (1LL << 24) || nnz < (1LL << 22) || nnz >= (1LL << 31)) return 0;
+   const int st = k <= 32 ? 8 : 4;
+   int rpw = 0, resident = 0;
+   if (isplib_spmm_stream_minmax_geometry(st, &rpw, &resident) != ISPLIB_SUCCESS || rpw <= 0 || resident <= 0) return 0;
+   if (!suggest_stream_geom(m, n, nnz, st, rpw, resident, 5.0e6, 1.7, slices, chunk)) return 0;
+   if (streams) *streams = st;
+   return 1;
 }
 
 extern "C" size_t isplib_spmm_stream_workspace_bytes(const isplib_stream_plan *plan) {
@@ -900,7 +920,7 @@ static int stream_run(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t
    if (n >= (1LL << 24) || ldy >= (1LL << 22)) return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: n must be < 2^24 and ldy < 2^22 (24-bit address arithmetic)");
    if (plan->streams != 2 && plan->streams != 4 && plan->streams != 8)
       return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: bad plan geometry (streams 2, 4 or 8)");
-   if (mm && plan->streams != 4) return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: max / min run on 4-stream plans (isplib_spmm_stream_minmax_geometry)");
+   if (mm && plan->streams != 4 && plan->streams != 8) return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: max / min run on 4- or 8-stream plans (isplib_spmm_stream_minmax_geometry)");
    if (plan->gens < 1 || plan->waves_per_gen < 1 || plan->rows_per_wave != stream_geom(plan->streams, mm).nvmax)
       return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: bad plan geometry (rows_per_wave must be what isplib_spmm_stream_geometry / _minmax_geometry reports)");
    if (mm && plan->n_steps > 0 && !plan->perm) return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: max / min need the plan's perm array (the winners' CSR positions)");
@@ -951,8 +971,8 @@ static int stream_run(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t
          p.wave_base = gen * plan->waves_per_gen;
          p.wave_count = plan->waves_per_gen;
          int rc;
-         if (imessage == ISPLIB_MSG_SPMM_MAX) rc = plan->vals ? launch_stream_minmax<OP_MAX, true>(p, st) : launch_stream_minmax<OP_MAX, false>(p, st);
-         else if (imessage == ISPLIB_MSG_SPMM_MIN) rc = plan->vals ? launch_stream_minmax<OP_MIN, true>(p, st) : launch_stream_minmax<OP_MIN, false>(p, st);
+         if (imessage == ISPLIB_MSG_SPMM_MAX) rc = plan->vals ? launch_stream_minmax<OP_MAX, true>(p, st, plan->streams) : launch_stream_minmax<OP_MAX, false>(p, st, plan->streams);
+         else if (imessage == ISPLIB_MSG_SPMM_MIN) rc = plan->vals ? launch_stream_minmax<OP_MIN, true>(p, st, plan->streams) : launch_stream_minmax<OP_MIN, false>(p, st, plan->streams);
          else if (plan->streams == 2) rc = plan->vals ? launch_stream<32, true>(p, st) : launch_stream<32, false>(p, st);
          else if (plan->streams == 4) rc = plan->vals ? launch_stream<16, true>(p, st) : launch_stream<16, false>(p, st);
          else rc = plan->vals ? launch_stream<8, true>(p, st) : launch_stream<8, false>(p, st);

@@ -421,11 +421,11 @@ __global__ __launch_bounds__(256) void sp_unsorted_kernel(int64_t m, int64_t nnz
 }
 
 extern "C" int isplib_stream_plan_build_minmax_hip(int64_t m, int64_t n, int64_t nnz, const int64_t *rowptr, const int64_t *col,
-                                                   const float *val, int slices, int chunk, int waves_per_gen,
+                                                   const float *val, int streams, int slices, int chunk, int waves_per_gen,
                                                    isplib_stream_plan *out, void *stream) {
    clear_error();
-   int streams = 0, rpw = 0, resident = 0;
-   if (isplib_spmm_stream_minmax_geometry(&streams, &rpw, &resident) != ISPLIB_SUCCESS) return ISPLIB_FAIL;
+   int rpw = 0, resident = 0;
+   if (isplib_spmm_stream_minmax_geometry(streams, &rpw, &resident) != ISPLIB_SUCCESS) return ISPLIB_FAIL;
    if (out) memset(out, 0, sizeof(*out));
    if (m <= 0 || nnz < 0 || !rowptr || (nnz > 0 && !col)) return fail(ISPLIB_FAIL, "isplib_stream_plan_build_minmax_hip: bad operand");
    // the kernel's tie rule (first strictly better candidate in stream order = lowest CSR position) holds for rows whose

@@ -362,7 +362,7 @@ def build_stream_plan(rowptr: torch.Tensor, col: torch.Tensor, val: Optional[tor
             starts[rowptr[:-1][rowptr[:-1] < col.numel()]] = True
             if bool(((col[1:] < col[:-1]) & ~starts[1:]).any()):
                 return None
-        streams, rpw, resident = cabi.stream_minmax_geometry()
+        rpw, resident = cabi.stream_minmax_geometry(streams)
     else:
         rpw, resident = cabi.stream_geometry(streams)
     rows_per_wave = rpw if rows_per_wave is None else rows_per_wave

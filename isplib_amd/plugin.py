@@ -195,19 +195,17 @@ def choose_stream(storage: SparseStorage, m: int, n: int, k: int):
 
 
 def choose_stream_minmax(storage: SparseStorage, m: int, n: int, k: int):
-    """(4, slices, chunk) when max / min of this shape should run on the stream schedule (column-sorted rows; the plan
-    builder has the last word), else None.  Same switches as choose_stream."""
+    """(streams, slices, chunk) when max / min of this shape should run on the stream schedule (column-sorted rows; the
+    plan builder has the last word), else None.  Same switches as choose_stream."""
     if os.environ.get("ISPLIB_STREAM", "1") == "0" or os.environ.get("ISPLIB_SLICES") is not None:
         return None
     if k < 4 or n >= (1 << 24) or storage._col.numel() >= (1 << 31):
         return None
-    forced = os.environ.get("ISPLIB_STREAM_MINMAX_GEOM")   # "slices:chunk": tests and experiments
+    forced = os.environ.get("ISPLIB_STREAM_MINMAX_GEOM")   # "streams:slices:chunk": tests and experiments
     if forced:
-        sl, ch = (int(v) for v in forced.split(":"))
-        return 4, sl, ch
+        return tuple(int(v) for v in forced.split(":"))
     from . import cabi
-    geom = cabi.suggest_stream_minmax(m, n, storage._col.numel(), k)
-    return None if geom is None else (4,) + tuple(geom)
+    return cabi.suggest_stream_minmax(m, n, storage._col.numel(), k)
 
 
 def spmm_autotuned(src, other: torch.Tensor, reduce: str = "sum") -> torch.Tensor:

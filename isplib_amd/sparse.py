@@ -145,7 +145,7 @@ class SparseStorage:
         hub_row, hub_off, meta_cpu] for A (or A^T), `geom` = (streams, slices, chunk) from ``cabi.suggest_stream``.
         `kind`: which weights ride in the plan -- "sum": value (A) / value[csr2csc] (A^T); "mean" (A^T only): the mean
         backward's value[csr2csc] / max(deg, 1); "minmax" (A only): value, on a plan of the max / min kernel's geometry
-        with the permutation appended (geom = (4, slices, chunk) from ``cabi.suggest_stream_minmax``).  The structure is built once per graph and geometry; the weights are
+        with the permutation appended (geom = (streams, slices, chunk) from ``cabi.suggest_stream_minmax``).  The structure is built once per graph and geometry; the weights are
         re-gathered through the plan's permutation whenever `value` was replaced or written in place."""
         from .plan import build_stream_plan
         minmax = kind == "minmax"       # (A only) the max / min kernel's own geometry; None when rows are not column-sorted

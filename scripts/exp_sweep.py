@@ -79,7 +79,8 @@ if red in ("max", "min"):
     ref_arg = arg.clone() if ref is not None else None
     for sg in filter(None, os.environ.get("MMSTREAMS", "16:0,32:0").split(",")):
         S, chunk = (int(v) for v in sg.split(":"))
-        streams, rpw, wpg = cabi.stream_minmax_geometry()
+        streams = 8 if k <= 32 else 4
+        rpw, wpg = cabi.stream_minmax_geometry(streams)
         wpg = int(os.environ.get("WPG", wpg))
         if chunk <= 0:                                     # the rule of isplib_suggest_stream
             gens_est = -(-n // (rpw * wpg))

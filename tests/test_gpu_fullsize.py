@@ -256,23 +256,23 @@ def test_config3_reddit_k64_default_plan_and_torch_arbiter(gpu, reddit, reddit_s
             assert np.array_equal(got.cpu().numpy(), third), f"{name} vs torch.sparse.mm amin"
 
 
-@pytest.mark.parametrize("red", ("max", "min"))
-def test_config3_reddit_k64_minmax_on_the_stream_schedule(gpu, reddit, oracle_mod, red):
-    """max / min, K=64, weighted, on the default schedule of round 2 for column-sorted graphs (the stream schedule's
-    max / min kernel with the plan of isplib_suggest_stream_minmax, both plan builders): values and arg bit for bit
-    against the oracle and against torch.sparse.mm's amax / amin on the CPU; integer X makes ties the rule."""
+@pytest.mark.parametrize("red,k", (("max", 64), ("min", 64), ("max", 32)))
+def test_config3_reddit_minmax_on_the_stream_schedule(gpu, reddit, oracle_mod, red, k):
+    """max / min, weighted, on the default schedule of round 2 for column-sorted graphs (the stream schedule's max / min
+    kernel with the plan of isplib_suggest_stream_minmax -- 64-column slots at K=64, 32-column slots at K=32 -- from both
+    plan builders): values and arg bit for bit against the oracle and against torch.sparse.mm's amax / amin on the CPU;
+    integer X makes ties the rule."""
     from isplib_amd import cabi, synth
     from isplib_amd.plan import build_stream_plan
     rowptr, col, n, _ = reddit
-    k = 64
     geom = cabi.suggest_stream_minmax(n, n, col.numel(), k)
-    assert geom is not None
+    assert geom is not None and geom[0] == (8 if k <= 32 else 4)
     x = synth.features(n, k, device=gpu, integer=True)
     w = synth.edge_weights(col.numel(), device=gpu)
-    plan = build_stream_plan(rowptr, col, w, n, geom[0], None, None, 4, geom[1], minmax=True)
+    plan = build_stream_plan(rowptr, col, w, n, geom[1], None, None, geom[0], geom[2], minmax=True)
     assert plan is not None
     out, arg = cabi.spmm_stream_minmax(rowptr, col.numel(), plan, x, red)
-    nat = cabi.NativeStreamPlan(rowptr, col, w, n, 0, geom[0], geom[1], minmax=True)
+    nat = cabi.NativeStreamPlan(rowptr, col, w, n, geom[0], geom[1], geom[2], minmax=True)
     out2, arg2 = cabi.spmm_stream_minmax(rowptr, col.numel(), nat, x, red)
     nat.close()
     assert torch.equal(out, out2) and torch.equal(arg, arg2), "the two plan builders must agree"

@@ -543,13 +543,13 @@ def test_graph_handle_runs_the_fast_path_for_torch_free_hosts(gpu, oracle_mod):
 @pytest.mark.parametrize("k", (32, 48))
 def test_graph_handle_takes_new_weights_without_rebuilding(gpu, oracle_mod, k):
     """isplib_graph_set_values on a graph large enough for the stream schedule (sum / mean forward and both backwards go
-    through stream plans that own a copy of the weights; at k = 48 so does max): another array, the same array edited in
+    through stream plans that own a copy of the weights, and so does max -- on 32-column slots at k = 32, 64-column ones at 48): another array, the same array edited in
     place, no weights at all -- every call after it must see the new weights, forward and backward, with the plans kept."""
     from isplib_amd import cabi
     n = 20000
     rowptr, col = cases.random_csr(n, n, 230.0, seed=41, empty_rows=(7,), hub=(3, 15000))
     assert col.size >= (1 << 22) and cabi.suggest_stream(n, n, col.size, k) is not None
-    assert (cabi.suggest_stream_minmax(n, n, col.size, k) is not None) == (k > 32)     # k = 48: max rides a stream plan too
+    assert cabi.suggest_stream_minmax(n, n, col.size, k)[0] == (8 if k <= 32 else 4)    # max rides a stream plan too
     x, g = cases.dense(n, k, 3), cases.dense(n, k, 5)
     w1, w2 = cases.weights(col.size, 4), cases.weights(col.size, 9)
     d_w = _t(w1, gpu)
@@ -738,7 +738,7 @@ def test_backward_sees_edge_weights_updated_in_place(gpu, oracle_mod):
             value.copy_(_t(val1, gpu))              # what optimizer.step() does to a trainable weight vector
 
 
-@pytest.mark.parametrize("geom", ("3:64", "1:2048", "7:300"))
+@pytest.mark.parametrize("geom", ("4:3:64", "4:1:2048", "8:7:300"))
 def test_plugin_runs_max_and_min_on_the_stream_schedule(gpu, oracle_mod, monkeypatch, geom):
     """The plug-in's default for max / min on large graphs with column-sorted rows, forced onto a small one
     (ISPLIB_STREAM_MINMAX_GEOM): values and arg bit for bit (integer operands: ties everywhere, a hub row cut into virtual

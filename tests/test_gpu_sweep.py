@@ -287,18 +287,19 @@ def test_native_stream_plan_equals_the_torch_built_one(gpu, oracle_mod, geom):
 
 # ---- max / min on the stream schedule (fusedMM_csr_stream_minmax_hip): (value, CSR position) pairs --------------------
 
-def _stream_minmax_all(gpu, oracle, rowptr, col, val, x, unit=False, geoms=((8, 16, 64), (5, 6, 2048), (3, 3, 300)), native=False):
-    """geoms: (slices, waves_per_gen, chunk); streams and rows per wave are the kernel's (isplib_spmm_stream_minmax_geometry)"""
+def _stream_minmax_all(gpu, oracle, rowptr, col, val, x, unit=False, geoms=((4, 8, 16, 64), (8, 5, 6, 2048), (4, 3, 3, 300), (8, 2, 4, 100)),
+                       native=False):
+    """geoms: (streams, slices, waves_per_gen, chunk); rows per wave are the kernel's (isplib_spmm_stream_minmax_geometry)"""
     from isplib_amd import cabi
     from isplib_amd.plan import build_stream_plan
     d_rowptr, d_col, d_x = _t(rowptr, gpu), _t(col, gpu), _t(x, gpu)
     d_val = None if unit else _t(val, gpu)
-    for (s, wpg, chunk) in geoms:
+    for (streams, s, wpg, chunk) in geoms:
         if native:
-            plan = cabi.NativeStreamPlan(d_rowptr, d_col, d_val, x.shape[0], 0, s, chunk, wpg, minmax=True)
+            plan = cabi.NativeStreamPlan(d_rowptr, d_col, d_val, x.shape[0], streams, s, chunk, wpg, minmax=True)
         else:
-            plan = build_stream_plan(d_rowptr, d_col, d_val, x.shape[0], s, wpg, None, 4, chunk, minmax=True)
-        assert plan.streams == cabi.stream_minmax_geometry()[0] and plan.rows_per_wave == cabi.stream_minmax_geometry()[1]
+            plan = build_stream_plan(d_rowptr, d_col, d_val, x.shape[0], s, wpg, None, streams, chunk, minmax=True)
+        assert plan.streams == streams and plan.rows_per_wave == cabi.stream_minmax_geometry(streams)[0]
         for red in ("max", "min"):
             out, arg = cabi.spmm_stream_minmax(d_rowptr, col.size, plan, d_x, red)
             torch.cuda.synchronize()
@@ -336,7 +337,7 @@ def test_stream_minmax_hub_row(gpu, oracle_mod, k):
     val = cases.weights(col.size, 4, "signed_int")
     x = cases.dense(400, k, 3, "integer")
     _stream_minmax_all(gpu, oracle_mod, rowptr, col, val, x)
-    _stream_minmax_all(gpu, oracle_mod, rowptr, col, val, x, native=True, geoms=((8, 16, 64),))
+    _stream_minmax_all(gpu, oracle_mod, rowptr, col, val, x, native=True, geoms=((4, 8, 16, 64), (8, 3, 5, 200)))
 
 
 def test_stream_minmax_refuses_unsorted_rows(gpu):
@@ -348,7 +349,7 @@ def test_stream_minmax_refuses_unsorted_rows(gpu):
     assert build_stream_plan(d_rowptr, d_col, None, 50, 2, 4, None, 4, 64, minmax=True) is None
     assert build_stream_plan(d_rowptr, d_col, None, 50, 2, 4, None, 4, 64) is not None          # sum / mean do not care
     with pytest.raises(RuntimeError, match="column-sorted"):
-        cabi.NativeStreamPlan(d_rowptr, d_col, None, 50, 0, 2, 64, 4, minmax=True)
+        cabi.NativeStreamPlan(d_rowptr, d_col, None, 50, 4, 2, 64, 4, minmax=True)
 
 
 def test_stream_minmax_status_codes(gpu):
