@@ -62,7 +62,7 @@ def main():
         np.add.at(ref64, row_ids, hv.astype(np.float64)[:, None] * x.astype(np.float64)[col])
         # round-2 schedules: rows resident in LDS.  sweep (all four reductions) and stream (sum / mean; the plan owns the
         # edges and the weights), the latter from either builder (torch / native) with random geometry
-        splan = wplan = None
+        splan = wplan = mplan = None
         native = False
         if k >= 4 and col.size:
             streams = int(rng.choice([2, 4, 8]))
@@ -72,6 +72,14 @@ def main():
                 splan = cabi.NativeStreamPlan(d_rowptr, d_col, d_val, n, streams, s_geom[0], s_geom[2], s_geom[1])
             else:
                 splan = build_stream_plan(d_rowptr, d_col, d_val, n, s_geom[0], s_geom[1], None, streams, s_geom[2])
+            mstreams = int(rng.choice([4, 8]))          # max / min kernel: its own geometry; None when a row is not column-sorted
+            if native:
+                try:
+                    mplan = cabi.NativeStreamPlan(d_rowptr, d_col, d_val, n, mstreams, s_geom[0], s_geom[2], s_geom[1], minmax=True)
+                except RuntimeError:
+                    mplan = None
+            else:
+                mplan = build_stream_plan(d_rowptr, d_col, d_val, n, s_geom[0], s_geom[1], None, mstreams, s_geom[2], minmax=True)
             if k % 4 == 0 and ld % 4 == 0:
                 wplan = build_sweep_plan(d_rowptr, d_col, n, s_geom[0], s_geom[1], int(rng.choice([8, 16])), s_geom[2], int(rng.choice([1, 8])))
         for red in cases.REDUCES:
@@ -89,6 +97,8 @@ def main():
                     cabi.fusedMM_csr_tasks_hip(cabi.MESSAGE[red], d_rowptr, d_col, d_val, plan, d_x, out, arg, plan.workspace(red, k))
                 elif name == "stream" and splan is not None and red in ("sum", "mean"):
                     cabi.fusedMM_csr_stream_hip(cabi.MESSAGE[red], d_rowptr, col.size, splan, d_x, out, splan.workspace())
+                elif name == "stream" and mplan is not None and red in ("max", "min"):
+                    cabi.fusedMM_csr_stream_minmax_hip(cabi.MESSAGE[red], d_rowptr, col.size, mplan, d_x, out, arg, mplan.workspace(minmax=True))
                 elif name == "sweep" and wplan is not None:
                     cabi.fusedMM_csr_sweep_hip(cabi.MESSAGE[red], d_rowptr, d_col, d_val, wplan, d_x, out, arg, wplan.workspace(red, k))
                 else:
@@ -112,6 +122,8 @@ def main():
                           + (f" streams={streams} stream geometry={s_geom} native={native}" if name in ("stream", "sweep") else ""), flush=True)
         if native and splan is not None:
             splan.close()
+        if native and mplan is not None:
+            mplan.close()
         # ---- the backward side on the same graph: transpose operands, dX of sum / mean, SDDMM dA, max/min scatter ----
         if a.backward and col.size:
             g = cases.dense(m, k, int(rng.integers(1 << 30)), "integer" if integer else "uniform")
