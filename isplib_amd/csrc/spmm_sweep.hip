@@ -365,38 +365,43 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, NVMAX, WGS>())) void s
    // lane i of batch register q holds word q*64 + i = (step (q*64 + i) / G, slot i % G); past the end of the wave: the
    // padding word of the slot (column n: the gather reads 0 through the range check; the row is one of the slot's own)
    const unsigned pad_word = ((unsigned)((lane % G) * PER) << 24) | a.null_word;
-   auto load_batch = [&](int64_t first, unsigned (&word)[NBW], float (&val)[NBW]) {
+   auto load_words = [&](int64_t first, unsigned (&word)[NBW]) {
 #pragma unroll
       for (int q = 0; q < NBW; q++) {
          const int64_t i = first + q * 64 + lane;
-         word[q] = pad_word;
-         val[q] = 0.0f;
-         if (i < nwords) {
-            word[q] = (unsigned)wp[i];
-            if (HAS_VAL) val[q] = vp[i];
-         }
+         word[q] = i < nwords ? (unsigned)wp[i] : pad_word;
+      }
+   };
+   auto load_vals = [&](int64_t first, float (&val)[NBW]) {
+#pragma unroll
+      for (int q = 0; q < NBW; q++) {
+         const int64_t i = first + q * 64 + lane;
+         val[q] = HAS_VAL && i < nwords ? vp[i] : 0.0f;
       }
    };
    unsigned w1[NBW], w2[NBW];                             // the words of the next batch and of the one after it
-   float v1[NBW], v2[NBW];
+   float v0[NBW], v1[NBW];                                // the weights of the batch being consumed and of the next: a weight is
+                                                          // needed one batch later than its word, so it is loaded one batch later
    v4i_t t[U];
    unsigned la[U];
-   float vv[U];
    // one ds_bpermute hands a slot its word of the step (the LDS pipe is otherwise idle; picking it with v_readlane +
    // v_cndmask cost 16 vector instructions per step); column * row pitch is a 24-bit multiply (n < 2^24, pitch < 2^24,
    // product < 2^32: checked by the entry)
-   auto issue = [&](int u, const unsigned (&word_l)[NBW], const float (&val_l)[NBW]) {
+   // (a weight is fetched from its batch register when its gather is consumed, one step ahead: a ring of U weights
+   // beside the U gathers in flight costs 30 registers)
+   auto issue = [&](int u, const unsigned (&word_l)[NBW]) {
       const unsigned word = (unsigned)__shfl((int)word_l[(u * G) / 64], (u * G) % 64 + g);
       const unsigned o = (__umul24(word & 0xFFFFFFu, ldyb) + cbyte) | poison;
       la[u] = (word >> 24) * (unsigned)PANEL;
-      if (HAS_VAL) vv[u] = __shfl(val_l[(u * G) / 64], (u * G) % 64 + g);
       t[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)o, 0, 0);
    };
-   load_batch(0, w1, v1);
+   load_words(0, w1);
+   load_vals(0, v0);
 #pragma unroll
-   for (int u = 0; u < U; u++) issue(u, w1, v1);
-   load_batch(64 * NBW, w1, v1);
-   load_batch(128 * NBW, w2, v2);
+   for (int u = 0; u < U; u++) issue(u, w1);
+   load_words(64 * NBW, w1);
+   load_vals(64 * NBW, v1);
+   load_words(128 * NBW, w2);
    // The row a slot is working on keeps its running sum in registers; it moves to the slot's LDS row when the stream
    // turns to another row (every ~deg / slices edges) and is picked up again from there when the stream comes back
    // in the next slice.  Plain read-add-write by the only lanes that ever touch that LDS row: LDS float atomics
@@ -415,8 +420,11 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, NVMAX, WGS>())) void s
 #endif
    for (int64_t b = 0; b < nb; b++) {
       // the U gathers of batch b are in flight; each one consumed is replaced by the same step of batch b + 1
+      float vnext = HAS_VAL ? __shfl(v0[0], g) : 0.0f;
 #pragma unroll
       for (int u = 0; u < U; u++) {
+         const float vcur = vnext;
+         if (HAS_VAL && u + 1 < U) vnext = __shfl(v0[((u + 1) * G) / 64], ((u + 1) * G) % 64 + g);
          if (la[u] != cur) {                             // per lane: the slots of a wave change rows at different steps
             flush();
             cur = la[u];
@@ -425,13 +433,14 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, NVMAX, WGS>())) void s
 #pragma unroll
          for (int v = 0; v < 4; v++) {
             const float x = __int_as_float(t[u][v]);
-            acc[v] = HAS_VAL ? fmaf(vv[u], x, acc[v]) : acc[v] + x;
+            acc[v] = HAS_VAL ? fmaf(vcur, x, acc[v]) : acc[v] + x;
          }
-         issue(u, w1, v1);
+         issue(u, w1);
       }
 #pragma unroll
-      for (int q = 0; q < NBW; q++) { w1[q] = w2[q]; v1[q] = v2[q]; }
-      load_batch((b + 3) * 64 * NBW, w2, v2);
+      for (int q = 0; q < NBW; q++) { w1[q] = w2[q]; v0[q] = v1[q]; }
+      load_words((b + 3) * 64 * NBW, w2);
+      load_vals((b + 2) * 64 * NBW, v1);
    }
    flush();
 #ifdef ISPLIB_EXP_WAVE_TIMES
