@@ -496,7 +496,8 @@ int    isplib_csr2csc_hip(int64_t m, int64_t n, int64_t nnz,
  *                         of exact 1.0f -- what isplib/__init__.py:51-57 materialises for an unweighted graph -- is
  *                         treated as NULL)
  *   isplib_graph_spmm     z = A (x) y for one of the four SpMM words; schedule by the measured rules: the stream
- *                         schedule where isplib_suggest_stream accepts the call (sum / mean), else isplib_suggest_slices
+ *                         schedule where isplib_suggest_stream (sum / mean) or isplib_suggest_stream_minmax (max / min,
+ *                         column-sorted rows) accepts the call, else isplib_suggest_slices
  *                         (or isplib_graph_set_slices: -1 rules, 0 plain kernel, 1..4096 task list)
  *   isplib_graph_spmm_backward   dx = A^T dy (mean != 0: with weights val/max(deg,1), the mean forward's
  *                         backward, csrc/fusedmm.cpp:375); the CSC operands are built on first use

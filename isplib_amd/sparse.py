@@ -46,7 +46,7 @@ class SparseStorage:
         # task plans of A and A^T per slice count ([] when the rows are not column-sorted: plain kernel)
         self._plans = {}
         self._plans_t = {}
-        # stream plans (sum / mean) of A and A^T per (transposed, streams, slices, chunk); their weight vectors in stream
+        # stream plans of A and A^T per (transposed, streams, slices, chunk[, "minmax"]); their weight vectors in stream
         # order per (transposed, streams, slices, chunk, kind) with the state of `value` they were gathered from
         self._streams = {}
         self._stream_vals = {}
