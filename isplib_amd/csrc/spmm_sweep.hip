@@ -891,16 +891,16 @@ extern "C" int isplib_suggest_stream(int64_t m, int64_t n, int64_t nnz, int64_t 
 
 extern "C" int isplib_suggest_stream_minmax(int64_t m, int64_t n, int64_t nnz, int64_t k, int *streams, int *slices, int *chunk) {
    // max / min: 32-column slots up to k = 32, 64-column slots above; the same reuse rule; rows must be column-sorted.
-   // Measured on the Reddit shape (K = 64): slices of ~5 MB (8-12 slices: 1.82 ms; 16: 1.88; 31, the sum kernel's count:
-   // 2.2 -- every change of row costs this kernel a read-compare-write of two LDS planes, and more slices mean more
-   // changes) and rows cut at ~0.6 of a stream's share (chunk 2048: 1.82 ms, 1028: 1.92, 4096: 1.96); task list: 2.04 ms
+   // Measured on the Reddit shape (K = 64): slices of ~7.5 MB (8 slices: 1.82 ms, 2.02 with weights; 12: 1.82 / 2.08; 16:
+   // 1.88 / 2.14; 31, the sum kernel's count: 2.2; K = 32 on 32-column slots: 4 slices 0.96, 6: 1.00, 12: 1.08 -- every
+   // change of row costs this kernel a read-compare-write of two LDS planes, and more slices mean more changes) and rows cut at ~0.6 of a stream's share (chunk 2048: 1.82 ms, 1028: 1.92, 4096: 1.96); task list: 2.04 ms
    // (K=41: 1.80 against 2.05, K=128: 3.58 against 3.98)
    clear_error();
    if (m <= 0 || n <= 0 || nnz <= 0 || k < 4 || n >= (1LL << 24) || nnz < (1LL << 22) || nnz >= (1LL << 31)) return 0;
    const int st = k <= 32 ? 8 : 4;
    int rpw = 0, resident = 0;
    if (isplib_spmm_stream_minmax_geometry(st, &rpw, &resident) != ISPLIB_SUCCESS || rpw <= 0 || resident <= 0) return 0;
-   if (!suggest_stream_geom(m, n, nnz, st, rpw, resident, 5.0e6, 1.7, slices, chunk)) return 0;
+   if (!suggest_stream_geom(m, n, nnz, st, rpw, resident, 7.5e6, 1.7, slices, chunk)) return 0;
    if (streams) *streams = st;
    return 1;
 }

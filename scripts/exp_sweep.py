@@ -86,7 +86,8 @@ if red in ("max", "min"):
             gens_est = -(-n // (rpw * wpg))
             chunk = max(256, int(nnz / (gens_est * wpg * streams) / 3.4))
         torch.cuda.synchronize()
-        plan = build_stream_plan(rowptr, col, None, n, S, wpg, rpw, streams, chunk, minmax=True)
+        mm_val = synth.edge_weights(nnz, device=dev) if os.environ.get("WEIGHTED") == "1" else None   # (then not comparable with the task list above)
+        plan = build_stream_plan(rowptr, col, mm_val, n, S, wpg, rpw, streams, chunk, minmax=True)
         ws = plan.workspace(minmax=True)
         cabi.fusedMM_csr_stream_minmax_hip(msg, rowptr, nnz, plan, x, out, arg, ws)
         torch.cuda.synchronize()
