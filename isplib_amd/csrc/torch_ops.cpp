@@ -569,9 +569,17 @@ class SpmmMean : public torch::autograd::Function<SpmmMean> {
          const bool cached = colptr.defined() && new_row.defined() && new_rowcount.defined() &&
                              new_row.numel() == col.numel() && new_rowcount.numel() == col.numel() &&
                              new_rowcount.scalar_type() == at::kFloat && new_row.is_cuda();
+         // an unweighted graph needs no edge weights here either: (A^T diag(1/deg)) dY = A^T (diag(1/deg) dY) -- the rows
+         // of dY are scaled once (M x K elementwise) and the SUM on A^T runs with unit weights, i.e. without a weight stream
+         const bool unit_planned = !has_value && colptr.defined() && new_row.defined() && !new_rowcount.defined() &&
+                                   new_row.numel() == col.numel() && new_row.is_cuda();
          if (cached) {
             grad_mat = std::get<0>(spmm_fw(colptr, new_row, optional<Tensor>(new_rowcount), grad_out, R_SUM,
                                            ctx->saved_data["plan_t"].toTensorVector()));
+         } else if (unit_planned) {
+            const Tensor deg = (rowptr.slice(0, 1) - rowptr.slice(0, 0, -1)).clamp_min(1).to(grad_out.scalar_type());
+            const Tensor gy = grad_out / deg.unsqueeze(1);
+            grad_mat = std::get<0>(spmm_fw(colptr, new_row, c10::nullopt, gy, R_SUM, ctx->saved_data["plan_t"].toTensorVector()));
          } else {
             auto t = build_transpose(rowptr, col, has_value ? value : Tensor(), mat.size(0), true);
             grad_mat = std::get<0>(spmm_fw(t.colptr, t.row_t, optional<Tensor>(t.val_t), grad_out, R_SUM));

@@ -242,9 +242,12 @@ def spmm_autotuned(src, other: torch.Tensor, reduce: str = "sum") -> torch.Tenso
         plan_t = []
         if needs_grad:                                               # :76-80 / :83-99 (built once per graph)
             colptr, row_t = s.colptr(), s.row_t()
-            val_t = s.mean_val_t() if reduce == "mean" else s.val_t()   # mean: intended pairing
+            # mean: the intended pairing, val[csr2csc] / max(deg, 1) -- for an unweighted graph that is
+            # 1 / deg of the edge's row in A, which the operator applies to the rows of dY instead: no weights at all
+            unit_mean = reduce == "mean" and s._value is None
+            val_t = None if unit_mean else (s.mean_val_t() if reduce == "mean" else s.val_t())
             geom_t = choose_stream(s, mat.size(0), m_rows, k)
-            plan_t = s.stream_plan(True, geom_t, "mean" if reduce == "mean" else "sum") if geom_t is not None else None
+            plan_t = s.stream_plan(True, geom_t, "mean" if reduce == "mean" and not unit_mean else "sum") if geom_t is not None else None
             if plan_t is None:
                 plan_t = s.plan_t(choose_slices(s, m_rows, k, transposed=True))
         if reduce == "mean":

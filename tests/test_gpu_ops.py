@@ -798,3 +798,5 @@ def test_plugin_runs_sum_and_mean_on_the_stream_schedule(gpu, oracle_mod, monkey
                 if weighted:
                     value.copy_(_t(val1, gpu))
             assert any(k[0] is False for k in adj.storage._streams) and any(k[0] is True for k in adj.storage._streams), "stream plans were not used"
+            if not weighted and red == "mean":      # unweighted mean: 1 / deg is applied to the rows of dY, no edge weights anywhere
+                assert adj.storage._mean_val_t is None and not adj.storage._stream_vals
