@@ -85,6 +85,8 @@ struct isplib_graph {
    Side fwd, bwd;                // bwd = A^T, built on first backward call
    bool has_bwd = false;
    float *mean_val_t = nullptr;  // val[csr2csc] / max(deg(row),1): the mean backward's weights
+   float *scaled = nullptr;      // grow-only [m][k] copy of dy with rows scaled by 1 / max(deg,1): the mean backward of a
+   size_t scaled_bytes = 0;      // unit-weight graph needs no edge weights (A^T diag(1/deg) dY = A^T (diag(1/deg) dY))
    uint64_t val_gen = 0;         // bumped by isplib_graph_set_values: copies of the weights older than this are stale
    bool bwd_vals_stale = false;  // the transposed weights (bwd.val, mean_val_t) predate the last isplib_graph_set_values
    struct Work { void *ptr = nullptr; size_t bytes = 0; };
@@ -152,6 +154,7 @@ extern "C" void isplib_graph_destroy(isplib_graph *g) {
    free_side(g->fwd, false);
    free_side(g->bwd, true);
    (void)hipFree(g->mean_val_t);
+   (void)hipFree(g->scaled);
    for (auto &kv : g->works) (void)hipFree(kv.second.ptr);
    delete g;
 }
@@ -472,6 +475,17 @@ static int ensure_transpose(isplib_graph *g, hipStream_t st) {
    return ISPLIB_SUCCESS;
 }
 
+// out[i][:] = in[i][:] / max(deg_i, 1)
+__global__ __launch_bounds__(256) void scale_rows_by_degree_kernel(int64_t m, int64_t k, const int64_t *__restrict__ rowptr,
+                                                                   const float *__restrict__ in, int64_t ld_in, float *__restrict__ out) {
+   const int64_t total = m * k, stride = (int64_t)gridDim.x * blockDim.x;
+   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+      const int64_t r = i / k, c = i - r * k;
+      const int64_t d = rowptr[r + 1] - rowptr[r];
+      out[i] = in[r * ld_in + c] / (float)(d > 1 ? d : 1);
+   }
+}
+
 extern "C" int isplib_graph_spmm_backward(isplib_graph *g, int mean, int64_t k, const float *dy, int64_t lddy, float *dx,
                                           int64_t lddx, void *stream) {
    clear_error();
@@ -479,6 +493,21 @@ extern "C" int isplib_graph_spmm_backward(isplib_graph *g, int mean, int64_t k, 
    hipStream_t st = (hipStream_t)stream;
    const int rc = ensure_transpose(g, st);
    if (rc) return rc;
+   if (mean && g->fwd.m > 0 && k > 0 && (!g->fwd.val || weights_are_unit(g->fwd, st) == 1)) {
+      // unit weights: scale the rows of dy once and run the SUM on A^T without edge weights (no weight stream)
+      const size_t need = (size_t)g->fwd.m * (size_t)k * sizeof(float);
+      if (g->scaled_bytes < need) {
+         if (g->scaled) { ISPLIB_HIP_TRY(hipStreamSynchronize(st)); (void)hipFree(g->scaled); g->scaled = nullptr; g->scaled_bytes = 0; }
+         TRY_ALLOC(g->scaled, need);
+         g->scaled_bytes = need;
+      }
+      const int64_t total = g->fwd.m * k, blocks = (total + 255) / 256;
+      hipLaunchKernelGGL(scale_rows_by_degree_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, st, g->fwd.m, k,
+                         g->fwd.rowptr, dy, lddy, g->scaled);
+      const int rl = check_launch("scale_rows_by_degree_kernel");
+      if (rl) return rl;
+      return run_side(g, g->bwd, nullptr, ISPLIB_MSG_SPMM_SUM, k, g->scaled, k, dx, lddx, nullptr, st);
+   }
    return run_side(g, g->bwd, mean ? g->mean_val_t : g->bwd.val, ISPLIB_MSG_SPMM_SUM, k, dy, lddy, dx, lddx, nullptr, st);
 }
 
