@@ -158,7 +158,14 @@ def extra_configs(dev, rowptr, col, n, with_cpu_epoch=True):
     for red in ("mean", "max", "min"):
         run(red, 64, w, f"config 3: reddit-like SpMM-{red} K=64, U(0,1) weights" + (" (+arg)" if red != "mean" else ""))
     run("sum", 128, w, "config 2: reddit-like SpMM-sum K=128, U(0,1) weights")
-    del w, col32
+    # the third leg of config 2's backward when the edge weights are trainable: dA[e] = <X[col[e]], dY[row(e)]>, the SDDMM the
+    # reference leaves commented out (csrc/fusedmm.cpp:270), through the graph handle (task list sized for whole rows)
+    h = cabi.GraphHandle(rowptr, col, w, n)
+    xs, gs = synth.features(n, 128, device=dev), synth.features(n, 128, seed=5, device=dev)
+    ms = _time_launches(lambda: h.sddmm(xs, gs))
+    entry("config 2 backward, trainable weights: dA = SDDMM(X, dY) K=128", ms, n, n, nnz, 128, False, "task list through isplib_graph_sddmm")
+    h.close()
+    del w, col32, xs, gs
 
     # config 5: the GCN epoch of tests/cpu/gcn-sparse.py:55-129 through iSpLibPlugin.patch_pyg (scripts/gcn_epoch.py restates it)
     import importlib.util
