@@ -512,6 +512,62 @@ def test_sweep_plan_covers_every_edge_once_in_csr_order(geom):
     assert int((p["task_meta"] & 0xFFFFFF).sum()) == col.size
 
 
+@pytest.mark.parametrize("streams,rpw", ((4, 32), (8, 64)))
+def test_stream_order_keeps_the_lowest_csr_position_on_ties(streams, rpw):
+    """The argument behind spmm_stream_minmax_kernel, replayed on the CPU: for rows whose columns ascend, a stream lists a
+    row's edges in CSR order (slice by slice, CSR order inside a slice), so "only a strictly better candidate replaces
+    the one held" -- tracked by WORD INDEX, translated through perm at the end -- leaves the lowest CSR position among
+    equal candidates; the pieces of a hub row are merged by explicit position compare.  Integer operands: ties everywhere.
+    Against the oracle, values and arg.  And: the plan builder refuses a graph with an unsorted row."""
+    import oracle
+    from isplib_amd.plan import build_stream_plan, stream_plan_arrays
+    m, n, slices, wpg, chunk = 120, 90, 5, 3, 40
+    rowptr, col = cases.random_csr(m, n, 25, 3, empty_rows=(0, 50), hub=(7, 700), duplicates=True)
+    val = cases.weights(col.size, 4, "signed_int")
+    x = cases.dense(n, 5, 3, "integer")
+    p = stream_plan_arrays(torch.from_numpy(rowptr), torch.from_numpy(col), n, slices, wpg, rpw, streams, chunk)
+    nw = p["gens"] * wpg
+    words = p["words"].numpy().astype(np.int64) & 0xFFFFFFFF
+    perm, off = p["perm"].numpy(), p["wave_step_off"].numpy()
+    wr, wp = p["wave_row"].numpy().reshape(nw, rpw), p["wave_part"].numpy().reshape(nw, rpw)
+    k = x.shape[1]
+    lowest = np.finfo(np.float32).min
+    out, arg = np.zeros((m, k), np.float32), np.full((m, k), col.size, np.int64)
+    part_v, part_i = np.full((p["n_parts"], k), lowest, np.float32), np.full((p["n_parts"], k), np.iinfo(np.int64).max, np.int64)
+    for w in range(nw):
+        best = np.full((rpw, k), lowest, np.float32)
+        widx = np.full((rpw, k), -1, np.int64)
+        for st in range(off[w], off[w + 1]):
+            for g in range(streams):
+                i = st * streams + g
+                c, lr = words[i] & 0xFFFFFF, words[i] >> 24
+                if c == n:
+                    continue                                     # padding: the kernel steers it to a spare row
+                t = np.float32(val[perm[i]]) * x[c]
+                win = t > best[lr]                               # strict, in stream order
+                best[lr][win], widx[lr][win] = t[win], i
+        for j in range(rpw):
+            if wr[w, j] < 0:
+                continue
+            pos = np.where(widx[j] >= 0, perm[np.maximum(widx[j], 0)], np.iinfo(np.int64).max)
+            if wp[w, j] >= 0:
+                part_v[wp[w, j]], part_i[wp[w, j]] = best[j], pos
+            elif rowptr[wr[w, j] + 1] > rowptr[wr[w, j]]:
+                out[wr[w, j]], arg[wr[w, j]] = best[j], np.where(widx[j] >= 0, pos, col.size)
+    hr, ho = p["hub_row"].numpy(), p["hub_off"].numpy()
+    for h in range(hr.size):
+        v, a = np.full(k, lowest, np.float32), np.full(k, np.iinfo(np.int64).max, np.int64)
+        for q in range(ho[h], ho[h + 1]):
+            take = (part_v[q] > v) | ((part_v[q] == v) & (part_i[q] < a))
+            v[take], a[take] = part_v[q][take], part_i[q][take]
+        out[hr[h]], arg[hr[h]] = v, a
+    ref, ref_arg = oracle.spmm_fw(rowptr, col, val, x, "max")
+    assert np.array_equal(out, ref) and np.array_equal(arg, ref_arg)
+    # unsorted rows: no plan (the stream order would no longer be the CSR order)
+    r2, c2 = cases.random_csr(40, 30, 6, 9, sort_cols=False)
+    assert build_stream_plan(torch.from_numpy(r2), torch.from_numpy(c2), None, 30, 2, 3, rpw, streams, 16, minmax=True) is None
+
+
 @pytest.mark.parametrize("geom", ((8, 8, 16, 4, 512), (5, 3, 32, 8, 64), (3, 2, 16, 2, 100000)))
 def test_stream_plan_lists_every_edge_once_slice_by_slice(geom):
     """Host logic of the stream plan (isplib_amd/plan.py: stream_plan_arrays), replayed on the CPU the way
