@@ -523,6 +523,9 @@ def main():
         from isplib_amd.plan import build_stream_plan
         geom = tuple(int(v) for v in a.stream_geom.split(":")) if a.stream_geom else \
             cabi.suggest_stream(m_local, x_in.size(0), l_col.numel(), k)
+        if geom is not None and not a.stream_geom:          # no degree skew: slices closer to the L2 size (the plug-in's rule)
+            from isplib_amd.plugin import skew_adjusted as _skew
+            geom = (geom[0], _skew(l_rowptr, geom[1], cap=512), geom[2])
         if geom is not None:
             splan = build_stream_plan(l_rowptr, l_col, l_val, x_in.size(0), geom[1], None, None, geom[0], geom[2])
             swork = None if splan is None else splan.workspace()

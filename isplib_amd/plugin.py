@@ -130,11 +130,12 @@ def degree_cv2(rowptr: torch.Tensor) -> float:
     return max(0.0, float((deg * deg).mean() / (mean * mean)) - 1.0)
 
 
-def skew_adjusted(storage_or_rowptr, slices: int) -> int:
+def skew_adjusted(storage_or_rowptr, slices: int, cap: int = 64) -> int:
     """The rule's 7 MB per slice leans on the popularity skew of real degree distributions (hot rows of the dense operand
     stay in the L2).  A graph whose degrees hardly vary (CV^2 < 0.25) has no hot rows and wants slices closer to the L2
-    size: half as many columns per slice again (uniform random graph of the Reddit size, K=128: 4.09 -> 3.49 ms).
-    The same test lives in the C handle (graph_runtime.hip)."""
+    size: half as many columns per slice again (uniform random graph of the Reddit size, K=128: 4.09 -> 3.49 ms on the
+    task list; on the stream schedule 31 -> 47 slices: 3.21 -> 3.00 ms).  The same test lives in the C handle
+    (graph_runtime.hip)."""
     if slices <= 0:
         return slices
     if isinstance(storage_or_rowptr, torch.Tensor):
@@ -143,7 +144,7 @@ def skew_adjusted(storage_or_rowptr, slices: int) -> int:
         cv2 = getattr(storage_or_rowptr, "_cv2", None)
         if cv2 is None:
             cv2 = storage_or_rowptr._cv2 = degree_cv2(storage_or_rowptr._rowptr)
-    return slices if cv2 >= 0.25 else min(64, int(1.5 * slices + 0.5))
+    return slices if cv2 >= 0.25 else min(cap, int(1.5 * slices + 0.5))
 
 
 def choose_slices(storage: SparseStorage, rows: int, k: int, minmax: bool = False, transposed: bool = False) -> int:
@@ -191,7 +192,8 @@ def choose_stream(storage: SparseStorage, m: int, n: int, k: int):
     if forced:
         return tuple(int(v) for v in forced.split(":"))
     from . import cabi
-    return cabi.suggest_stream(m, n, storage._col.numel(), k)
+    geom = cabi.suggest_stream(m, n, storage._col.numel(), k)
+    return None if geom is None else (geom[0], skew_adjusted(storage, geom[1], cap=512), geom[2])
 
 
 def choose_stream_minmax(storage: SparseStorage, m: int, n: int, k: int):
@@ -205,7 +207,8 @@ def choose_stream_minmax(storage: SparseStorage, m: int, n: int, k: int):
     if forced:
         return tuple(int(v) for v in forced.split(":"))
     from . import cabi
-    return cabi.suggest_stream_minmax(m, n, storage._col.numel(), k)
+    geom = cabi.suggest_stream_minmax(m, n, storage._col.numel(), k)
+    return None if geom is None else (geom[0], skew_adjusted(storage, geom[1], cap=512), geom[2])
 
 
 def spmm_autotuned(src, other: torch.Tensor, reduce: str = "sum") -> torch.Tensor:
