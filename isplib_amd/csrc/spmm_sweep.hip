@@ -858,7 +858,7 @@ static int suggest_stream_geom(int64_t m, int64_t n, int64_t nnz, int st, int rp
                                int *slices, int *chunk) {
    const int64_t per_gen = (int64_t)rpw * resident;
    const int64_t gens = (m + per_gen - 1) / per_gen;
-   if ((double)nnz / (double)gens / 8.0 < 8.0 * (double)n) return 0;
+   if ((double)nnz / (double)gens / 8.0 < 3.0 * (double)n) return 0;
    const double panel_bytes = 1024.0 / st;
    int sl = (int)((double)n * panel_bytes / slice_bytes + 0.5);
    sl = sl < 1 ? 1 : (sl > 512 ? 512 : sl);
@@ -876,8 +876,10 @@ extern "C" int isplib_suggest_stream(int64_t m, int64_t n, int64_t nnz, int64_t 
    //     (task list 3.17); K=72: 2.92 / 2.30 (2.42); K=96: 2.51 / 2.30 (2.56); K=160 wants 64 + 64 + 32: 3.85 / 4.97 (4.15);
    //   * a column slice of ~1.9 MB of the panel (Reddit shape: 32 slices at 64 columns, 16 at 32);
    //   * every generation of waves sweeps the whole dense operand once per XCD, so the rows a generation holds must
-   //     reuse each row of it often: edges per generation and XCD >= 8 x rows of y (Reddit shape: 31; the
-   //     ogbn-products shape, mean degree 50 over 2.4 M rows: 0.3 -- such graphs stay on the plain kernel);
+   //     reuse each row of it often: edges per generation and XCD >= 3 x rows of y (Reddit shape: 31; one rank's shard
+   //     of it at 8 / 16 / 32 ranks: 7.7 / 3.9 / 1.9 -- stream 0.37 / 0.22-0.24 / 0.16-0.18 ms against 0.43 / 0.24 /
+   //     0.16-0.19 ms on the task list, scripts/exp_shard_schedule.py; the ogbn-products shape, mean degree 50 over 2.4 M
+   //     rows: 0.3 -- such graphs stay on the plain kernel);
    //   * rows longer than ~0.3 of a stream's share of the edges are dealt to several virtual rows (chunk).
    clear_error();
    if (m <= 0 || n <= 0 || nnz <= 0 || k < 4 || n >= (1LL << 24) || nnz < (1LL << 22)) return 0;
