@@ -347,19 +347,100 @@ def dist_extra_configs(dev, rank, world, rowptr, col, n):
     buf = part.gather_buffer(k)
     z = torch.empty((part.rows, k), dtype=torch.float32, device=dev)
 
-    def step():
+    # One step = the exchange of X + the local SpMM.  This is the workload where the exchange dominates (2.19 GB inbound
+    # per rank at 8 ranks against ~2.3 ms of local SpMM), so the overlapped forms of isplib_amd/dist.py are candidates
+    # beside the blocking all-gather, each validated against it once (1e-5 of sum |a||x| per element: other summation
+    # orders) and timed for a few steps; the fastest on THIS node is kept and named.
+    def gather_plain():
         part.all_gather(shard, buf)
         cabi.fusedMM_csr_hip(cabi.MSG_SPMM_SUM, part.rowptr, part.col_padded, None, buf, z)
 
-    for _ in range(2):
-        step()
-    torch.cuda.synchronize()
-    dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(5):
-        step()
-    torch.cuda.synchronize()
-    ms = over_ranks(time.perf_counter() - t0) / 5 * 1e3
+    # K = 256 as 4 panels of 64 columns: every panel its own all-gather, issued up front; panel c is aggregated (plain
+    # kernel on the panel: columns are independent) while panels c+1.. are still on the links
+    panels = [(c0, min(k, c0 + 64)) for c0 in range(0, k, 64)]
+    p_send = [torch.zeros((part.max_rows, c1 - c0), dtype=torch.float32, device=dev) for c0, c1 in panels]
+    p_recv = [torch.empty((part.ncols_padded, c1 - c0), dtype=torch.float32, device=dev) for c0, c1 in panels]
+
+    def pipelined_plain():
+        handles = []
+        for (c0, c1), sb, rb in zip(panels, p_send, p_recv):
+            sb.copy_(shard[:, c0:c1])
+            handles.append(dist.all_gather_into_tensor(rb, sb, async_op=True))
+        for (c0, c1), rb, h in zip(panels, p_recv, handles):
+            h.wait()
+            cabi.fusedMM_csr_hip(cabi.MSG_SPMM_SUM, part.rowptr, part.col_padded, None, rb, z[:, c0:c1])
+
+    candidates = {"gather + plain kernel": gather_plain, "pipelined x4 (64-column panels, plain kernel)": pipelined_plain}
+
+    def all_agree(good):
+        flag = torch.tensor([1 if good else 0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item())
+
+    # the library's pipelined form (task list or stream schedule per panel) where its rules accept this rank's shard
+    for stream_form in (True, False):
+        state = None
+        try:
+            state = part.pipeline_state(k, 4, "sum", stream=stream_form)
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] config 4: pipeline_state(stream={stream_form}) raised {type(e).__name__}: {e}", file=sys.stderr)
+        if all_agree(state is not None):
+            candidates["pipelined x4 (" + ("stream schedule" if stream_form else "task list") + " per panel)"] = \
+                (lambda st: lambda: part.spmm_pipelined(shard, z, st, "sum"))(state)
+    # direct per-peer exchange: one column slice per shard (the slice rule itself may decline a graph this sparse), the
+    # shards aggregated as their group lands; over gloo a point-to-point shard takes seconds (rehearsals skip it)
+    if os.environ.get("ISPLIB_BENCH_BACKEND", "nccl") == "nccl" or os.environ.get("ISPLIB_BENCH_DIRECT") == "1":
+        dplan = None
+        try:
+            dplan = part.plan(k, "sum", slices=world)
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] config 4: sliced plan raised {type(e).__name__}: {e}", file=sys.stderr)
+        if all_agree(dplan is not None):
+            for nb in sorted({1, 2, world - 1}):
+                if 1 <= nb <= world - 1:
+                    candidates[f"direct x{nb} (per-peer send / receive, {world} column slices)"] = \
+                        (lambda b: lambda: part.spmm_direct(shard, buf, z, dplan, "sum", None, batches=b))(nb)
+
+    gather_plain()
+    want = z.clone()
+    cabi.fusedMM_csr_hip(cabi.MSG_SPMM_SUM, part.rowptr, part.col_padded, None, buf.abs(), z)
+    bound = z.abs() * 1e-5 + 1e-30
+    times = {}
+    for name, fn in list(candidates.items()):
+        good = True
+        try:
+            z.zero_()
+            fn()
+            torch.cuda.synchronize()
+            good = bool(((z - want).abs() <= bound).all())
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] config 4 schedule '{name}' raised {type(e).__name__}: {e}", file=sys.stderr)
+            good = False
+        if not all_agree(good):
+            if rank == 0:
+                print(f"[bench] config 4 schedule '{name}' disabled (mismatch or error)", file=sys.stderr)
+            del candidates[name]
+            continue
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        first = over_ranks(time.perf_counter() - t0) * 1e3
+        if first > 2000.0:                     # a schedule this slow (a rehearsal over gloo) is not worth more steps
+            times[name] = first
+            continue
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        times[name] = over_ranks(time.perf_counter() - t0) / 5 * 1e3
+    del want, bound
+    chosen = min(times, key=times.get)
+    ms = times[chosen]
+    if rank == 0:
+        print(f"[bench] config 4, N={world}: " + ", ".join(f"{n_} {t_:.3f} ms/step" for n_, t_ in times.items()) + f" -> {chosen}", file=sys.stderr)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     part.all_gather(shard, buf)
     ev0.record()
@@ -367,8 +448,9 @@ def dist_extra_configs(dev, rank, world, rowptr, col, n):
     ev1.record()
     torch.cuda.synchronize()
     b_alg = synth.algorithmic_bytes(pn, pn, e, k, False)
-    out.append({"config": f"config 4 on {world} GPUs: products-like SpMM-sum K=256 (N={pn}, nnz={e}), rows by nnz, one all-gather(X) "
-                          f"({pn * k * 4 / 1e9:.2f} GB gathered per rank) + the plain row-per-wave kernel per step",
+    out.append({"config": f"config 4 on {world} GPUs: products-like SpMM-sum K=256 (N={pn}, nnz={e}), rows by nnz, one exchange of X "
+                          f"({pn * k * 4 / 1e9:.2f} GB gathered per rank) + the local SpMM per step",
+                "schedule": chosen, "candidates_ms": {n_: round(t_, 3) for n_, t_ in times.items()},
                 "ms": ms, "edges_per_s": e / (ms * 1e-3), "local_spmm_ms_rank0": ev0.elapsed_time(ev1), "n_gpus": world,
                 "roofline": {"bound": "hbm", "achieved": b_alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS * world, "unit": "GB/s",
                              "frac": b_alg / (ms * 1e-3) / 1e9 / (HBM_PEAK_GBPS * world), "algorithmic_bytes_per_launch": b_alg}})
@@ -382,15 +464,60 @@ def launcher_command(gpus: int, argv, port: int):
             "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
+def visible_gpu_count(sysfs: str = "/sys/class/kfd/kfd/topology/nodes", dri: str = "/dev/dri", env=None):
+    """How many GPUs a HIP process started from here would see, WITHOUT loading HIP (or amdsmi) in this process: the
+    launcher parent must stay GPU-free (a process that has initialised the GPU may neither fork ranks nor be replaced).
+    KFD topology nodes with simd_count > 0 are GPUs (CPU nodes have 0); a node whose render device this user cannot
+    open is not ours (container isolation); ROCR_ / HIP_ / CUDA_VISIBLE_DEVICES narrow the list the way the runtime
+    reads them (each a comma list of indices into what is left, or GPU-<uuid> tokens; the list ends at the first index
+    that does not exist).  0 without a KFD driver; None when the driver is there but its topology is not readable (the
+    ranks then find out themselves)."""
+    import glob
+    env = os.environ if env is None else env
+    nodes = []
+    for nd in glob.glob(os.path.join(sysfs, "*")):
+        try:
+            idx = int(os.path.basename(nd))
+            with open(os.path.join(nd, "properties")) as f:
+                props = dict(ln.split()[:2] for ln in f if len(ln.split()) >= 2)
+        except (OSError, ValueError):
+            continue
+        if int(props.get("simd_count", "0")) <= 0:
+            continue
+        minor = int(props.get("drm_render_minor", "-1"))
+        if minor > 0 and os.path.isdir(dri) and not os.access(os.path.join(dri, f"renderD{minor}"), os.R_OK | os.W_OK):
+            continue
+        nodes.append(idx)
+    if not os.path.isdir(sysfs):
+        # no topology to read: without /dev/kfd there is no ROCm device at all; with it, the count is unknown from here
+        return None if os.path.exists("/dev/kfd") else 0
+    count = len(nodes)
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        spec = env.get(var)
+        if spec is None:
+            continue
+        kept = 0
+        for tok in (t.strip() for t in spec.split(",")):
+            if tok.lstrip("-").isdigit():
+                if not 0 <= int(tok) < count:
+                    break
+            elif not tok.upper().startswith("GPU-"):
+                break
+            kept += 1
+        count = min(count, kept)
+    return count
+
+
 def self_launch(a, argv) -> int:
     """`--gpus N` with N > 1 and no WORLD_SIZE: this process becomes the launcher.  It must not touch the GPU (a
     process that has initialised HIP may neither fork ranks nor be replaced): it only counts devices, starts the
-    ranks as children, relays rank 0's JSON line and returns non-zero if any child failed."""
+    ranks as children, relays rank 0's JSON line and returns non-zero if any child failed.  Devices are counted from
+    sysfs (visible_gpu_count): torch.cuda.device_count() goes through amdsmi or hipGetDeviceCount, i.e. may load HIP."""
     import socket
     import subprocess
     backend = os.environ.get("ISPLIB_BENCH_BACKEND", "nccl")
-    have = torch.cuda.device_count()             # counting devices does not initialise the GPU
-    if backend == "nccl" and have < a.gpus:
+    have = visible_gpu_count()                   # from sysfs: no HIP call, no amdsmi, nothing that could initialise a GPU
+    if backend == "nccl" and have is not None and have < a.gpus:
         print(f"bench.py: --gpus {a.gpus} but only {have} GPU(s) visible: refusing to print a number for fewer ranks "
               "(ISPLIB_BENCH_BACKEND=gloo rehearses N ranks on one GPU, labelled as a rehearsal)", file=sys.stderr)
         return 2

@@ -218,9 +218,21 @@ def last_error() -> str:
     return lib().isplib_hip_last_error().decode()
 
 
+# status codes of include/isplib_hip.h (csrc/fusedMM.h:105-114 of the reference)
+ISPLIB_SUCCESS, ISPLIB_FAIL, ISPLIB_NOT_ENOUGH_MEM, ISPLIB_NO_OPT_IMPL, ISPLIB_HIP_ERROR = 0, 1, -1, 128, 256
+
+
+class IsplibError(RuntimeError):
+    """A non-zero status of the C ABI (include/isplib_hip.h: ISPLIB_*), with the library's message."""
+
+    def __init__(self, status: int, what: str, message: str):
+        super().__init__(f"{what} failed with status {status}: {message}")
+        self.status = int(status)
+
+
 def _check(status: int, what: str) -> None:
     if status != 0:
-        raise RuntimeError(f"{what} failed with status {status}: {last_error()}")
+        raise IsplibError(status, what, last_error())
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -725,6 +737,21 @@ class NativeStreamPlan:
         if not ptr or count == 0:
             return torch.empty(0, device=self.device)
         return torch.as_tensor(_DevView(ptr, count, typestr), device=self.device).clone()
+
+    def view(self, name: str, dtype: torch.dtype) -> torch.Tensor:
+        """One of the plan's device arrays as a tensor WITHOUT a copy: the memory belongs to this plan object, which
+        the caller keeps alive for as long as the tensor is used (plan.py: build_stream_plan_native does)."""
+        nw = self.gens * self.waves_per_gen
+        count, typestr = {"words": (self.n_steps * self.streams, "<i4"), "perm": (self.n_steps * self.streams, "<i4"),
+                          "wave_step_off": (nw + 1, "<i8"), "wave_row": (nw * self.rows_per_wave, "<i4"),
+                          "wave_part": (nw * self.rows_per_wave, "<i4"), "hub_row": (self.n_hub, "<i4"),
+                          "hub_off": (self.n_hub + 1, "<i4")}[name]
+        ptr = getattr(self._s, name)
+        if not ptr or count == 0:
+            return torch.empty(0, dtype=dtype, device=self.device)
+        t = torch.as_tensor(_DevView(ptr, count, typestr), device=self.device)
+        assert t.dtype == dtype and t.data_ptr() == ptr, "zero-copy view of a library array"
+        return t
 
     def close(self):
         if self._s.words or self._s.wave_row:

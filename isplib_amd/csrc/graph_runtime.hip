@@ -41,6 +41,7 @@ struct Side {                    // A, or A^T, as CSR
    // stream order: `val` of the side, or the mean backward's weights)
    struct Stream { isplib_stream_plan plan; const float *vals_of = nullptr; bool has_vals = false; uint64_t gen = 0; };
    std::map<uint64_t, Stream> streams;
+   bool stream_refused = false;          // the sum / mean stream builder declined this side (outside its domain): task list / plain
    bool minmax_stream_refused = false;   // the max / min stream builder declined this side (rows not column-sorted): task list
 };
 
@@ -300,7 +301,9 @@ static int run_side(isplib_graph *g, Side &s, const float *val, int32_t imessage
    // sum / mean on graphs with work for the whole chip: the stream schedule (rows resident in LDS, the plan's own copy of
    // the edges), unless a slice count was forced
    int st_streams = 0, st_slices = 0, st_chunk = 0;
-   if (!minmax && g->forced_slices < 0 && ldy < (1LL << 22) && isplib_suggest_stream(s.m, s.n, s.nnz, k, &st_streams, &st_slices, &st_chunk)) {
+   const bool y_in_one_descriptor = (double)s.n * (double)ldy * 4.0 <= 3.5 * 1073741824.0;      // with the caller's ldy, not k
+   if (!minmax && g->forced_slices < 0 && !s.stream_refused && ldy < (1LL << 22) && y_in_one_descriptor &&
+       isplib_suggest_stream(s.m, s.n, s.nnz, k, &st_streams, &st_slices, &st_chunk)) {
       st_slices = skew_adjusted(s, st_slices, st, 512);      // no degree skew: slices closer to the L2 size (31 -> 47: 3.21 -> 3.00 ms)
       const uint64_t key = ((uint64_t)st_streams << 48) | ((uint64_t)st_slices << 32) | (uint64_t)(uint32_t)st_chunk;
       auto it = s.streams.find(key);
@@ -310,6 +313,9 @@ static int run_side(isplib_graph *g, Side &s, const float *val, int32_t imessage
          if (rc == ISPLIB_SUCCESS) {
             fresh.vals_of = val; fresh.has_vals = val != nullptr; fresh.gen = g->val_gen;
             it = s.streams.emplace(key, fresh).first;
+         } else if (rc == ISPLIB_FAIL) {
+            s.stream_refused = true;                  // outside the builder's domain: not an error of this call; the
+            clear_error();                            // task list / plain kernel below serve the graph
          } else if (rc != ISPLIB_NOT_ENOUGH_MEM) {
             return rc;
          }                                           // no room for the plan: the task list / plain kernel below need less
@@ -331,7 +337,7 @@ static int run_side(isplib_graph *g, Side &s, const float *val, int32_t imessage
    }
    // max / min on such graphs: the stream schedule's own kernel and plan geometry, for column-sorted rows
    int mm_streams = 0, mm_slices = 0, mm_chunk = 0;
-   if (minmax && g->forced_slices < 0 && !s.minmax_stream_refused && ldy < (1LL << 22) &&
+   if (minmax && g->forced_slices < 0 && !s.minmax_stream_refused && ldy < (1LL << 22) && y_in_one_descriptor &&
        isplib_suggest_stream_minmax(s.m, s.n, s.nnz, k, &mm_streams, &mm_slices, &mm_chunk)) {
       mm_slices = skew_adjusted(s, mm_slices, st, 512);
       const uint64_t key = (1ULL << 63) | ((uint64_t)mm_streams << 48) | ((uint64_t)mm_slices << 32) | (uint64_t)(uint32_t)mm_chunk;

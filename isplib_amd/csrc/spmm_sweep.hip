@@ -76,7 +76,7 @@ struct SweepArgs {
    const int32_t *task_meta;       // [n_tasks] (slot << 24) | edges
    int wave_base, wave_count;      // waves of this launch (one generation): [wave_base, wave_base + wave_count)
    // stream form (spmm_stream_kernel): the plan's own copy of the edges, in the order the waves walk them
-   const int32_t *words;           // [steps][G] (local row << 27) | column; the null word is (0 << 27) | n
+   const int32_t *words;           // [steps][G] (local row << 24) | column; padding = (the slot's first row << 24) | n
    const float *vals;              // [steps][G] weights in the same order, or null (unit weights)
    const int64_t *wave_step_off;   // [waves + 1] first step of a wave
    unsigned null_word;
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void sweep_hub_fold_kernel(const SweepArgs a) 
 // ---- stream form ------------------------------------------------------------------------------------------------
 // The sweep above still pays one latency chain per (row, slice) segment -- and with L2-sized slices a segment is
 // 15 edges.  Here a wave does not see segments at all.  The plan gives each of the G = 64 / LPR slots of a wave its
-// own STREAM: the edges of the slot's NVMAX / G rows, slice by slice, as 4-byte words (local row << 27 | column) in
+// own STREAM: the edges of the slot's NVMAX / G rows, slice by slice, as 4-byte words (local row << 24 | column) in
 // the plan's own copy of the index array.  Step i of a wave gathers word i of each of its G streams -- one 1-KiB
 // buffer load, always full -- and every lane adds the four floats it receives to the running sum of the row its
 // slot is on (registers), which moves to and from the slot's LDS row when the stream changes rows.  The slots of a
@@ -335,6 +335,7 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, NVMAX, WGS>())) void s
    constexpr int WAVES = 4, G = 64 / LPR, PANEL = LPR * 4, U = 64 * NBW / G;     // a batch = NBW x 64 words = U steps
    constexpr int PER = NVMAX / G;                         // rows of a slot
    constexpr int WAVE_FLOATS = NVMAX * PANEL;
+   static_assert(NVMAX <= 256 && NVMAX % G == 0, "the local row is the top byte of a word");
    __shared__ __attribute__((aligned(16))) float s_all[WAVES * WAVE_FLOATS];
    const int lane = threadIdx.x & 63;
    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -869,6 +870,14 @@ static int suggest_stream_geom(int64_t m, int64_t n, int64_t nnz, int st, int rp
    return 1;
 }
 
+// The domain of the stream entries and of isplib_stream_plan_build_hip, with ldy = k (a contiguous dense operand; callers
+// with a padded leading dimension check n * ldy themselves): the dense operand inside one buffer descriptor (3.5 GiB) and
+// 32-bit edge positions.  A shape outside it is simply not offered the schedule -- it runs on the task list or the plain
+// kernel as before the stream schedule existed -- instead of being offered and then refused with an error.
+static bool stream_domain_ok(int64_t n, int64_t k, int64_t nnz) {
+   return (unsigned long long)n * (unsigned long long)k * 4ull <= (unsigned long long)BUF_LIMIT && nnz < (1LL << 31);
+}
+
 extern "C" int isplib_suggest_stream(int64_t m, int64_t n, int64_t nnz, int64_t k, int *streams, int *slices, int *chunk) {
    // When does the stream schedule pay, and with which plan?  Measured on MI355X:
    //   * slots of 8 lanes (32-column panels) up to k = 32, of 16 lanes (64-column panels) up to 64 and from 128 on, of
@@ -883,6 +892,7 @@ extern "C" int isplib_suggest_stream(int64_t m, int64_t n, int64_t nnz, int64_t 
    //   * rows longer than ~0.3 of a stream's share of the edges are dealt to several virtual rows (chunk).
    clear_error();
    if (m <= 0 || n <= 0 || nnz <= 0 || k < 4 || n >= (1LL << 24) || nnz < (1LL << 22)) return 0;
+   if (!stream_domain_ok(n, k, nnz)) return 0;         // what the entry and the plan builder would refuse: not offered
    const int st = k <= 32 ? 8 : (k <= 64 ? 4 : (k < 128 ? 2 : 4));
    int rpw = 0, resident = 0;
    if (isplib_spmm_stream_geometry(st, &rpw, &resident) != ISPLIB_SUCCESS || rpw <= 0 || resident <= 0) return 0;
@@ -899,6 +909,7 @@ extern "C" int isplib_suggest_stream_minmax(int64_t m, int64_t n, int64_t nnz, i
    // (K=41: 1.80 against 2.05, K=128: 3.58 against 3.98)
    clear_error();
    if (m <= 0 || n <= 0 || nnz <= 0 || k < 4 || n >= (1LL << 24) || nnz < (1LL << 22) || nnz >= (1LL << 31)) return 0;
+   if (!stream_domain_ok(n, k, nnz)) return 0;
    const int st = k <= 32 ? 8 : 4;
    int rpw = 0, resident = 0;
    if (isplib_spmm_stream_minmax_geometry(st, &rpw, &resident) != ISPLIB_SUCCESS || rpw <= 0 || resident <= 0) return 0;

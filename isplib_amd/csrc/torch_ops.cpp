@@ -271,7 +271,9 @@ std::tuple<Tensor, Tensor> spmm_fw(const Tensor &rowptr_, const Tensor &col_, co
    if (reduction == R_MAX || reduction == R_MIN) arg = at::empty({M, K}, rowptr.options());
    const int64_t *rp = rowptr.data_ptr<int64_t>();
    const bool tasks_fit = K >= 4 && (double)N * (double)K * 4.0 <= 3.5 * 1073741824.0;
-   if (is_stream_plan(plan) && M > 0 && K > 0) {
+   // (a stream plan for a shape outside the stream entry's domain -- dense operand over 3.5 GiB, k < 4 -- is not an error:
+   // the graph is served by the kernels below, which read `col` / `value`)
+   if (is_stream_plan(plan) && M > 0 && K >= 4 && (double)N * (double)K * 4.0 <= 3.5 * 1073741824.0) {
       // the plan carries the edges (and the weights) in its own order: `col` / `value` are not read
       const isplib_stream_plan sp = stream_plan_of(plan);
       if (reduction == R_MAX || reduction == R_MIN) {

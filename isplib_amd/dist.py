@@ -37,6 +37,19 @@ def nnz_balanced_cuts(rowptr: torch.Tensor, world: int) -> List[int]:
     return out
 
 
+def _p2p_is_stream_ordered(group, device) -> bool:
+    """True when the group's point-to-point calls on `device` order themselves behind the current stream (RCCL)."""
+    if device.type != "cuda":
+        return True                                   # host tensors: nothing is queued anywhere
+    try:
+        name = str(dist.get_backend(group)).lower()
+    except Exception:                                 # noqa: BLE001 - an unknown backend is treated as unordered
+        return False
+    if "cuda:" in name:                               # "cpu:gloo,cuda:nccl"
+        name = name.split("cuda:", 1)[1].split(",", 1)[0]
+    return "nccl" in name or "rccl" in name
+
+
 class RowPartition:
     """This rank's slice of a CSR matrix whose columns index the row-sharded X."""
 
@@ -163,6 +176,15 @@ class RowPartition:
         P, r = self.world, self.rank
         works = []
         if P > 1:
+            # RCCL's send / receive are enqueued on a stream that waits for the caller's current stream.  Gloo's are not:
+            # its SendWork / RecvWork (ProcessGroupGloo.hpp:200-245 of the installed torch) hold a tensor and an unbound
+            # buffer over its data pointer and "are entirely completed by the device thread" -- no stream, no event,
+            # unlike the collectives (initializeStreamsEvents, ProcessGroupGlooDetail.hpp:100-108) -- so the transport
+            # reads `x_shard` and writes `buf` from the host the moment the call is posted, whatever the device still
+            # has queued.  Kernels that produce x_shard, or that still write buf (a fill, the previous step's readers),
+            # must therefore have finished before anything is posted.
+            if not _p2p_is_stream_ordered(self.group, x_shard.device):
+                torch.cuda.current_stream(x_shard.device).synchronize()
             batches = max(1, min(int(batches), P - 1))
             bounds = [1 + (P - 1) * b // batches for b in range(batches + 1)]
             for b in range(batches):

@@ -147,16 +147,17 @@ class SparseStorage:
         backward's value[csr2csc] / max(deg, 1); "minmax" (A only): value, on a plan of the max / min kernel's geometry
         with the permutation appended (geom = (streams, slices, chunk) from ``cabi.suggest_stream_minmax``).  The structure is built once per graph and geometry; the weights are
         re-gathered through the plan's permutation whenever `value` was replaced or written in place."""
-        from .plan import build_stream_plan
+        from .plan import build_stream_plan_native
         minmax = kind == "minmax"       # (A only) the max / min kernel's own geometry; None when rows are not column-sorted
         key = (bool(transposed),) + tuple(int(v) for v in geom) + (("minmax",) if minmax else ())
         plan = self._streams.get(key, False)
         if plan is False:
+            # the library's own builder (rocPRIM sorts: ~10 ms on the Reddit shape; the torch construction of plan.py,
+            # which produces the same arrays, takes 27-30 ms) -- the one-off cache build of isplib/__init__.py:76-106
             if transposed:
-                plan = build_stream_plan(self.colptr(), self.row_t(), None, self._sparse_sizes[0], geom[1], None, None, geom[0], geom[2])
+                plan = build_stream_plan_native(self.colptr(), self.row_t(), self._sparse_sizes[0], geom[1], geom[0], geom[2])
             else:
-                plan = build_stream_plan(self._rowptr, self._col, None, self._sparse_sizes[1], geom[1], None, None, geom[0], geom[2],
-                                         minmax=minmax)
+                plan = build_stream_plan_native(self._rowptr, self._col, self._sparse_sizes[1], geom[1], geom[0], geom[2], minmax=minmax)
             self._streams[key] = plan
             if plan is not None:
                 plan.meta = torch.tensor([plan.rows, plan.cols, plan.slices, plan.gens, plan.waves_per_gen, plan.rows_per_wave,

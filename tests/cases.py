@@ -97,3 +97,15 @@ def sum_tolerance(oracle, rowptr, col, val, x, rel=1e-5):
     """Per-element bound rel * sum_j |val_j * x_j| (BASELINE.md section 3 parity rule) + 1 ulp-ish floor."""
     mag, _ = oracle.spmm_fw(rowptr, col, np.abs(val), np.abs(x), "sum")
     return rel * mag + 1e-30
+
+
+def rowwise_relative_error(got, ref):
+    """||got_i - ref_i||_2 / ||ref_i||_2 per row (fp64 arithmetic), rows with ||ref_i|| = 0 skipped after checking that
+    got_i is zero there too: the conventional reading of BASELINE.json's "1e-5 relative fp32" for a row-producing op."""
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    den = np.sqrt((ref * ref).sum(1))
+    num = np.sqrt(((got - ref) ** 2).sum(1))
+    zero = den == 0
+    assert np.all(num[zero] == 0), "rows whose reference is exactly zero must be exactly zero"
+    return num[~zero] / den[~zero]

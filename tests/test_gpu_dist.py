@@ -103,18 +103,23 @@ for kk, geom in ((64, (4, 3, 200)), (41, (8, 2, 64)), (130, (2, 4, 500))):
 # the column-sliced SpMM over the all-gathered buffer, every reduction, arg included
 plan = part.plan(32, "sum", slices=2 * world)
 xk = cases.dense(n, 32, 11)
-shard, buf = part.shard(t(xk)), part.gather_buffer(32)
+shard_src, buf = part.shard(t(xk)), part.gather_buffer(32)
+shard = torch.zeros_like(shard_src)
 for red in ("sum", "mean", "max", "min"):
-    part.all_gather(shard, buf)
+    part.all_gather(shard_src, buf)
     want, want_arg = cabi.spmm_sliced(part.rowptr, part.col_padded, part.val, plan[1], plan[0], buf, red)
     for nb in sorted({{1, 2, max(world - 1, 1)}}):
-        buf.fill_(float("nan"))                     # nothing may be read before it has landed
-        # world=4 failed here ONCE (('sum', 1): out != want) and passed before and after without a code change to the
-        # exchange.  Suspected, not confirmed: gloo's receive path for device tensors does not order itself behind this
-        # stream's fill, so the NaNs can land on top of a shard that has already arrived (a hazard of this test only;
-        # RCCL's collectives wait for the issuing stream).  The assertion below reports NaN / mismatch counts so that a
-        # recurrence says whether that was it (NaNs) or a wrong slice range (finite values).
+        # Regression for the one red run of round 2 (world 4, ('sum', 1)): gloo's send / receive of a device tensor
+        # carry no stream or event, so they used to read the shard and write the buffer while the kernels producing
+        # both were still queued.  Here those kernels are held back behind a long sleep on the compute stream -- the
+        # shard is still zero and the NaN fill has not run when the exchange is posted -- and NOTHING in the test
+        # waits for them: RowPartition.post_direct has to (it does, for every backend that is not stream-ordered).
+        shard.zero_()
         torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda._sleep(60_000_000)               # ~25-30 ms of the compute stream
+        shard.copy_(shard_src)                      # the producer of what is sent
+        buf.fill_(float("nan"))                     # nothing may be read before it has landed
         out = torch.zeros((part.rows, 32), device=dev)
         arg = torch.zeros((part.rows, 32), dtype=torch.int64, device=dev) if red in ("max", "min") else None
         part.spmm_direct(shard, buf, out, (plan[0], plan[1], cabi.sliced_workspace(red, part.rows, 32, plan[0], dev)), red, arg, batches=nb)
@@ -126,6 +131,28 @@ for red in ("sum", "mean", "max", "min"):
     ref, _ = oracle.spmm_fw(rowptr, col, val, xk, red)
     if red in ("max", "min"):
         assert np.array_equal(want.cpu().numpy(), ref[part.row0:part.row0 + part.rows])
+# ... and the same delayed producers with the guard taken out: the exchange then ships the zeroed shard (and the late NaN
+# fill lands on top of what was received), which is what the guard is for.  One configuration, once.
+import isplib_amd.dist as idist
+guard = idist._p2p_is_stream_ordered
+idist._p2p_is_stream_ordered = lambda group, device: True
+try:
+    part.all_gather(shard_src, buf)
+    want, _ = cabi.spmm_sliced(part.rowptr, part.col_padded, part.val, plan[1], plan[0], buf, "sum")
+    shard.zero_()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda._sleep(60_000_000)
+    shard.copy_(shard_src)
+    buf.fill_(float("nan"))
+    out = torch.zeros((part.rows, 32), device=dev)
+    part.spmm_direct(shard, buf, out, (plan[0], plan[1], cabi.sliced_workspace("sum", part.rows, 32, plan[0], dev)), "sum", None, batches=1)
+    torch.cuda.synchronize()
+    bad = int((out != want).sum())
+    print("rank", rank, "unguarded exchange:", int(torch.isnan(out).sum()), "NaN,", bad, "mismatches")
+    assert bad > 0, "the unguarded gloo exchange was expected to race with the queued producers"
+finally:
+    idist._p2p_is_stream_ordered = guard
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")

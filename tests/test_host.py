@@ -408,6 +408,25 @@ def test_slice_rule_lives_in_the_c_abi_and_handle_entries_validate():
     L.isplib_graph_destroy(None)                                   # a no-op, like free(NULL)
 
 
+def test_stream_rule_offers_only_what_the_stream_entries_accept():
+    """The schedule rule and the entries it feeds share one domain: a shape the stream entry / plan builder would refuse
+    (dense operand beyond one 3.5 GiB buffer descriptor, 32-bit edge positions) is not offered the stream schedule, so it
+    reaches the task list / plain kernel as it did before the schedule existed instead of raising (round-2 advisor)."""
+    import ctypes
+    from isplib_amd import cabi
+    L = cabi.lib()
+
+    def offered(fn, m, n, nnz, k):
+        st, sl, ch = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        return bool(fn(m, n, nnz, k, ctypes.byref(st), ctypes.byref(sl), ctypes.byref(ch)))
+    for fn in (L.isplib_suggest_stream, L.isplib_suggest_stream_minmax):
+        assert offered(fn, 232965, 232965, 114615892, 64)                         # the Reddit shape: yes
+        assert not offered(fn, 1_000_000, 1_000_000, 500_000_000, 1024)           # 4.1 GB of y: one descriptor cannot hold it
+        assert offered(fn, 1_000_000, 1_000_000, 500_000_000, 512)                # 2 GB: fine
+        assert not offered(fn, 2_000_000, 2_000_000, (1 << 31) + 5, 64)           # edge positions beyond 32 bits
+    assert cabi.suggest_stream(1_000_000, 1_000_000, 500_000_000, 1024) is None   # what plugin.choose_stream asks
+
+
 def test_degree_skew_adjustment_of_the_slice_rule():
     from isplib_amd import plugin
     flat = torch.arange(0, 101 * 50, 50, dtype=torch.int64)                       # every row has 50 entries
@@ -437,6 +456,33 @@ def test_bench_self_launches_one_rank_per_gpu_and_refuses_missing_gpus():
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
                            capture_output=True, text=True, env=env, timeout=300)
         assert r.returncode != 0 and "refusing" in r.stderr and '"metric"' not in r.stdout
+    # the launcher parent counts devices from sysfs and never through torch.cuda / HIP / amdsmi
+    import ast
+    used = {}
+    for fn in ast.parse(src).body:
+        if isinstance(fn, ast.FunctionDef) and fn.name in ("self_launch", "visible_gpu_count", "launcher_command"):
+            used[fn.name] = {n.id for n in ast.walk(fn) if isinstance(n, ast.Name)} | \
+                            {a_.name.split(".")[0] for n in ast.walk(fn) if isinstance(n, (ast.Import, ast.ImportFrom)) for a_ in n.names}
+    assert set(used) == {"self_launch", "visible_gpu_count", "launcher_command"}
+    for name, ids in used.items():
+        assert not ids & {"torch", "ctypes", "amdsmi", "cabi", "isplib_amd"}, f"{name} must not reach HIP: {ids}"
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        sysfs, dri = os.path.join(tmp, "nodes"), os.path.join(tmp, "dri")
+        os.makedirs(dri)
+        for i, (simd, minor) in enumerate(((0, -1), (0, -1), (1024, 128), (1024, 129), (1024, 130), (1024, 131))):   # 2 CPU + 4 GPU nodes
+            os.makedirs(os.path.join(sysfs, str(i)))
+            with open(os.path.join(sysfs, str(i), "properties"), "w") as f:
+                f.write(f"cpu_cores_count {0 if simd else 64}\nsimd_count {simd}\ndrm_render_minor {minor}\ngfx_target_version 90500\n")
+            if simd and minor != 131:                                   # the fourth GPU's render node is not ours to open
+                open(os.path.join(dri, f"renderD{minor}"), "w").close()
+        count = lambda **env: bench.visible_gpu_count(sysfs, dri, env)  # noqa: E731
+        assert count() == 3
+        assert count(HIP_VISIBLE_DEVICES="0,2") == 2 and count(ROCR_VISIBLE_DEVICES="1") == 1
+        assert count(ROCR_VISIBLE_DEVICES="0,1", HIP_VISIBLE_DEVICES="0,1,2") == 2      # the second list indexes what the first left
+        assert count(HIP_VISIBLE_DEVICES="0,7,1") == 1 and count(HIP_VISIBLE_DEVICES="") == 0 and count(CUDA_VISIBLE_DEVICES="-1") == 0
+        assert count(ROCR_VISIBLE_DEVICES="GPU-0123456789abcdef") == 1
+        assert bench.visible_gpu_count(os.path.join(tmp, "missing"), dri, {}) in (0, None)
     # a launcher that disagrees with --gpus is an error too, not a silent single-rank run
     env2 = dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True, env=env2, timeout=300)
