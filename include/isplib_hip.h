@@ -406,6 +406,66 @@ int    fusedMM_csr_stream_hip(int32_t imessage /* ISPLIB_MSG_SPMM_SUM | _MEAN */
                               void *workspace, size_t workspace_bytes,
                               const isplib_epilogue *epilogue /*host, may be NULL*/, void *stream);
 
+/* The plain row-per-wave kernel of fusedMM_csr_hip with the rows taken in a caller-given ORDER (`row_order`: position ->
+ * row, a permutation of [0, m), [dev] int32; NULL = fusedMM_csr_hip).  For operands larger than the Infinity Cache (the
+ * ogbn-products shape: y = 2.5 GB) no schedule of this library reuses a gathered row -- unless rows that share neighbours
+ * are worked on at the same time on the same XCD: the workgroups of an XCD walk a contiguous range of positions, so a
+ * community-grouped order (isplib_amd/reorder.py: label propagation, once per graph) turns the gathers of a community's
+ * rows into hits of that XCD's L2.  Nothing is moved: y is gathered and z written where they are, every row is computed
+ * by the same code in the same edge order -- the result is bit for bit that of fusedMM_csr_hip for any order.
+ * No reference counterpart (the reference's CPU kernel walks rows in index order, csrc/fusedmm.cpp:198). */
+int    fusedMM_csr_ordered_hip(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t nnz, const float *val,
+                               const int64_t *indx, const int64_t *pntrb, const int64_t *pntre,
+                               const int32_t *row_order /*[dev] m | NULL*/, const float *y, int64_t ldy, float *z,
+                               int64_t ldz, int64_t *z_arg, void *stream);
+
+/* SDDMM over a stream plan (the dA of sum / mean: dval[e] = <y[col[e], :], g[row(e), :]>, / max(deg, 1) for mean -- the
+ * call the reference leaves commented out, csrc/fusedmm.cpp:270,351).  Same edges and same gathers of y as the SpMM, so
+ * the same plan (a sum / mean plan of isplib_spmm_stream_geometry WITH its perm array; weights in the plan are ignored)
+ * and the same front end; the wave's rows of g sit in LDS where the SpMM keeps its accumulators, every step yields one
+ * dot product per slot, and a batch's results are stored through `perm` once.  k is swept in panels of 256 / streams
+ * columns; later panels add to what earlier ones stored.  Plain stores by the one owner of every edge: bitwise
+ * reproducible.  k >= 4, n < 2^24, ldy < 2^22, n*ldy*4 <= 3.5 GiB, nnz < 2^31. */
+int    isplib_sddmm_stream_hip(int64_t m, int64_t n, int64_t k, int64_t nnz, const int64_t *pntrb, const int64_t *pntre,
+                               const isplib_stream_plan *plan /*host*/, const float *y, int64_t ldy,
+                               const float *g /*[dev] m x ldg*/, int64_t ldg, int mean, float *dval /*[dev] nnz*/, void *stream);
+
+/*
+ * Hybrid form of the stream schedule (sum / mean, unit weights): north_star's "dense feature tiles staged through LDS".
+ * What bounds fusedMM_csr_stream_hip is the CU's address pipeline -- every gathered row of y crosses it whether the L2
+ * hits or not -- so the only gathered bytes that cost less are bytes that do not cross it.  The plan picks, per column
+ * slice, the table_rows - 1 most-referenced rows of y (in-degree; the same table for every workgroup); a workgroup of
+ * 8 waves (one per CU: 128 KB of row accumulators + a 32 KB table) stages the table of a slice ONCE by LDS-DMA
+ * (buffer_load ... lds) and serves the edges that point into it -- the "hot" words, (local row << 24) | table row --
+ * with ds_read_b128, while the remaining "cold" edges run through the gather pipeline exactly as in the stream form
+ * (`cold` is a complete stream plan of those edges; its `slices` is also the number of phases the hot chunks are
+ * interleaved at).  Two workgroup barriers per slice order table reuse; nothing drains the gather pipeline.  A row's
+ * contributions are added in the program order of the one wave that owns it: bitwise reproducible, no atomics.
+ * Same operand requirements as fusedMM_csr_stream_hip; cold.vals must be NULL (weighted graphs stay on the stream
+ * form).  isplib_spmm_hybrid_geometry reports, per slot width (streams 4: 64-column panels, 8: 32-column panels), what
+ * a plan must be built for: rows per wave, resident waves (waves_per_gen; a multiple of 8), table rows and the most hot
+ * steps one wave may have in one slice (edges beyond it stay cold).  No reference counterpart: supersedes
+ * gpu/kernels/spmm.cuh:3-23 (thread per row, straight to global memory).
+ */
+typedef struct isplib_hybrid_plan {
+   isplib_stream_plan cold;         /* the edges that stay on the gather path; cold.slices = phases */
+   int32_t table_rows;              /* rows of the per-slice LDS table; the last one is all zero (padding words point at it) */
+   int32_t hot_cap;                 /* most hot steps of one wave in one slice */
+   int64_t n_hot_steps;
+   const int32_t *hot_rows;         /* [dev] slices*table_rows: column id of every table row; n = unused / the zero row */
+   const int32_t *hot_words;        /* [dev] n_hot_steps*streams: (local row << 24) | table row, chunk by chunk */
+   const int64_t *hot_step_off;     /* [dev] gens*waves_per_gen*slices + 1: first hot step of a (wave, slice) chunk */
+   const int32_t *hot_perm;         /* [dev] n_hot_steps*streams: CSR position of every hot word, -1 = padding; may be NULL */
+} isplib_hybrid_plan;
+int    isplib_spmm_hybrid_geometry(int streams /* 4 | 8 */, int *rows_per_wave, int *waves_resident, int *table_rows, int *hot_cap);
+size_t isplib_spmm_hybrid_workspace_bytes(const isplib_hybrid_plan *plan);
+int    fusedMM_csr_hybrid_hip(int32_t imessage /* ISPLIB_MSG_SPMM_SUM | _MEAN */, int64_t m, int64_t n, int64_t k,
+                              int64_t nnz, const int64_t *pntrb, const int64_t *pntre,
+                              const isplib_hybrid_plan *plan /*host*/,
+                              const float *y, int64_t ldy, float *z, int64_t ldz,
+                              void *workspace, size_t workspace_bytes,
+                              const isplib_epilogue *epilogue /*host, may be NULL*/, void *stream);
+
 /* Tuning knobs for experiments (process-wide, not thread-safe; every setting gives the same results):
  *   0  lanes per row slot of the row kernels (0 = by k)      1  0: 64-bit addressing instead of buffer descriptors
  *   2  consecutive tasks per wave of the task kernel (0=auto) 4  column-panel width of the task entries, sum / mean (64)

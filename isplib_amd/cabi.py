@@ -53,6 +53,8 @@ EXPORTS = (
     "isplib_graph_destroy", "isplib_suggest_slices_whole_rows", "isplib_graph_sddmm",
     "fusedMM_csr_sweep_hip", "isplib_spmm_sweep_workspace_bytes", "isplib_spmm_sweep_resident_waves",
     "fusedMM_csr_stream_hip", "isplib_spmm_stream_workspace_bytes", "isplib_spmm_stream_geometry", "isplib_suggest_stream", "isplib_stream_plan_build_hip", "isplib_stream_plan_build_minmax_hip", "fusedMM_csr_stream_minmax_hip", "isplib_spmm_stream_minmax_geometry", "isplib_suggest_stream_minmax", "isplib_spmm_stream_minmax_workspace_bytes", "isplib_stream_plan_set_values_hip", "isplib_stream_plan_free", "isplib_spmm_minmax_bw_det_hip", "isplib_spmm_minmax_bw_workspace_bytes",
+    "fusedMM_csr_hybrid_hip", "isplib_spmm_hybrid_geometry", "isplib_spmm_hybrid_workspace_bytes", "isplib_sddmm_stream_hip",
+    "fusedMM_csr_ordered_hip",
 )
 
 _i64, _f32, _vp, _i32 = ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_int32
@@ -83,6 +85,12 @@ class StreamPlanStruct(ctypes.Structure):  # isplib_stream_plan
                 ("words", ctypes.c_void_p), ("vals", ctypes.c_void_p), ("wave_step_off", ctypes.c_void_p),
                 ("wave_row", ctypes.c_void_p), ("wave_part", ctypes.c_void_p),
                 ("hub_row", ctypes.c_void_p), ("hub_off", ctypes.c_void_p), ("perm", ctypes.c_void_p)]
+
+
+class HybridPlanStruct(ctypes.Structure):  # isplib_hybrid_plan
+    _fields_ = [("cold", StreamPlanStruct), ("table_rows", ctypes.c_int32), ("hot_cap", ctypes.c_int32), ("n_hot_steps", ctypes.c_int64),
+                ("hot_rows", ctypes.c_void_p), ("hot_words", ctypes.c_void_p), ("hot_step_off", ctypes.c_void_p),
+                ("hot_perm", ctypes.c_void_p)]
 
 
 _sigs_set = False
@@ -194,6 +202,18 @@ def lib() -> ctypes.CDLL:
         L.isplib_stream_plan_set_values_hip.argtypes = [ctypes.POINTER(StreamPlanStruct), _vp, _vp]
         L.isplib_stream_plan_free.restype = None
         L.isplib_stream_plan_free.argtypes = [ctypes.POINTER(StreamPlanStruct)]
+        L.isplib_spmm_hybrid_geometry.restype = ctypes.c_int
+        L.isplib_spmm_hybrid_geometry.argtypes = [ctypes.c_int] + [ctypes.POINTER(ctypes.c_int)] * 4
+        L.isplib_spmm_hybrid_workspace_bytes.restype = ctypes.c_size_t
+        L.isplib_spmm_hybrid_workspace_bytes.argtypes = [ctypes.POINTER(HybridPlanStruct)]
+        L.fusedMM_csr_hybrid_hip.restype = ctypes.c_int
+        L.fusedMM_csr_hybrid_hip.argtypes = [_i32, _i64, _i64, _i64, _i64, _vp, _vp, ctypes.POINTER(HybridPlanStruct), _vp, _i64, _vp, _i64,
+                                             _vp, ctypes.c_size_t, _vp, _vp]
+        L.fusedMM_csr_ordered_hip.restype = ctypes.c_int
+        L.fusedMM_csr_ordered_hip.argtypes = [_i32, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp]
+        L.isplib_sddmm_stream_hip.restype = ctypes.c_int
+        L.isplib_sddmm_stream_hip.argtypes = [_i64, _i64, _i64, _i64, _vp, _vp, ctypes.POINTER(StreamPlanStruct), _vp, _i64, _vp, _i64,
+                                              ctypes.c_int, _vp, _vp]
         L.isplib_suggest_stream.restype = ctypes.c_int
         L.isplib_suggest_stream.argtypes = [_i64, _i64, _i64, _i64, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
         L.isplib_spmm_stream_geometry.restype = ctypes.c_int
@@ -273,6 +293,35 @@ def fusedMM_csr_hip(imessage: int, rowptr: torch.Tensor, col: torch.Tensor, val:
     if check:
         _check(st, "fusedMM_csr_hip")
     return st
+
+
+def fusedMM_csr_ordered_hip(imessage: int, rowptr, col, val, order, y, z, z_arg=None, check: bool = True) -> int:
+    """The plain kernel with the rows taken in `order` (int32 [m], position -> row; None = fusedMM_csr_hip)."""
+    rowptr = _dev(rowptr, "rowptr", torch.int64)
+    col = _dev(col, "col", torch.int64)
+    if order is not None:
+        order = _dev(order, "order", torch.int32)
+        assert order.numel() == rowptr.numel() - 1
+    assert y.is_cuda and z.is_cuda and y.dtype == torch.float32 and z.dtype == torch.float32 and y.stride(1) == 1 and z.stride(1) == 1
+    m, n, k = rowptr.numel() - 1, y.size(0), y.size(1)
+    rp = rowptr.data_ptr()
+    with torch.cuda.device(y.device):
+        st = lib().fusedMM_csr_ordered_hip(int(imessage), m, n, k, col.numel(), _ptr(val), _ptr(col), ctypes.c_void_p(rp),
+                                           ctypes.c_void_p(rp + 8), _ptr(order), _ptr(y), y.stride(0) if n > 1 else max(k, y.stride(0)),
+                                           _ptr(z), z.stride(0) if m > 1 else max(k, z.stride(0)), _ptr(z_arg), _stream(y.device))
+    if check:
+        _check(st, "fusedMM_csr_ordered_hip")
+    return st
+
+
+def spmm_ordered(rowptr, col, val, order, y, reduce: str = "sum"):
+    """Allocate the outputs and call the ordered plain kernel; returns (out, arg|None)."""
+    y = y.contiguous()
+    m, k = rowptr.numel() - 1, y.size(1)
+    out = torch.empty((m, k), dtype=torch.float32, device=y.device)
+    arg = torch.empty((m, k), dtype=torch.int64, device=y.device) if reduce in ("max", "min") else None
+    fusedMM_csr_ordered_hip(MESSAGE[reduce], rowptr, col, val, order, y, out, arg)
+    return out, arg
 
 
 def fusedmm(imessage: int, rowptr, col, val, x, y, sop_udef="none", sop_param: float = 0.0, check: bool = True, plan=None):
@@ -522,6 +571,22 @@ def spmm_tasks(rowptr, col, val, plan, y, reduce: str = "sum", workspace=None):
     return out, arg
 
 
+def sddmm_stream(rowptr, nnz: int, plan, y, g, mean: bool = False):
+    """dA over the stream plan of the SpMM (isplib_sddmm_stream_hip): dval[e] = <y[col[e]], g[row(e)]> (/ max(deg, 1))."""
+    rowptr = _dev(rowptr, "rowptr", torch.int64)
+    y, g = y.contiguous(), g.contiguous()
+    m, n, k = rowptr.numel() - 1, y.size(0), y.size(1)
+    assert g.size(0) == m and g.size(1) == k
+    dval = torch.empty(int(nnz), dtype=torch.float32, device=y.device)
+    rp = rowptr.data_ptr()
+    ps = plan.struct()
+    with torch.cuda.device(y.device):
+        st = lib().isplib_sddmm_stream_hip(m, n, k, int(nnz), ctypes.c_void_p(rp), ctypes.c_void_p(rp + 8), ctypes.byref(ps), _ptr(y), k,
+                                           _ptr(g), k, int(bool(mean)), _ptr(dval), _stream(y.device))
+    _check(st, "isplib_sddmm_stream_hip")
+    return dval
+
+
 def sddmm_tasks(rowptr, col, plan, y, g, mean: bool = False):
     """dA over the task plan of the SpMM (isplib_sddmm_csr_tasks_hip)."""
     rowptr = _dev(rowptr, "rowptr", torch.int64)
@@ -676,6 +741,46 @@ def stream_minmax_geometry(streams: int = 4):
     rpw, res = ctypes.c_int(0), ctypes.c_int(0)
     _check(lib().isplib_spmm_stream_minmax_geometry(int(streams), ctypes.byref(rpw), ctypes.byref(res)), "isplib_spmm_stream_minmax_geometry")
     return rpw.value, res.value
+
+
+def hybrid_geometry(streams: int = 4):
+    """(rows per wave, resident waves, table rows, hot-step cap per wave and slice) of the hybrid kernel (isplib_spmm_hybrid_geometry)."""
+    v = [ctypes.c_int(0) for _ in range(4)]
+    _check(lib().isplib_spmm_hybrid_geometry(int(streams), *[ctypes.byref(x) for x in v]), "isplib_spmm_hybrid_geometry")
+    return tuple(x.value for x in v)
+
+
+def fusedMM_csr_hybrid_hip(imessage: int, rowptr, nnz: int, plan, y, z, workspace=None, epilogue=None, check: bool = True) -> int:
+    """Raw boundary call of the hybrid-form SpMM (sum / mean, unit weights); ``plan`` is an isplib_amd.plan.HybridPlan."""
+    assert y.is_cuda and y.dtype == torch.float32 and y.dim() == 2 and y.stride(1) == 1
+    m, n, k = rowptr.numel() - 1, y.size(0), y.size(1)
+    rp = rowptr.data_ptr()
+    ps = plan.struct()
+    with torch.cuda.device(y.device):
+        st = lib().fusedMM_csr_hybrid_hip(int(imessage), m, n, k, int(nnz), ctypes.c_void_p(rp), ctypes.c_void_p(rp + 8),
+                                          ctypes.byref(ps), _ptr(y), y.stride(0) if n > 1 else max(k, y.stride(0)), _ptr(z),
+                                          z.stride(0) if m > 1 else max(k, z.stride(0)), _ptr(workspace),
+                                          0 if workspace is None else workspace.numel(),
+                                          None if epilogue is None else ctypes.byref(epilogue), _stream(y.device))
+    if check:
+        _check(st, "fusedMM_csr_hybrid_hip")
+    return st
+
+
+def spmm_hybrid(rowptr, nnz: int, plan, y, reduce: str = "sum", workspace=None, row_scale=None, self_term=None, bias=None, relu=False):
+    """Allocate the output (+ workspace) and call the hybrid boundary; returns out."""
+    rowptr = _dev(rowptr, "rowptr", torch.int64)
+    y = y.contiguous()
+    m, k = rowptr.numel() - 1, y.size(1)
+    out = torch.empty((m, k), dtype=torch.float32, device=y.device)
+    if workspace is None:
+        workspace = plan.workspace()
+    ep = None
+    if row_scale is not None or self_term is not None or bias is not None or relu:
+        ep = Epilogue(None if row_scale is None else row_scale.data_ptr(), None if self_term is None else self_term.data_ptr(),
+                      k if self_term is None else self_term.stride(0), None if bias is None else bias.data_ptr(), int(bool(relu)))
+    fusedMM_csr_hybrid_hip(MESSAGE[reduce], rowptr, nnz, plan, y, out, workspace, ep)
+    return out
 
 
 def suggest_stream(m: int, n: int, nnz: int, k: int):

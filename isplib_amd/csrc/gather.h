@@ -308,8 +308,56 @@ template <int OP, int LPR, int NCH, int ADDR> constexpr int min_waves_of() {
 // keeps the values whose index bit matches its own lane bit and hands the others over), so U values cost
 // U-1 + log2(LPR) - log2(U) shuffles instead of U * log2(LPR).  Returns the finished sum of edge `mine`
 // (valid in every lane of the owning LPR/U-lane group).
+// x of lane (lane ^ O) for O = 1, 2, 4, 8 by data-parallel-primitive moves inside the 16-lane DPP row -- no LDS round trip
+// and no wait, where a ds_bpermute costs both (SDDMM on the stream plan: 4.50 -> ... ms); wider
+// partners cross DPP rows and stay on ds_bpermute.  gfx9 has no row_xmask: xor 1 / 2 are quad permutations, xor 8 is
+// the row rotated by 8, xor 4 is the half-row mirror (i -> 7 - i) followed by the quad reversal (j -> 3 - j).
+template <int O> __device__ __forceinline__ float lane_xor(float x) {
+   if constexpr (O == 1 || O == 2 || O == 4 || O == 8) {
+      int v = __float_as_int(x);
+      if constexpr (O == 1) v = __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);          // quad_perm:[1,0,3,2]
+      else if constexpr (O == 2) v = __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);     // quad_perm:[2,3,0,1]
+      else if constexpr (O == 8) v = __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, false);    // row_ror:8
+      else {
+         v = __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);                            // row_half_mirror
+         v = __builtin_amdgcn_update_dpp(0, v, 0x1B, 0xF, 0xF, false);                             // quad_perm:[3,2,1,0]
+      }
+      return __int_as_float(v);
+   } else {
+      return __shfl_xor(x, O);
+   }
+}
+
+template <int U, int N, int O> struct transposed_steps {
+   __device__ __forceinline__ static void run(float (&d)[U], int lc, int &mine) {
+      if constexpr (N > 1) {
+         const bool hi = (lc & O) != 0;
+         mine |= hi ? (N >> 1) : 0;
+#pragma unroll
+         for (int i = 0; i < N / 2; i++) {
+            const float send = hi ? d[i] : d[i + N / 2];
+            const float keep = hi ? d[i + N / 2] : d[i];
+            d[i] = keep + lane_xor<O>(send);
+         }
+         transposed_steps<U, N / 2, O / 2>::run(d, lc, mine);
+      } else if constexpr (O >= 1) {
+         d[0] += lane_xor<O>(d[0]);
+         transposed_steps<U, 1, O / 2>::run(d, lc, mine);
+      }
+   }
+};
+
 template <int U, int LPR>
 __device__ __forceinline__ float reduce_transposed(float (&d)[U], int lc, int &mine) {
+   static_assert(U == 1 || U == 2 || U == 4 || U == 8, "U must be a power of two <= 8");
+   static_assert(LPR >= U, "slot narrower than the values to transpose");
+   mine = 0;
+   transposed_steps<U, U, LPR / 2>::run(d, lc, mine);
+   return d[0];
+}
+
+template <int U, int LPR>
+__device__ __forceinline__ float reduce_transposed_bpermute(float (&d)[U], int lc, int &mine) {
    static_assert(U == 1 || U == 2 || U == 4 || U == 8, "U must be a power of two <= 8");
    static_assert(LPR >= U, "slot narrower than the values to transpose");
    mine = 0;
@@ -350,5 +398,6 @@ template <int OP, int LPR, int NCH, int ADDR> constexpr bool pipelined_tasks() {
 // tuning knobs (isplib_hip_tune), defined in spmm.hip
 extern int g_force_lpr, g_addr_mode, g_tasks_per_wave, g_panel_cols, g_panel_cols_minmax, g_one_pass_kib;
 extern int g_sweep_panel;    // defined in spmm_sweep.hip
+extern int g_stream_merge_gens;   // defined in spmm_sweep.hip
 
 }  // namespace isplib

@@ -294,45 +294,63 @@ static int skew_adjusted(Side &s, int slices, hipStream_t st, int cap = 64) {
    return more > cap ? cap : more;
 }
 
+// The side's sum / mean stream plan for width k, built on first use with the weights `val` (NULL: unit weights); *out stays
+// null where the stream schedule does not serve the shape (the rule, a forced slice count, a refusal of the builder, no
+// room for the plan): not an error, the caller's other schedules take the call.
+static int side_stream_plan(isplib_graph *g, Side &s, const float *val, int64_t k, int64_t ldy, hipStream_t st, Side::Stream **out) {
+   *out = nullptr;
+   int st_streams = 0, st_slices = 0, st_chunk = 0;
+   const bool y_in_one_descriptor = (double)s.n * (double)ldy * 4.0 <= 3.5 * 1073741824.0;      // with the caller's ldy, not k
+   if (g->forced_slices >= 0 || s.stream_refused || ldy >= (1LL << 22) || !y_in_one_descriptor ||
+       !isplib_suggest_stream(s.m, s.n, s.nnz, k, &st_streams, &st_slices, &st_chunk))
+      return ISPLIB_SUCCESS;
+   st_slices = skew_adjusted(s, st_slices, st, 512);      // no degree skew: slices closer to the L2 size (31 -> 47: 3.21 -> 3.00 ms)
+   const uint64_t key = ((uint64_t)st_streams << 48) | ((uint64_t)st_slices << 32) | (uint64_t)(uint32_t)st_chunk;
+   auto it = s.streams.find(key);
+   if (it == s.streams.end()) {
+      Side::Stream fresh;
+      const int rc = isplib_stream_plan_build_hip(s.m, s.n, s.nnz, s.rowptr, s.col, val, st_streams, st_slices, st_chunk, 0, &fresh.plan, st);
+      if (rc == ISPLIB_SUCCESS) {
+         fresh.vals_of = val; fresh.has_vals = val != nullptr; fresh.gen = g->val_gen;
+         it = s.streams.emplace(key, fresh).first;
+      } else if (rc == ISPLIB_FAIL) {
+         s.stream_refused = true;                  // outside the builder's domain: not an error of this call; the
+         clear_error();                            // task list / plain kernel serve the graph
+         return ISPLIB_SUCCESS;
+      } else if (rc != ISPLIB_NOT_ENOUGH_MEM) {
+         return rc;
+      } else {
+         clear_error();                            // no room for the plan: the task list / plain kernel need less
+         return ISPLIB_SUCCESS;
+      }
+   }
+   *out = &it->second;
+   return ISPLIB_SUCCESS;
+}
+
 static int run_side(isplib_graph *g, Side &s, const float *val, int32_t imessage, int64_t k, const float *y, int64_t ldy,
                     float *z, int64_t ldz, int64_t *z_arg, hipStream_t st) {
    if (val && val == s.val && weights_are_unit(s, st) == 1) val = nullptr;
    const int minmax = (imessage & 0xF0000) != ISPLIB_AOP_ADD;
    // sum / mean on graphs with work for the whole chip: the stream schedule (rows resident in LDS, the plan's own copy of
    // the edges), unless a slice count was forced
-   int st_streams = 0, st_slices = 0, st_chunk = 0;
    const bool y_in_one_descriptor = (double)s.n * (double)ldy * 4.0 <= 3.5 * 1073741824.0;      // with the caller's ldy, not k
-   if (!minmax && g->forced_slices < 0 && !s.stream_refused && ldy < (1LL << 22) && y_in_one_descriptor &&
-       isplib_suggest_stream(s.m, s.n, s.nnz, k, &st_streams, &st_slices, &st_chunk)) {
-      st_slices = skew_adjusted(s, st_slices, st, 512);      // no degree skew: slices closer to the L2 size (31 -> 47: 3.21 -> 3.00 ms)
-      const uint64_t key = ((uint64_t)st_streams << 48) | ((uint64_t)st_slices << 32) | (uint64_t)(uint32_t)st_chunk;
-      auto it = s.streams.find(key);
-      if (it == s.streams.end()) {
-         Side::Stream fresh;
-         const int rc = isplib_stream_plan_build_hip(s.m, s.n, s.nnz, s.rowptr, s.col, val, st_streams, st_slices, st_chunk, 0, &fresh.plan, st);
-         if (rc == ISPLIB_SUCCESS) {
-            fresh.vals_of = val; fresh.has_vals = val != nullptr; fresh.gen = g->val_gen;
-            it = s.streams.emplace(key, fresh).first;
-         } else if (rc == ISPLIB_FAIL) {
-            s.stream_refused = true;                  // outside the builder's domain: not an error of this call; the
-            clear_error();                            // task list / plain kernel below serve the graph
-         } else if (rc != ISPLIB_NOT_ENOUGH_MEM) {
-            return rc;
-         }                                           // no room for the plan: the task list / plain kernel below need less
-      }
-      if (it != s.streams.end()) {
-         Side::Stream &sp = it->second;
-         if (sp.vals_of != val || sp.has_vals != (val != nullptr) || (val && sp.gen != g->val_gen)) {
+   if (!minmax) {
+      Side::Stream *sp = nullptr;
+      int rc = side_stream_plan(g, s, val, k, ldy, st, &sp);
+      if (rc) return rc;
+      if (sp) {
+         if (sp->vals_of != val || sp->has_vals != (val != nullptr) || (val && sp->gen != g->val_gen)) {
             // other weights than last time (sum vs mean backward), or new contents (isplib_graph_set_values)
-            const int rc = isplib_stream_plan_set_values_hip(&sp.plan, val, st);
+            rc = isplib_stream_plan_set_values_hip(&sp->plan, val, st);
             if (rc) return rc;
-            sp.vals_of = val; sp.has_vals = val != nullptr; sp.gen = g->val_gen;
+            sp->vals_of = val; sp->has_vals = val != nullptr; sp->gen = g->val_gen;
          }
-         const size_t need = isplib_spmm_stream_workspace_bytes(&sp.plan);
+         const size_t need = isplib_spmm_stream_workspace_bytes(&sp->plan);
          isplib_graph::Work *w = nullptr;
-         const int rc = ensure_work(g, need, st, &w);
+         rc = ensure_work(g, need, st, &w);
          if (rc) return rc;
-         return fusedMM_csr_stream_hip(imessage, s.m, s.n, k, s.nnz, s.rowptr, s.rowptr + 1, &sp.plan, y, ldy, z, ldz, w->ptr, w->bytes, nullptr, st);
+         return fusedMM_csr_stream_hip(imessage, s.m, s.n, k, s.nnz, s.rowptr, s.rowptr + 1, &sp->plan, y, ldy, z, ldz, w->ptr, w->bytes, nullptr, st);
       }
    }
    // max / min on such graphs: the stream schedule's own kernel and plan geometry, for column-sorted rows
@@ -527,6 +545,16 @@ extern "C" int isplib_graph_sddmm(isplib_graph *g, int mean, int64_t k, const fl
    if (!g) return fail(ISPLIB_FAIL, "isplib_graph_sddmm: null handle");
    hipStream_t st = (hipStream_t)stream;
    Side &s = g->fwd;
+   // the forward's stream plan where there is one (same edges, same gathers: the SpMM's front end with g's rows in LDS;
+   // dA does not read the weights, a plan that carries some is used as it is)
+   if (k >= 4 && s.nnz < (1LL << 31)) {
+      Side::Stream *sp = nullptr;
+      const float *val_new = (s.val && weights_are_unit(s, st) != 1) ? s.val : nullptr;      // what a plan built here should carry
+      const int rc = side_stream_plan(g, s, val_new, k, ldy, st, &sp);
+      if (rc) return rc;
+      if (sp && sp->plan.perm)
+         return isplib_sddmm_stream_hip(s.m, s.n, k, s.nnz, s.rowptr, s.rowptr + 1, &sp->plan, y, ldy, gm, ldg, mean, dval, st);
+   }
    int slices = g->forced_slices >= 0 ? g->forced_slices : isplib_suggest_slices_whole_rows(s.m, s.n, s.nnz, k);
    if (k < 4 || k > 1024 || (double)s.n * (double)ldy * 4.0 > 3.5 * 1073741824.0) slices = 0;
    if (slices > 0) {

@@ -52,6 +52,11 @@ struct SpmmArgs {
    int slices, slice_first, slice_count, combine;
    float *part_val;        // [slices][m][k] partial results
    int *part_idx;          // [slices][m][k] row-relative edge ids (max/min), INT_MAX = none
+   // plain mode only (fusedMM_csr_ordered_hip): position -> row, a permutation of [0, m); the workgroups of an XCD walk
+   // a contiguous range of POSITIONS, so rows that share neighbours and sit next to each other in the order share that
+   // XCD's L2 while they are worked on.  Every row is still computed by the same code in the same edge order: any
+   // order gives the same bits.  Null = the identity.
+   const int32_t *row_order;
 };
 
 template <int OP, int VEC, int NCH>
@@ -163,10 +168,10 @@ __global__ __launch_bounds__(WAVES * 64, (min_waves_of<OP, LPR, NCH, ADDR>())) v
    }
 
    const int64_t row0 = (int64_t)lb * WAVES;
-   const int64_t row = row0 + wave;
+   const int64_t row = (!SLICED && a.row_order && row0 + wave < a.m) ? (int64_t)a.row_order[row0 + wave] : row0 + wave;
 
    // phase 1: one row per wave (rows up to long_row edges)
-   if (row < a.m) {
+   if (row0 + wave < a.m) {
       int64_t b, e, row_b;
       if (SLICED) {
          const int64_t *sp = a.sliceptr + (size_t)row * (size_t)(a.slices + 1) + slice;
@@ -195,8 +200,8 @@ __global__ __launch_bounds__(WAVES * 64, (min_waves_of<OP, LPR, NCH, ADDR>())) v
 
    // phase 2: long rows of this block, all waves on one row at a time
    for (int r = 0; r < WAVES; r++) {
-      const int64_t lr = row0 + r;
-      if (lr >= a.m) break;                        // uniform over the block
+      if (row0 + r >= a.m) break;                  // uniform over the block
+      const int64_t lr = (!SLICED && a.row_order) ? (int64_t)a.row_order[row0 + r] : row0 + r;
       int64_t b, e, row_b;
       if (SLICED) {
          const int64_t *sp = a.sliceptr + (size_t)lr * (size_t)(a.slices + 1) + slice;
@@ -405,7 +410,7 @@ static int spmm_entry(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t
                       const int64_t *indx, const int64_t *pntrb, const int64_t *pntre, const float *y, int64_t ldy,
                       float beta, float *z, int64_t ldz, int64_t *z_arg, const int64_t *sliceptr, int slices,
                       int slice_first, int slice_count, int combine, void *workspace, size_t workspace_bytes,
-                      void *stream) {
+                      void *stream, const int32_t *row_order = nullptr) {
    clear_error();
    const int32_t vop = imessage & 0xF, rop = imessage & 0xF0, sop = imessage & 0xF00, vsc = imessage & 0xF000,
                  aop = imessage & 0xF0000;
@@ -438,6 +443,7 @@ static int spmm_entry(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t
    }
    a.sliceptr = nullptr; a.slices = 1; a.slice_first = 0; a.slice_count = 0; a.combine = 0;
    a.part_val = nullptr; a.part_idx = nullptr;
+   a.row_order = row_order;
    if (sliceptr) {
       if (slices < 1 || slices > ISPLIB_MAX_SLICES) return fail(ISPLIB_FAIL, "fusedMM_csr_sliced_hip: slices must be in [1, 4096]");
       const size_t need = isplib_spmm_sliced_workspace_bytes(imessage, m, k, slices);
@@ -470,6 +476,18 @@ extern "C" int fusedMM_csr_hip(int32_t imessage, int64_t m, int64_t n, int64_t k
                                   z, ldz, z_arg, ISPLIB_SOP_NONE, 0.0f, stream);
    return spmm_entry(imessage, m, n, k, nnz, val, indx, pntrb, pntre, y, ldy, beta, z, ldz, z_arg, nullptr, 1, 0, 0, 0,
                      nullptr, 0, stream);
+}
+
+extern "C" int fusedMM_csr_ordered_hip(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t nnz, const float *val,
+                                       const int64_t *indx, const int64_t *pntrb, const int64_t *pntre,
+                                       const int32_t *row_order, const float *y, int64_t ldy, float *z, int64_t ldz,
+                                       int64_t *z_arg, void *stream) {
+   if (m >= (1LL << 31)) {
+      clear_error();
+      return fail(ISPLIB_FAIL, "fusedMM_csr_ordered_hip: m must be < 2^31 (32-bit row order)");
+   }
+   return spmm_entry(imessage, m, n, k, nnz, val, indx, pntrb, pntre, y, ldy, 0.0f, z, ldz, z_arg, nullptr, 1, 0, 0, 0,
+                     nullptr, 0, stream, row_order);
 }
 
 extern "C" size_t isplib_spmm_sliced_workspace_bytes(int32_t imessage, int64_t m, int64_t k, int slices) {
@@ -515,6 +533,7 @@ extern "C" int isplib_hip_tune(int key, int value) {
    if (key == 5) { g_panel_cols_minmax = value; return ISPLIB_SUCCESS; }
    if (key == 8 && value >= 0) { g_one_pass_kib = value; return ISPLIB_SUCCESS; }
    if (key == 9 && (value == 32 || value == 64 || value == 128)) { g_sweep_panel = value; return ISPLIB_SUCCESS; }
+   if (key == 10) { g_stream_merge_gens = value ? 1 : 0; return ISPLIB_SUCCESS; }
    return ISPLIB_FAIL;
 }
 

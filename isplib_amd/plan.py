@@ -397,3 +397,182 @@ def build_stream_plan_native(rowptr: torch.Tensor, col: torch.Tensor, ncols: int
                       hub_off=native.view("hub_off", i32), chunk=chunk)
     plan._native = native            # owns the device arrays the tensors above look at
     return plan
+
+
+@dataclass
+class HybridPlan:
+    """Plan of the hybrid form of the stream schedule (``fusedMM_csr_hybrid_hip``, include/isplib_hip.h:
+    isplib_hybrid_plan): a stream plan of the COLD edges plus, per column slice, the table of the hottest rows of y and
+    the hot edges as (local row, table row) words, chunked by (wave, slice)."""
+    cold: StreamPlan
+    table_rows: int
+    hot_cap: int
+    n_hot_steps: int
+    hot_rows: torch.Tensor       # int32 [slices*table_rows]
+    hot_words: torch.Tensor      # int32 [n_hot_steps*streams]
+    hot_step_off: torch.Tensor   # int64 [gens*waves_per_gen*slices + 1]
+    hot_perm: torch.Tensor       # int32 [n_hot_steps*streams], -1 = padding
+    hot_edges: int = 0           # how many edges are served from the tables
+
+    def struct(self) -> "cabi.HybridPlanStruct":
+        p = lambda t: t.data_ptr() if t is not None and t.numel() else None  # noqa: E731
+        return cabi.HybridPlanStruct(self.cold.struct(), self.table_rows, self.hot_cap, self.n_hot_steps, p(self.hot_rows),
+                                     p(self.hot_words), p(self.hot_step_off), p(self.hot_perm))
+
+    def workspace(self) -> torch.Tensor:
+        return self.cold.workspace()
+
+
+def hybrid_plan_arrays(rowptr: torch.Tensor, col: torch.Tensor, ncols: int, slices: int, waves_per_gen: int, rows_per_wave: int,
+                       streams: int, chunk: int, table_rows: int, hot_cap: int, min_refs: int = 2) -> dict:
+    """The arrays of a hybrid plan; plain torch ops on the device of `col` (once per graph and geometry).
+
+      * Hot rows: per column slice, the table_rows - 1 columns with the most references (in-degree; at least
+        `min_refs`), the same table for every workgroup; table row table_rows - 1 stays all zero (padding words point
+        at it).  An edge is HOT when its column is in the table of its slice, else COLD.
+      * Rows are dealt to streams exactly as in `stream_plan_arrays` (virtual rows for hub rows, rounds of one row per
+        stream, longest first to the least loaded stream) but by their COLD length: the gather pipeline is what bounds the
+        kernel, so that is what is balanced.
+      * Cold edges: a stream plan like any other (`cold`), whose `slices` is also the number of phases.
+      * Hot edges: per (wave, slice) a chunk of steps; step j holds word j of each of the wave's slots, (local row << 24)
+        | table row, rows ascending then CSR order; a slot with fewer hot edges in the slice than the chunk's longest is
+        padded with (its first row << 24) | table_rows - 1.  At most `hot_cap` steps per chunk (the kernel keeps a
+        chunk's words in registers): hot edges beyond it stay cold."""
+    assert 1 <= slices <= 4096 and streams in (4, 8) and waves_per_gen >= 8 and waves_per_gen % 8 == 0
+    assert rows_per_wave % streams == 0 and rows_per_wave <= 256 and 2 <= table_rows <= 65536 and hot_cap >= 1
+    assert ncols < (1 << 24)
+    m = rowptr.numel() - 1
+    dev = col.device
+    i64 = dict(dtype=torch.int64, device=dev)
+    nnz = col.numel()
+    assert nnz < 2 ** 31
+    per = rows_per_wave // streams
+    width = -(-ncols // slices)
+    # ---- the tables ----
+    indeg = torch.bincount(col, minlength=ncols)
+    cslice = torch.arange(ncols, **i64) // width
+    top = int(indeg.max()) + 1 if ncols else 1
+    order = torch.sort(cslice * top + (top - 1 - indeg), stable=True).indices        # slice ascending, in-degree descending
+    s_sorted = cslice[order]
+    counts = torch.bincount(cslice, minlength=slices)
+    starts = torch.cumsum(counts, 0) - counts
+    rank = torch.arange(ncols, **i64) - starts[s_sorted]
+    is_top = (rank < table_rows - 1) & (indeg[order] >= min_refs)
+    tidx = torch.full((ncols,), -1, **i64)
+    tidx[order[is_top]] = rank[is_top]
+    hot_rows = torch.full((slices * table_rows,), int(ncols), dtype=torch.int32, device=dev)
+    hot_rows[s_sorted[is_top] * table_rows + rank[is_top]] = order[is_top].to(torch.int32)
+    del order, s_sorted, rank, is_top, counts, starts, indeg, cslice
+    e_hot = tidx[col] >= 0
+    # ---- virtual rows and their streams (stream_plan_arrays, on cold lengths) ----
+    deg = rowptr[1:] - rowptr[:-1]
+    nchunk = ((deg + chunk - 1) // chunk).clamp(min=1)
+    nv = int(nchunk.sum())
+    vrow = torch.repeat_interleave(torch.arange(m, **i64), nchunk)
+    first = torch.cumsum(nchunk, 0) - nchunk
+    erow = torch.repeat_interleave(torch.arange(m, **i64), deg)
+    ev = first[erow] + (torch.arange(nnz, **i64) - rowptr[erow]) % nchunk[erow]
+    del erow
+    vlen = torch.bincount(ev[~e_hot], minlength=nv)
+    gens = max(1, -(-nv // (waves_per_gen * rows_per_wave)))
+    nw = gens * waves_per_gen
+    ns = nw * streams
+    order = torch.sort(vlen, descending=True, stable=True).indices
+    sid = torch.empty(nv, **i64)
+    rnd = torch.empty(nv, **i64)
+    loads = torch.zeros(ns, **i64)
+    for r in range(-(-nv // ns)):
+        items = order[r * ns:(r + 1) * ns]
+        to = torch.sort(loads, stable=True).indices[:items.numel()]
+        sid[items] = to
+        rnd[items] = r
+        loads[to] += vlen[items]
+    del order, loads
+    wave, slot = sid // streams, sid % streams
+    lrow = slot * per + rnd
+    is_hub = nchunk[vrow] > 1
+    part = torch.where(is_hub, torch.cumsum(is_hub.to(torch.int64), 0) - 1, torch.full((nv,), -1, **i64))
+    wave_row = torch.full((nw * rows_per_wave,), -1, dtype=torch.int32, device=dev)
+    wave_part = torch.full((nw * rows_per_wave,), -1, dtype=torch.int32, device=dev)
+    at = wave * rows_per_wave + lrow
+    wave_row[at] = vrow.to(torch.int32)
+    wave_part[at] = part.to(torch.int32)
+    hub_rows = torch.nonzero(nchunk > 1).flatten()
+    hub_off = torch.zeros(hub_rows.numel() + 1, dtype=torch.int32, device=dev)
+    if hub_rows.numel():
+        hub_off[1:] = torch.cumsum(nchunk[hub_rows], 0).to(torch.int32)
+    e_sid_all = sid[ev]
+    e_rnd_all = rnd[ev]
+    e_lrow_all = lrow[ev]
+    del ev
+    # ---- hot edges: order inside (stream, slice) groups, the cap, the chunks ----
+    h_e = torch.nonzero(e_hot).flatten()
+    hkey = (e_sid_all[h_e] * slices + col[h_e] // width) * per + e_rnd_all[h_e]
+    hperm = torch.sort(hkey, stable=True).indices
+    h_e = h_e[hperm]
+    group = hkey[hperm] // per                                   # stream * slices + slice
+    del hkey, hperm
+    gcount = torch.bincount(group, minlength=ns * slices)
+    gstart = torch.cumsum(gcount, 0) - gcount
+    hrank = torch.arange(h_e.numel(), **i64) - gstart[group]
+    over = hrank >= hot_cap
+    if bool(over.any()):
+        e_hot[h_e[over]] = False                                 # beyond the cap: served by the gather path
+        h_e, group, hrank = h_e[~over], group[~over], hrank[~over]
+    hsteps = gcount.clamp(max=hot_cap).view(nw, streams, slices).max(dim=1).values      # [nw, slices]
+    hot_step_off = torch.zeros(nw * slices + 1, **i64)
+    hot_step_off[1:] = torch.cumsum(hsteps.flatten(), 0)
+    n_hot_steps = int(hot_step_off[-1])
+    h_sid = group // slices
+    h_slice = group % slices
+    widx = (hot_step_off[(h_sid // streams) * slices + h_slice] + hrank) * streams + h_sid % streams
+    pad = ((torch.arange(streams, **i64) * per) << 24) | int(table_rows - 1)
+    hot_words = pad.to(torch.int32).repeat(n_hot_steps)
+    hot_words[widx] = ((e_lrow_all[h_e] << 24) | tidx[col[h_e]]).to(torch.int32)
+    hot_perm = torch.full((n_hot_steps * streams,), -1, dtype=torch.int32, device=dev)
+    hot_perm[widx] = h_e.to(torch.int32)
+    n_hot = int(h_e.numel())
+    del h_e, group, hrank, gcount, gstart, widx, h_sid, h_slice, tidx
+    # ---- cold edges: the stream plan's construction on what is left ----
+    c_e = torch.nonzero(~e_hot).flatten()
+    c_sid = e_sid_all[c_e]
+    key = (c_sid * slices + col[c_e] // width) * per + e_rnd_all[c_e]
+    perm = torch.sort(key, stable=True).indices
+    del key
+    c_e, c_sid = c_e[perm], c_sid[perm]
+    del perm
+    lens = torch.bincount(c_sid, minlength=ns)
+    start = torch.cumsum(lens, 0) - lens
+    p = torch.arange(c_e.numel(), **i64) - start[c_sid]
+    steps = lens.view(nw, streams).max(dim=1).values
+    wave_step_off = torch.zeros(nw + 1, **i64)
+    wave_step_off[1:] = torch.cumsum(steps, 0)
+    n_steps = int(wave_step_off[-1])
+    idx = (wave_step_off[c_sid // streams] + p) * streams + c_sid % streams
+    del p, start
+    pad = ((torch.arange(streams, **i64) * per) << 24) | int(ncols)
+    words = pad.to(torch.int32).repeat(n_steps)
+    words[idx] = ((e_lrow_all[c_e] << 24) | col[c_e]).to(torch.int32)
+    perm_out = torch.full((n_steps * streams,), -1, dtype=torch.int32, device=dev)
+    perm_out[idx] = c_e.to(torch.int32)
+    cold = dict(rows=m, cols=int(ncols), slices=slices, gens=gens, waves_per_gen=waves_per_gen, rows_per_wave=rows_per_wave,
+                streams=streams, n_steps=n_steps, n_parts=int(is_hub.sum()), n_hub=int(hub_rows.numel()), words=words, vals=None,
+                perm=perm_out, wave_step_off=wave_step_off, wave_row=wave_row, wave_part=wave_part,
+                hub_row=hub_rows.to(torch.int32), hub_off=hub_off, chunk=chunk)
+    return dict(cold=cold, table_rows=table_rows, hot_cap=hot_cap, n_hot_steps=n_hot_steps, hot_rows=hot_rows, hot_words=hot_words,
+                hot_step_off=hot_step_off, hot_perm=hot_perm, hot_edges=n_hot)
+
+
+def build_hybrid_plan(rowptr: torch.Tensor, col: torch.Tensor, ncols: int, slices: int, streams: int = 4, chunk: int = 512,
+                      waves_per_gen: Optional[int] = None, rows_per_wave: Optional[int] = None, table_rows: Optional[int] = None,
+                      hot_cap: Optional[int] = None, min_refs: int = 2) -> Optional[HybridPlan]:
+    """Hybrid plan of a graph on the device (unit weights); geometry defaults to what the kernel of this slot width is built
+    for (isplib_spmm_hybrid_geometry).  None when n >= 2^24 or nnz >= 2^31."""
+    if ncols >= (1 << 24) or col.numel() >= (1 << 31):
+        return None
+    rpw, resident, ht, cap = cabi.hybrid_geometry(streams)
+    arrays = hybrid_plan_arrays(rowptr, col, ncols, slices, resident if waves_per_gen is None else waves_per_gen,
+                                rpw if rows_per_wave is None else rows_per_wave, streams, chunk,
+                                ht if table_rows is None else table_rows, cap if hot_cap is None else hot_cap, min_refs)
+    arrays["cold"] = StreamPlan(**arrays["cold"])
+    return HybridPlan(**arrays)

@@ -1,0 +1,70 @@
+"""Locality ordering of the rows of a graph for SpMM operands larger than every cache (the ogbn-products shape: X is
+2.5 GB at K=256, ten times the Infinity Cache).
+
+No schedule of this library reuses a gathered row of such an operand; the only reuse there is lies in the graph's own
+structure: rows of one community gather mostly each other.  `fusedMM_csr_ordered_hip` takes the rows in a given order,
+every XCD walking a contiguous range of positions, so rows that sit next to each other in the order are worked on at the
+same time behind the same 4 MiB L2 -- nothing is moved, the result is bit for bit that of the plain kernel.  This module
+finds the order: label propagation (Raghavan et al. 2007), synchronous, on the device, with plain torch ops -- one
+sort of nnz keys per round, a handful of rounds, once per graph (the cost class of the plan builders in plan.py).
+The reference has no counterpart (its CPU kernel walks rows in index order, csrc/fusedmm.cpp:198).
+"""
+from __future__ import annotations
+
+import torch
+
+
+def label_propagation(rowptr: torch.Tensor, col: torch.Tensor, rounds: int = 8, seed: int = 0, min_change: float = 0.01):
+    """Community labels [n] (int64; label = a node id of the community) of a square graph by synchronous label
+    propagation: every node takes the label most of its neighbours carry, ties broken by a per-round hash of the label
+    (a fixed seed: the same graph gives the same labels).  Stops after `rounds` rounds or when fewer than `min_change`
+    of the nodes changed.  Returns (labels, rounds run)."""
+    n = rowptr.numel() - 1
+    dev = col.device
+    nnz = col.numel()
+    labels = torch.arange(n, dtype=torch.int64, device=dev)
+    if nnz == 0 or n == 0:
+        return labels, 0
+    deg = rowptr[1:] - rowptr[:-1]
+    row = torch.repeat_interleave(torch.arange(n, dtype=torch.int64, device=dev), deg)
+    big = 1 << 20                                           # tie-break range below one count
+    done = 0
+    for r in range(rounds):
+        key = torch.sort(row * n + labels[col]).values      # (row, neighbour label) runs
+        ukey, cnt = torch.unique_consecutive(key, return_counts=True)
+        del key
+        urow, ulab = ukey // n, ukey % n
+        del ukey
+        tie = ((ulab * 2654435761 + (seed + r) * 40503 + 12345) >> 7) % big
+        score = cnt * big + tie
+        best = torch.zeros(n, dtype=torch.int64, device=dev)
+        best.scatter_reduce_(0, urow, score, reduce="amax", include_self=True)
+        win = score == best[urow]
+        new = labels.clone()
+        new[urow[win]] = ulab[win]
+        changed = int((new != labels).sum())
+        labels = new
+        done = r + 1
+        del urow, ulab, cnt, tie, score, best, win, new
+        if changed < min_change * n:
+            break
+    return labels, done
+
+
+def community_order(rowptr: torch.Tensor, col: torch.Tensor, rounds: int = 8, seed: int = 0) -> torch.Tensor:
+    """int32 [n]: position -> row, rows of one community (label_propagation) next to each other, communities in the
+    order of their labels, rows of a community in index order.  A permutation of [0, n)."""
+    labels, _ = label_propagation(rowptr, col, rounds, seed)
+    return torch.sort(labels, stable=True).indices.to(torch.int32)
+
+
+def ordered_gather_locality(rowptr: torch.Tensor, col: torch.Tensor, order: torch.Tensor, window: int = 1024) -> float:
+    """Share of the stored entries whose column lies within `window` positions of its row in `order` (1.0 = every
+    neighbour is worked on at about the same time): a quick, kernel-free figure of what an order found."""
+    n = rowptr.numel() - 1
+    pos = torch.empty(n, dtype=torch.int64, device=col.device)
+    pos[order.to(torch.int64)] = torch.arange(n, dtype=torch.int64, device=col.device)
+    deg = rowptr[1:] - rowptr[:-1]
+    row = torch.repeat_interleave(torch.arange(n, dtype=torch.int64, device=col.device), deg)
+    near = (pos[row] - pos[col]).abs() <= window
+    return float(near.sum()) / max(1, col.numel())

@@ -158,3 +158,82 @@ def algorithmic_bytes(m: int, n: int, nnz: int, k: int, with_arg: bool = False) 
 def gather_bytes(m: int, nnz: int, k: int) -> int:
     """Traffic with zero cache reuse of the gathered rows."""
     return nnz * (12 + 4 * k) + m * k * 4 + (m + 1) * 8
+
+
+def sbm_csr(n: int, nnz: int, communities: int, p_in: float, max_deg: int, sigma: float, seed: int, device="cpu",
+            return_membership: bool = False):
+    """Degree-corrected stochastic block model with the SAME degree law as `chung_lu_csr` (log-normal weights): every
+    node belongs to one of `communities` blocks (assigned at random, so vertex ids carry no locality at all -- what a
+    locality ordering has to find, it has to find in the edges); an undirected edge picks its first endpoint by weight
+    and its second, with probability `p_in`, by weight inside the first one's block, else by weight anywhere.  Symmetric,
+    loop-free, duplicate-free CSR with exactly `nnz` entries.  The structure real co-purchase / social graphs have and a
+    Chung-Lu graph lacks: for SpMM operands larger than every cache it is the only reuse there is to plan for."""
+    assert nnz % 2 == 0 and 1 <= communities <= n and 0.0 <= p_in <= 1.0
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    und = nnz // 2
+    w = _weights(n, nnz / n, max_deg, sigma, gen)
+    member = torch.randint(0, communities, (n,), generator=gen, device=device)
+    by_block = torch.sort(member, stable=True).indices                    # nodes grouped by block
+    w_sorted = w[by_block]
+    cdf_b = torch.cumsum(w_sorted, 0)                                      # running weight in block order
+    size = torch.bincount(member, minlength=communities)
+    end = torch.cumsum(size, 0)
+    start = end - size
+    zero = torch.zeros(1, dtype=cdf_b.dtype, device=device)
+    cum_before = torch.cat([zero, cdf_b])                                  # weight before sorted position i
+    cdf = torch.cumsum(w, 0)
+    cdf = cdf / cdf[-1]
+    keys = torch.empty(0, dtype=torch.int64, device=device)
+    need = und
+    for _ in range(64):
+        if need <= 0:
+            break
+        draw = int(need * 1.15) + 1024
+        a = torch.searchsorted(cdf, torch.rand(draw, generator=gen, device=device, dtype=torch.float64)).clamp_(max=n - 1)
+        inside = torch.rand(draw, generator=gen, device=device) < p_in
+        u = torch.rand(draw, generator=gen, device=device, dtype=torch.float64)
+        blk = member[a]
+        lo_w, hi_w = cum_before[start[blk]], cum_before[end[blk]]
+        pos = torch.searchsorted(cdf_b, lo_w + u * (hi_w - lo_w)).clamp_(max=n - 1)
+        pos = torch.minimum(torch.maximum(pos, start[blk]), end[blk] - 1)
+        b_in = by_block[pos]
+        b_out = torch.searchsorted(cdf, u).clamp_(max=n - 1)
+        b = torch.where(inside, b_in, b_out)
+        keep = a != b
+        lo, hi = torch.minimum(a, b)[keep], torch.maximum(a, b)[keep]
+        keys = torch.unique(torch.cat([keys, lo * n + hi]))
+        del a, b, lo, hi, keep, inside, u, blk, pos, b_in, b_out, lo_w, hi_w
+        need = und - keys.numel()
+    if keys.numel() < und:
+        raise RuntimeError("sbm_csr: could not reach the requested edge count (blocks too small for their degrees)")
+    if keys.numel() > und:
+        drop = torch.randperm(keys.numel(), generator=gen, device=device)[: keys.numel() - und]
+        mask = torch.ones(keys.numel(), dtype=torch.bool, device=device)
+        mask[drop] = False
+        keys = keys[mask]
+        del mask, drop
+    lo, hi = keys // n, keys % n
+    del keys
+    full = torch.sort(torch.cat([lo * n + hi, hi * n + lo])).values
+    del lo, hi
+    row, col = full // n, full % n
+    del full
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    torch.cumsum(torch.bincount(row, minlength=n), 0, out=rowptr[1:])
+    if return_membership:
+        return rowptr, col.contiguous(), member
+    return rowptr, col.contiguous()
+
+
+def sbm_like(name: str, device="cpu", scale: float = 1.0, communities: Optional[int] = None, p_in: float = 0.8):
+    """(rowptr, col, n) with the node / edge counts and degree law of `dataset_like(name)` and block structure on top:
+    blocks of ~1,000 nodes unless `communities` says otherwise (ogbn-products shape: 2,449 blocks)."""
+    n, nnz, max_deg, sigma, seed = SHAPES[name]
+    if scale != 1.0:
+        n = max(64, int(n * scale))
+        nnz = max(2, int(nnz * scale)) // 2 * 2
+        max_deg = max(8, min(max_deg, n // 4))
+    c = max(1, n // 1000) if communities is None else communities
+    rowptr, col = sbm_csr(n, nnz, c, p_in, max_deg, sigma, seed + 100, device)
+    return rowptr, col, n

@@ -15,8 +15,11 @@ esac
 if [[ "$1" == *.py ]]; then set -- "$(command -v python3)" "$@"; fi
 prog=$(command -v "$1" || true)
 if [ -z "$prog" ]; then echo "prof_pmc.sh: '$1' not found" >&2; exit 2; fi
-prog=$(readlink -f "$prog")
-if [ "$(head -c 4 "$prog" | od -An -c | tr -d ' ')" != '177ELF' ]; then
+# the ELF test reads the file behind the symlinks; the program is STARTED from the path it was found at (a venv's
+# python3 is a symlink into the base installation: started from there it would not find its pyvenv.cfg / site-packages;
+# executing a symlink to an ELF is not an extra exec hop)
+real=$(readlink -f "$prog")
+if [ "$(head -c 4 "$real" | od -An -c | tr -d ' ')" != '177ELF' ]; then
   echo "prof_pmc.sh: '$prog' is not an ELF binary (a script would be exec'd through its interpreter): name the interpreter" >&2; exit 2
 fi
 shift

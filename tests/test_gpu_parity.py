@@ -325,3 +325,38 @@ def test_task_list_schedule(gpu, oracle_mod, k):
                     assert np.array_equal(out.cpu().numpy().view(np.uint32), ref.view(np.uint32)), (red, slices)
                     assert np.array_equal(arg.cpu().numpy(), ref_arg), (red, slices)
     cabi.lib().isplib_hip_tune(8, 9216)
+
+
+@pytest.mark.parametrize("k", (16, 41, 256))
+def test_ordered_plain_kernel_is_bitwise_the_plain_kernel(gpu, oracle_mod, k):
+    """fusedMM_csr_ordered_hip: the rows taken in a community order (isplib_amd/reorder.py on a block-structured graph), in
+    a random order and in none: every reduction bit for bit the plain kernel -- values, arg, empty rows, a hub row that
+    the whole workgroup shares -- and the plain kernel within the oracle's bound."""
+    from isplib_amd import cabi, reorder, synth
+    rowptr, col = synth.sbm_csr(3000, 120000, 6, 0.8, 400, 1.0, 5, device=gpu)
+    n = 3000
+    hub = torch.arange(0, n, 2, device=gpu)                                 # row 7 becomes a hub of 1500 entries (> long_row / 4 waves)
+    deg = (rowptr[1:] - rowptr[:-1]).clone()
+    row = torch.repeat_interleave(torch.arange(n, device=gpu), deg)
+    keep = row != 7
+    col2 = torch.cat([col[keep & (row < 7)], hub, col[keep & (row > 7)]])
+    deg[7] = hub.numel()
+    rowptr2 = torch.zeros(n + 1, dtype=torch.int64, device=gpu)
+    torch.cumsum(deg, 0, out=rowptr2[1:])
+    val = synth.edge_weights(col2.numel(), device=gpu)
+    x = synth.features(n, k, device=gpu, integer=True)
+    order = reorder.community_order(rowptr2, col2)
+    assert torch.equal(torch.sort(order.long()).values, torch.arange(n, device=gpu)), "a permutation of the rows"
+    ident = torch.arange(n, device=gpu, dtype=torch.int32)
+    assert reorder.ordered_gather_locality(rowptr2, col2, order, 300) > 2 * reorder.ordered_gather_locality(rowptr2, col2, ident, 300)
+    shuffled = torch.randperm(n, device=gpu).to(torch.int32)
+    for red in ("sum", "mean", "max", "min"):
+        want, want_arg = cabi.spmm(rowptr2, col2, val, x, red)
+        for o in (order, shuffled, None):
+            got, got_arg = cabi.spmm_ordered(rowptr2, col2, val, o, x, red)
+            assert torch.equal(got.view(torch.int32), want.view(torch.int32)), (red, k)
+            if want_arg is not None:
+                assert torch.equal(got_arg, want_arg), (red, k)
+    ref, _ = oracle_mod.spmm_fw(rowptr2.cpu().numpy(), col2.cpu().numpy(), val.cpu().numpy(), x.cpu().numpy(), "max")
+    got, _ = cabi.spmm_ordered(rowptr2, col2, val, order, x, "max")
+    assert np.array_equal(got.cpu().numpy().view(np.uint32), ref.view(np.uint32))

@@ -364,3 +364,128 @@ def test_stream_minmax_status_codes(gpu):
     if sum_plan.rows_per_wave != mm_plan.rows_per_wave:                                                                    # a sum plan is not a max plan
         assert cabi.fusedMM_csr_stream_minmax_hip(cabi.MSG_SPMM_MAX, d_rowptr, col.size, sum_plan, x, z, check=False) == 1
     assert cabi.fusedMM_csr_stream_minmax_hip(cabi.MSG_SPMM_MAX, d_rowptr, col.size, mm_plan, x, z, check=False) == 0
+
+
+# ---- SDDMM over the stream plan (isplib_sddmm_stream_hip): the dA of sum / mean on the SpMM's front end ---------------
+
+@pytest.mark.parametrize("k", (4, 5, 16, 32, 41, 64, 66, 67, 100, 128, 130, 256, 300))
+def test_sddmm_over_stream_plan(gpu, oracle_mod, k):
+    """dval[e] = <y[col[e]], g[row(e)]> (/ max(deg, 1) for mean; csrc/fusedmm.cpp:270,351) over the stream plan of the SpMM,
+    from both plan builders: every slot width (8, 16, 32 lanes), one and several column panels, a sliver panel of 1-3
+    columns (k = 66, 67, 130), ragged k, empty rows, a hub row cut into virtual rows, rectangular; twice for bitwise
+    reproducibility; integer operands make the dot products exact."""
+    from isplib_amd import cabi
+    from isplib_amd.plan import build_stream_plan
+    rowptr, col = cases.random_csr(200, 700, 25.0, seed=k, empty_rows=(0, 199), hub=(9, 6000))
+    x, g = cases.dense(700, k, 3), cases.dense(200, k, 5)
+    xi, gi = cases.dense(700, k, 3, "integer"), cases.dense(200, k, 5, "integer")
+    d = [_t(a, gpu) for a in (rowptr, col, x, g, xi, gi)]
+    for (s, wpg, streams, chunk) in ((8, 16, 4, 64), (5, 6, 8, 2048), (16, 7, 2, 100), (3, 3, 4, 300)):
+        plan = build_stream_plan(d[0], d[1], None, 700, s, wpg, None, streams, chunk)
+        nat = cabi.NativeStreamPlan(d[0], d[1], None, 700, streams, s, chunk, wpg)
+        for mean in (False, True):
+            got = cabi.sddmm_stream(d[0], col.size, plan, d[2], d[3], mean)
+            again = cabi.sddmm_stream(d[0], col.size, nat, d[2], d[3], mean)
+            assert torch.equal(got.view(torch.int32), again.view(torch.int32)), "bitwise reproducible, whichever builder made the plan"
+            ref = oracle_mod.sddmm(rowptr, col, x, g, mean=mean)
+            bound = 1e-5 * oracle_mod.sddmm(rowptr, col, np.abs(x), np.abs(g), mean=mean) + 1e-30
+            assert np.all(np.abs(got.cpu().numpy() - ref) <= bound), (k, streams, mean)
+        exact = cabi.sddmm_stream(d[0], col.size, plan, d[4], d[5], False).cpu().numpy()
+        assert np.array_equal(exact, oracle_mod.sddmm(rowptr, col, xi, gi)), (k, streams)
+        nat.close()
+
+
+def test_sddmm_stream_status_codes(gpu):
+    import ctypes
+    from isplib_amd import cabi
+    from isplib_amd.plan import build_stream_plan
+    rowptr, col = cases.random_csr(40, 40, 5.0, seed=1)
+    d_rowptr, d_col = _t(rowptr, gpu), _t(col, gpu)
+    plan = build_stream_plan(d_rowptr, d_col, None, 40, 2, 4, None, 4, 64)
+    L = cabi.lib()
+    y, g, dval = torch.zeros((40, 8), device=gpu), torch.zeros((40, 8), device=gpu), torch.zeros(col.size, device=gpu)
+    rp = d_rowptr.data_ptr()
+
+    def call(ps, k=8, ldy=8, nnz=col.size):
+        return L.isplib_sddmm_stream_hip(40, 40, k, nnz, ctypes.c_void_p(rp), ctypes.c_void_p(rp + 8), ps, ctypes.c_void_p(y.data_ptr()),
+                                         ldy, ctypes.c_void_p(g.data_ptr()), 8, 0, ctypes.c_void_p(dval.data_ptr()), None)
+    ps = plan.struct()
+    assert call(ctypes.byref(ps)) == 0
+    assert call(None) == 1 and "plan is required" in cabi.last_error()
+    assert call(ctypes.byref(ps), k=3) == 1 and call(ctypes.byref(ps), ldy=4) == 1
+    no_perm = plan.struct()
+    no_perm.perm = None
+    assert call(ctypes.byref(no_perm)) == 1 and "perm" in cabi.last_error()
+    other = plan.struct()
+    other.rows_per_wave = 8
+    assert call(ctypes.byref(other)) == 1
+
+
+# ---- hybrid form (fusedMM_csr_hybrid_hip): hot rows of y from an LDS table, cold edges through the gather pipeline ------
+
+def _hybrid_geoms(streams):
+    from isplib_amd import cabi
+    rpw, _, ht, cap = cabi.hybrid_geometry(streams)
+    return rpw, ht, cap
+
+
+@pytest.mark.parametrize("k,streams", ((4, 8), (16, 8), (32, 8), (41, 4), (64, 4), (67, 4), (128, 4), (130, 4), (31, 8), (100, 8)))
+def test_hybrid_widths(gpu, oracle_mod, k, streams):
+    """sum / mean, unit weights, through the hybrid kernel: slices with more and fewer hot rows than the table holds, chunks
+    that hit the hot-step cap (the rest stays cold), a wave with fewer cold batches than slices (padding pairs), empty rows,
+    a hub row in virtual rows, ragged k and sliver panels; twice for bitwise reproducibility; integer X: exact."""
+    from isplib_amd import cabi
+    from isplib_amd.plan import build_hybrid_plan
+    rowptr, col = cases.random_csr(900, 1200, 30.0, seed=100 + k, empty_rows=(0, 450, 899), hub=(17, 9000), duplicates=True)
+    val = cases.weights(col.size, 0, "unit")
+    x = cases.dense(1200, k, 3)
+    xi = cases.dense(1200, k, 3, "integer")
+    d_rowptr, d_col = _t(rowptr, gpu), _t(col, gpu)
+    for slices, wpg, chunk, refs in ((3, 8, 300, 2), (7, 16, 2048, 1), (40, 8, 64, 2)):
+        plan = build_hybrid_plan(d_rowptr, d_col, 1200, slices, streams, chunk, waves_per_gen=wpg, min_refs=refs)
+        assert plan is not None and plan.hot_edges + int((plan.cold.perm >= 0).sum()) == col.size and plan.hot_edges > 0
+        for red in ("sum", "mean"):
+            out = cabi.spmm_hybrid(d_rowptr, col.size, plan, _t(x, gpu), red)
+            again = cabi.spmm_hybrid(d_rowptr, col.size, plan, _t(x, gpu), red)
+            torch.cuda.synchronize()
+            assert torch.equal(out.view(torch.int32), again.view(torch.int32)), "hybrid schedule must be bitwise reproducible"
+            _check(oracle_mod, rowptr, col, val, x, red, out, None)
+        out = cabi.spmm_hybrid(d_rowptr, col.size, plan, _t(xi, gpu), "sum").cpu().numpy()
+        ref, _ = oracle_mod.spmm_fw(rowptr, col, val, xi, "sum")
+        assert np.array_equal(out, ref), (k, streams, slices)
+
+
+def test_hybrid_epilogue_and_status_codes(gpu, oracle_mod):
+    import ctypes
+    from isplib_amd import cabi
+    from isplib_amd.plan import build_hybrid_plan
+    n, k = 500, 64
+    rowptr, col = cases.random_csr(n, n, 20.0, seed=3, empty_rows=(7,))
+    d_rowptr, d_col = _t(rowptr, gpu), _t(col, gpu)
+    plan = build_hybrid_plan(d_rowptr, d_col, n, 4, 4, 256, waves_per_gen=8)
+    x, self_t = cases.dense(n, k, 3), cases.dense(n, k, 8)
+    rs, bias = np.abs(cases.dense(n, 1, 4)).ravel() + 0.5, cases.dense(1, k, 6).ravel()
+    got = cabi.spmm_hybrid(d_rowptr, col.size, plan, _t(x, gpu), "sum", row_scale=_t(rs, gpu), self_term=_t(self_t, gpu),
+                           bias=_t(bias, gpu), relu=True).cpu().numpy()
+    ref, _ = oracle_mod.spmm_fw(rowptr, col, np.ones(col.size, np.float32), x, "sum")
+    want = np.maximum(rs[:, None] * (ref + self_t) + bias[None, :], 0.0)
+    mag, _ = oracle_mod.spmm_fw(rowptr, col, np.ones(col.size, np.float32), np.abs(x), "sum")
+    assert np.all(np.abs(got - want) <= 1e-5 * (rs[:, None] * (mag + np.abs(self_t)) + np.abs(bias)[None, :]) + 1e-30)
+    L = cabi.lib()
+    y, z = _t(x, gpu), torch.zeros((n, k), device=gpu)
+    ws = plan.workspace()
+    rp = d_rowptr.data_ptr()
+
+    def call(msg, ps, kk=k):
+        return L.fusedMM_csr_hybrid_hip(msg, n, n, kk, col.size, ctypes.c_void_p(rp), ctypes.c_void_p(rp + 8), ps, ctypes.c_void_p(y.data_ptr()),
+                                        k, ctypes.c_void_p(z.data_ptr()), k, ctypes.c_void_p(ws.data_ptr()), ws.numel(), None, None)
+    ps = plan.struct()
+    assert call(cabi.MSG_SPMM_SUM, ctypes.byref(ps)) == 0
+    assert call(cabi.MSG_SPMM_MAX, ctypes.byref(ps)) == 128
+    assert call(cabi.MSG_SPMM_SUM, None) == 1 and call(cabi.MSG_SPMM_SUM, ctypes.byref(ps), kk=3) == 1
+    bad = plan.struct()
+    bad.table_rows = 64
+    assert call(cabi.MSG_SPMM_SUM, ctypes.byref(bad)) == 1 and "geometry" in cabi.last_error()
+    odd = plan.struct()
+    odd.cold.waves_per_gen = 12
+    assert call(cabi.MSG_SPMM_SUM, ctypes.byref(odd)) == 1

@@ -669,3 +669,60 @@ def test_stream_plan_lists_every_edge_once_slice_by_slice(geom):
     if chunk < 5000:                                            # the hub row's pieces all span the whole column range
         hub_slots = [(w, j) for w in range(nw) for j in range(rpw) if wr[w, j] == 7]
         assert len(hub_slots) == -(-5000 // chunk)
+
+
+@pytest.mark.parametrize("geom", ((4, 8, 8, 5, 16, 3, 100), (8, 16, 8, 12, 8, 2, 64), (4, 64, 16, 3, 32, 64, 50), (8, 128, 8, 40, 256, 64, 1000)))
+def test_hybrid_plan_serves_every_edge_once_from_the_table_or_the_gather_stream(geom):
+    """Host logic of the hybrid schedule's plan (isplib_amd/plan.py: hybrid_plan_arrays), replayed on the CPU the way the
+    kernel walks it: every stored entry is either a cold word of its wave's stream (column = the entry's column) or a hot
+    word of its wave's chunk of the entry's slice (the table row holds the entry's column); local rows stay inside their
+    slot; chunks respect the cap; padding points at the zero row / column n; and the replay reproduces A x."""
+    from isplib_amd.plan import hybrid_plan_arrays
+    streams, rpw, wpg, slices, table_rows, cap, chunk = geom
+    n = 700
+    rowptr, col = cases.random_csr(n, n, 40.0, seed=3, empty_rows=(0, 350), hub=(9, 650), duplicates=True)
+    a = hybrid_plan_arrays(torch.from_numpy(rowptr), torch.from_numpy(col), n, slices, wpg, rpw, streams, chunk, table_rows, cap)
+    c = a["cold"]
+    rng = np.random.default_rng(0)
+    x = rng.integers(-3, 4, (n, 3)).astype(np.float64)
+    xz = np.vstack([x, np.zeros((1, 3))])
+    nw, per, width = c["gens"] * c["waves_per_gen"], rpw // streams, -(-n // slices)
+    acc = np.zeros((nw, rpw, 3))
+    seen = np.zeros(col.size, np.int64)
+    words, perm, wso = c["words"].numpy().astype(np.int64) & 0xFFFFFFFF, c["perm"].numpy(), c["wave_step_off"].numpy()
+    hw, hp, hso = a["hot_words"].numpy().astype(np.int64) & 0xFFFFFFFF, a["hot_perm"].numpy(), a["hot_step_off"].numpy()
+    table = a["hot_rows"].numpy().reshape(slices, table_rows)
+    assert np.all(table[:, table_rows - 1] == n), "the last table row is the zero row in every slice"
+    for w in range(nw):
+        for s in range(wso[w], wso[w + 1]):
+            for g in range(streams):
+                wd = words[s * streams + g]
+                lr, cc, e = wd >> 24, wd & 0xFFFFFF, perm[s * streams + g]
+                assert g * per <= lr < (g + 1) * per
+                assert (col[e] == cc) if e >= 0 else (cc == n)
+                acc[w, lr] += xz[cc]
+                if e >= 0:
+                    seen[e] += 1
+        for sl in range(slices):
+            o0, o1 = hso[w * slices + sl], hso[w * slices + sl + 1]
+            assert 0 <= o1 - o0 <= cap
+            for s in range(o0, o1):
+                for g in range(streams):
+                    wd = hw[s * streams + g]
+                    lr, ti, e = wd >> 24, wd & 0xFFFF, hp[s * streams + g]
+                    assert g * per <= lr < (g + 1) * per and ti < table_rows
+                    cc = table[sl, ti]
+                    assert (col[e] == cc and cc // width == sl) if e >= 0 else (ti == table_rows - 1)
+                    acc[w, lr] += xz[cc]
+                    if e >= 0:
+                        seen[e] += 1
+    assert np.all(seen == 1) and a["hot_edges"] == int((hp >= 0).sum()) and a["hot_edges"] > 0
+    out = np.zeros((n, 3))
+    wr = c["wave_row"].numpy().reshape(nw, rpw)
+    for w in range(nw):
+        for l in range(rpw):
+            if wr[w, l] >= 0:
+                out[wr[w, l]] += acc[w, l]
+    ref = np.zeros((n, 3))
+    np.add.at(ref, np.repeat(np.arange(n), np.diff(rowptr)), x[col])
+    assert np.array_equal(out, ref)
