@@ -419,6 +419,22 @@ int    fusedMM_csr_ordered_hip(int32_t imessage, int64_t m, int64_t n, int64_t k
                                const int32_t *row_order /*[dev] m | NULL*/, const float *y, int64_t ldy, float *z,
                                int64_t ldz, int64_t *z_arg, void *stream);
 
+/* The order for fusedMM_csr_ordered_hip, found on the device (square graphs): synchronous label propagation -- every
+ * row takes the label most of its stored entries' columns carry, ties by a per-round hash of the label, at most `rounds`
+ * rounds (8 is plenty; it stops when fewer than 1 % of the rows change) -- then the rows sorted by label, index order
+ * inside a label.  order: [dev] m int32, position -> row.  labels (may be NULL): [dev] m int32, the label of every row.
+ * One radix sort of nnz 64-bit keys per round: ~0.2 s for the ogbn-products shape, once per graph.  The result only
+ * affects speed.  isplib_order_locality_hip reports what an order found: the share of stored entries whose column lies
+ * within `window` positions of its row (order NULL: index order) -- a community order of a graph WITH structure lifts it
+ * from ~0 to the share of edges inside communities; one that lifts nothing is not worth passing on. */
+size_t isplib_community_order_workspace_bytes(int64_t m, int64_t nnz);
+int    isplib_community_order_hip(int64_t m, int64_t nnz, const int64_t *rowptr, const int64_t *col, int rounds, int seed,
+                                  int32_t *order, int32_t *labels /*may be NULL*/, int *rounds_run /*host, may be NULL*/,
+                                  void *workspace, size_t workspace_bytes, void *stream);
+int    isplib_order_locality_hip(int64_t m, int64_t nnz, const int64_t *rowptr, const int64_t *col, const int32_t *order,
+                                 int64_t window, double *share /*host*/, void *workspace /*4 m + 512 bytes*/,
+                                 size_t workspace_bytes, void *stream);
+
 /* SDDMM over a stream plan (the dA of sum / mean: dval[e] = <y[col[e], :], g[row(e), :]>, / max(deg, 1) for mean -- the
  * call the reference leaves commented out, csrc/fusedmm.cpp:270,351).  Same edges and same gathers of y as the SpMM, so
  * the same plan (a sum / mean plan of isplib_spmm_stream_geometry WITH its perm array; weights in the plan are ignored)
@@ -571,6 +587,12 @@ int  isplib_suggest_slices(int64_t m, int64_t n, int64_t nnz, int64_t k, int min
 int  isplib_graph_create(int64_t m, int64_t n, int64_t nnz, const int64_t *rowptr, const int64_t *col,
                          const float *val, isplib_graph **out);
 int  isplib_graph_set_slices(isplib_graph *g, int slices);
+/* The order in which the plain kernel takes the rows of A (order: [dev] m int32, position -> row) and of A^T (order_t:
+ * [dev] n int32) -- fusedMM_csr_ordered_hip; borrowed, NULL = index order.  Without this call the handle looks for a
+ * community order itself (isplib_community_order_hip, once, ~0.2 s for the ogbn-products shape) the first time a square
+ * graph reaches the plain kernel with a dense operand larger than the Infinity Cache (n k 4 > 256 MiB), and keeps it
+ * only if it found structure.  Speed only: any order gives the same bits. */
+int  isplib_graph_set_row_order(isplib_graph *g, const int32_t *order, const int32_t *order_t);
 /* New weights for the same structure (val: [dev] nnz | NULL, borrowed like create's; also to be called when the
  * CONTENTS of the array given before have changed): plans, packed column ids and the CSC structure stay; the
  * unit-weight test, the stream plans' copies of the weights and the transposed weights of the backward are refreshed

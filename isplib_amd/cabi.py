@@ -54,7 +54,8 @@ EXPORTS = (
     "fusedMM_csr_sweep_hip", "isplib_spmm_sweep_workspace_bytes", "isplib_spmm_sweep_resident_waves",
     "fusedMM_csr_stream_hip", "isplib_spmm_stream_workspace_bytes", "isplib_spmm_stream_geometry", "isplib_suggest_stream", "isplib_stream_plan_build_hip", "isplib_stream_plan_build_minmax_hip", "fusedMM_csr_stream_minmax_hip", "isplib_spmm_stream_minmax_geometry", "isplib_suggest_stream_minmax", "isplib_spmm_stream_minmax_workspace_bytes", "isplib_stream_plan_set_values_hip", "isplib_stream_plan_free", "isplib_spmm_minmax_bw_det_hip", "isplib_spmm_minmax_bw_workspace_bytes",
     "fusedMM_csr_hybrid_hip", "isplib_spmm_hybrid_geometry", "isplib_spmm_hybrid_workspace_bytes", "isplib_sddmm_stream_hip",
-    "fusedMM_csr_ordered_hip",
+    "fusedMM_csr_ordered_hip", "isplib_community_order_hip", "isplib_community_order_workspace_bytes", "isplib_order_locality_hip",
+    "isplib_graph_set_row_order",
 )
 
 _i64, _f32, _vp, _i32 = ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_int32
@@ -209,6 +210,15 @@ def lib() -> ctypes.CDLL:
         L.fusedMM_csr_hybrid_hip.restype = ctypes.c_int
         L.fusedMM_csr_hybrid_hip.argtypes = [_i32, _i64, _i64, _i64, _i64, _vp, _vp, ctypes.POINTER(HybridPlanStruct), _vp, _i64, _vp, _i64,
                                              _vp, ctypes.c_size_t, _vp, _vp]
+        L.isplib_community_order_workspace_bytes.restype = ctypes.c_size_t
+        L.isplib_community_order_workspace_bytes.argtypes = [_i64, _i64]
+        L.isplib_community_order_hip.restype = ctypes.c_int
+        L.isplib_community_order_hip.argtypes = [_i64, _i64, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.POINTER(ctypes.c_int), _vp,
+                                                 ctypes.c_size_t, _vp]
+        L.isplib_order_locality_hip.restype = ctypes.c_int
+        L.isplib_order_locality_hip.argtypes = [_i64, _i64, _vp, _vp, _vp, _i64, ctypes.POINTER(ctypes.c_double), _vp, ctypes.c_size_t, _vp]
+        L.isplib_graph_set_row_order.restype = ctypes.c_int
+        L.isplib_graph_set_row_order.argtypes = [_vp, _vp, _vp]
         L.fusedMM_csr_ordered_hip.restype = ctypes.c_int
         L.fusedMM_csr_ordered_hip.argtypes = [_i32, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp]
         L.isplib_sddmm_stream_hip.restype = ctypes.c_int
@@ -293,6 +303,34 @@ def fusedMM_csr_hip(imessage: int, rowptr: torch.Tensor, col: torch.Tensor, val:
     if check:
         _check(st, "fusedMM_csr_hip")
     return st
+
+
+def community_order(rowptr, col, rounds: int = 8, seed: int = 0):
+    """(order int32 [m], labels int32 [m], rounds run) by the library's label propagation (isplib_community_order_hip)."""
+    rowptr = _dev(rowptr, "rowptr", torch.int64)
+    col = _dev(col, "col", torch.int64)
+    m, nnz = rowptr.numel() - 1, col.numel()
+    order = torch.empty(m, dtype=torch.int32, device=col.device)
+    labels = torch.empty(m, dtype=torch.int32, device=col.device)
+    ran = ctypes.c_int(0)
+    with torch.cuda.device(col.device):
+        ws = torch.empty(lib().isplib_community_order_workspace_bytes(m, nnz), dtype=torch.uint8, device=col.device)
+        _check(lib().isplib_community_order_hip(m, nnz, _ptr(rowptr), _ptr(col), int(rounds), int(seed), _ptr(order), _ptr(labels),
+                                                ctypes.byref(ran), _ptr(ws), ws.numel(), _stream(col.device)), "isplib_community_order_hip")
+    return order, labels, ran.value
+
+
+def order_locality(rowptr, col, order, window: int = 1024) -> float:
+    """Share of the stored entries whose column lies within `window` positions of its row in `order` (None: index order)."""
+    rowptr = _dev(rowptr, "rowptr", torch.int64)
+    col = _dev(col, "col", torch.int64)
+    m = rowptr.numel() - 1
+    share = ctypes.c_double(0.0)
+    with torch.cuda.device(col.device):
+        ws = torch.empty(4 * m + 1024, dtype=torch.uint8, device=col.device)
+        _check(lib().isplib_order_locality_hip(m, col.numel(), _ptr(rowptr), _ptr(col), _ptr(order), int(window), ctypes.byref(share),
+                                               _ptr(ws), ws.numel(), _stream(col.device)), "isplib_order_locality_hip")
+    return share.value
 
 
 def fusedMM_csr_ordered_hip(imessage: int, rowptr, col, val, order, y, z, z_arg=None, check: bool = True) -> int:

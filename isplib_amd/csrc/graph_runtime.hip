@@ -41,6 +41,11 @@ struct Side {                    // A, or A^T, as CSR
    // stream order: `val` of the side, or the mean backward's weights)
    struct Stream { isplib_stream_plan plan; const float *vals_of = nullptr; bool has_vals = false; uint64_t gen = 0; };
    std::map<uint64_t, Stream> streams;
+   // plain-kernel rows in a community order (reorder.hip), for dense operands larger than the Infinity Cache: found on
+   // first need (order_state 0 -> 1: tried and kept in `order`, or 2: tried, no structure found / not applicable), or
+   // given by the caller (isplib_graph_set_row_order: state 3, borrowed, never freed here)
+   int32_t *order = nullptr;
+   int order_state = 0;
    bool stream_refused = false;          // the sum / mean stream builder declined this side (outside its domain): task list / plain
    bool minmax_stream_refused = false;   // the max / min stream builder declined this side (rows not column-sorted): task list
 };
@@ -73,6 +78,7 @@ void free_side(Side &s, bool owns_arrays) {
    for (auto &kv : s.streams) isplib_stream_plan_free(&kv.second.plan);
    s.streams.clear();
    (void)hipFree(s.col32);
+   if (s.order_state == 1) (void)hipFree(s.order);
    s.col32 = nullptr;
    if (owns_arrays) {
       (void)hipFree(const_cast<int64_t *>(s.rowptr)); (void)hipFree(const_cast<int64_t *>(s.col));
@@ -93,6 +99,8 @@ struct isplib_graph {
    struct Work { void *ptr = nullptr; size_t bytes = 0; };
    std::map<hipStream_t, Work> works;   // one grow-only workspace per stream the handle has been used on
    int forced_slices = -1;       // -1: isplib_suggest_slices
+   bool order_given = false;     // isplib_graph_set_row_order was called: order_t_given is A^T's order when that side is built
+   const int32_t *order_t_given = nullptr;
 };
 
 #define TRY_ALLOC(ptr, bytes)                                                                              \
@@ -166,6 +174,58 @@ extern "C" int isplib_graph_set_slices(isplib_graph *g, int slices) {
    if (slices < -1 || slices > ISPLIB_MAX_SLICES) return fail(ISPLIB_FAIL, "isplib_graph_set_slices: -1 (rule), 0 (plain) or 1..4096");
    g->forced_slices = slices;
    return ISPLIB_SUCCESS;
+}
+
+extern "C" int isplib_graph_set_row_order(isplib_graph *g, const int32_t *order, const int32_t *order_t) {
+   // The order the plain kernel takes the rows of A (order) / of A^T (order_t) in: borrowed device arrays of m / n int32,
+   // position -> row; NULL = index order and no search for one.  Speed only.
+   clear_error();
+   if (!g) return fail(ISPLIB_FAIL, "isplib_graph_set_row_order: null handle");
+   Side *sides[2] = {&g->fwd, &g->bwd};
+   const int32_t *given[2] = {order, order_t};
+   for (int i = 0; i < 2; i++) {
+      if (sides[i]->order_state == 1) (void)hipFree(sides[i]->order);
+      sides[i]->order = const_cast<int32_t *>(given[i]);
+      sides[i]->order_state = 3;
+   }
+   g->order_t_given = order_t;
+   g->order_given = true;
+   return ISPLIB_SUCCESS;
+}
+
+// The plain kernel's row order of a side: the caller's, or -- square graphs whose dense operand is larger than the
+// Infinity Cache -- the community order, looked for once and kept only if it found structure (at least a fifth of the
+// stored entries, and twice the index order's share, within the ~1024 rows an XCD has in flight)
+static const int32_t *side_row_order(isplib_graph *g, Side &s, int64_t k, hipStream_t st) {
+   if (s.order_state != 0) return s.order;
+   s.order_state = 2;
+   if (s.m != s.n || s.m >= (1LL << 31) || s.nnz <= 0 || (double)s.n * (double)k * 4.0 <= 256.0 * 1048576.0) {
+      if ((double)s.n * (double)k * 4.0 <= 256.0 * 1048576.0) s.order_state = 0;      // a wider call may still want one
+      return nullptr;
+   }
+   const size_t ws_bytes = isplib_community_order_workspace_bytes(s.m, s.nnz);
+   void *ws = nullptr;
+   int32_t *order = nullptr;
+   if (hipMalloc(&ws, ws_bytes) != hipSuccess || hipMalloc((void **)&order, (size_t)s.m * sizeof(int32_t)) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipFree(ws); (void)hipFree(order);
+      clear_error();
+      return nullptr;
+   }
+   double before = 0.0, after = 0.0;
+   int rc = isplib_community_order_hip(s.m, s.nnz, s.rowptr, s.col, 8, 0, order, nullptr, nullptr, ws, ws_bytes, st);
+   if (!rc) rc = isplib_order_locality_hip(s.m, s.nnz, s.rowptr, s.col, nullptr, 1024, &before, ws, ws_bytes, st);
+   if (!rc) rc = isplib_order_locality_hip(s.m, s.nnz, s.rowptr, s.col, order, 1024, &after, ws, ws_bytes, st);
+   (void)hipFree(ws);
+   if (rc || after < 0.2 || after < 2.0 * before) {
+      (void)hipFree(order);
+      clear_error();
+      return nullptr;
+   }
+   s.order = order;
+   s.order_state = 1;
+   (void)g;
+   return s.order;
 }
 
 extern "C" int isplib_graph_set_values(isplib_graph *g, const float *val) {
@@ -431,8 +491,9 @@ static int run_side(isplib_graph *g, Side &s, const float *val, int32_t imessage
                                       w->ptr, w->bytes, st);
       }
    }
-   return fusedMM_csr_hip(imessage, s.m, s.n, k, 1.0f, s.nnz, s.m, s.n, val, s.col, s.rowptr, s.rowptr + 1, nullptr, k, y, ldy,
-                          0.0f, z, ldz, z_arg, st);
+   // the plain kernel; rows in a community order where the dense operand is beyond every cache and the graph has structure
+   return fusedMM_csr_ordered_hip(imessage, s.m, s.n, k, s.nnz, val, s.col, s.rowptr, s.rowptr + 1, side_row_order(g, s, k, st), y, ldy,
+                                  z, ldz, z_arg, st);
 }
 
 extern "C" int isplib_graph_spmm(isplib_graph *g, int32_t imessage, int64_t k, const float *y, int64_t ldy, float *z,
@@ -497,6 +558,7 @@ static int ensure_transpose(isplib_graph *g, hipStream_t st) {
    }
    t.rowptr = colptr; t.col = row_t; t.val = val_t;
    g->bwd = t;
+   if (g->order_given) { g->bwd.order = const_cast<int32_t *>(g->order_t_given); g->bwd.order_state = 3; }
    g->has_bwd = true;
    return ISPLIB_SUCCESS;
 }

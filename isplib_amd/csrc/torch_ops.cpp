@@ -313,6 +313,18 @@ std::tuple<Tensor, Tensor> spmm_fw(const Tensor &rowptr_, const Tensor &col_, co
       check_status(st, "fusedMM_csr_tasks_hip");
       return std::make_tuple(out, arg);
    }
+   if (plan.size() == 1 && plan[0].defined() && plan[0].scalar_type() == at::kInt && M > 0 && K > 0) {
+      // a row order (int32 [M], position -> row): the plain kernel with the rows taken in that order (operands larger
+      // than the Infinity Cache on graphs with community structure; fusedMM_csr_ordered_hip) -- the same bits as below
+      const Tensor order = plan[0].contiguous();
+      TORCH_CHECK(order.is_cuda() && order.numel() == M, "isplib: the row order must hold one int32 position per row");
+      const int st = fusedMM_csr_ordered_hip(msg, M, N, K, nnz, value.defined() ? value.data_ptr<float>() : nullptr,
+                                             col.data_ptr<int64_t>(), rp, rp + 1, order.data_ptr<int32_t>(), mat.data_ptr<float>(), K,
+                                             out.data_ptr<float>(), K, arg.defined() ? arg.data_ptr<int64_t>() : nullptr,
+                                             current_stream(mat));
+      check_status(st, "fusedMM_csr_ordered_hip");
+      return std::make_tuple(out, arg);
+   }
    if (plan.size() == 1 && plan[0].defined() && M > 0 && K > 0) {
       check_index(plan[0], "slices");
       const Tensor table = plan[0].contiguous();

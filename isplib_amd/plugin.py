@@ -240,6 +240,8 @@ def spmm_autotuned(src, other: torch.Tensor, reduce: str = "sum") -> torch.Tenso
     if plan is None:
         n_sl = choose_slices(s, mat.size(0), k, reduce in ("max", "min"))
         plan = s.plan(n_sl)                                          # per-graph, built once on the device
+        if not plan:                                                 # the plain kernel: rows in a community order where that pays
+            plan = s.row_order(False, k)
     if reduce in ("sum", "add", "mean"):
         colptr = val_t = row_t = None
         plan_t = []
@@ -253,6 +255,8 @@ def spmm_autotuned(src, other: torch.Tensor, reduce: str = "sum") -> torch.Tenso
             plan_t = s.stream_plan(True, geom_t, "mean" if reduce == "mean" and not unit_mean else "sum") if geom_t is not None else None
             if plan_t is None:
                 plan_t = s.plan_t(choose_slices(s, m_rows, k, transposed=True))
+                if not plan_t:
+                    plan_t = s.row_order(True, k)
         if reduce == "mean":
             out = ops.fusedmm_spmm_mean_planned(rowptr, col, value, colptr, mat, row_t, val_t, plan, plan_t)
         else:

@@ -36,8 +36,8 @@ def label_propagation(rowptr: torch.Tensor, col: torch.Tensor, rounds: int = 8, 
         urow, ulab = ukey // n, ukey % n
         del ukey
         tie = ((ulab * 2654435761 + (seed + r) * 40503 + 12345) >> 7) % big
-        score = cnt * big + tie
-        best = torch.zeros(n, dtype=torch.int64, device=dev)
+        score = (cnt * big + tie) * n + ulab               # equal count and hash: the larger label (reorder.hip: ro_mode_kernel)
+        best = torch.full((n,), -1, dtype=torch.int64, device=dev)
         best.scatter_reduce_(0, urow, score, reduce="amax", include_self=True)
         win = score == best[urow]
         new = labels.clone()
@@ -51,11 +51,28 @@ def label_propagation(rowptr: torch.Tensor, col: torch.Tensor, rounds: int = 8, 
     return labels, done
 
 
-def community_order(rowptr: torch.Tensor, col: torch.Tensor, rounds: int = 8, seed: int = 0) -> torch.Tensor:
-    """int32 [n]: position -> row, rows of one community (label_propagation) next to each other, communities in the
-    order of their labels, rows of a community in index order.  A permutation of [0, n)."""
+def community_order(rowptr: torch.Tensor, col: torch.Tensor, rounds: int = 8, seed: int = 0, native: bool = True) -> torch.Tensor:
+    """int32 [n]: position -> row, rows of one community (label propagation) next to each other, communities in the
+    order of their labels, rows of a community in index order.  A permutation of [0, n).  native: the library's own
+    implementation (isplib_community_order_hip: rocPRIM sorts + three kernels, no torch op) -- the same labels as the
+    torch statement above (tests/test_gpu_parity.py holds the two together)."""
+    if native and col.is_cuda:
+        from . import cabi
+        return cabi.community_order(rowptr, col, rounds, seed)[0]
     labels, _ = label_propagation(rowptr, col, rounds, seed)
     return torch.sort(labels, stable=True).indices.to(torch.int32)
+
+
+def useful_order(rowptr: torch.Tensor, col: torch.Tensor, rounds: int = 8, window: int = 1024):
+    """The community order of a square graph if it found structure, else None: kept when at least a fifth of the stored
+    entries AND twice the share of the index order lie within `window` positions (the rows an XCD has in flight) of their
+    row.  A structure-free graph (Chung-Lu: 0.1 % -> 0.1 %) keeps the index order and loses nothing but the one-off
+    ~0.2 s; the result of the SpMM is the same bits either way."""
+    from . import cabi
+    order, _, _ = cabi.community_order(rowptr, col, rounds)
+    before = cabi.order_locality(rowptr, col, None, window)
+    after = cabi.order_locality(rowptr, col, order, window)
+    return order if after >= 0.2 and after >= 2.0 * before else None
 
 
 def ordered_gather_locality(rowptr: torch.Tensor, col: torch.Tensor, order: torch.Tensor, window: int = 1024) -> float:

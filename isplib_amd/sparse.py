@@ -119,6 +119,22 @@ class SparseStorage:
         (col32, the packed column ids, once per graph)."""
         return self._plan_for(self._plans, n_slices, self._rowptr, self._col, self._sparse_sizes[1])
 
+    def row_order(self, transposed: bool, k: int):
+        """[order] -- the plain kernel's rows in a community order (isplib_amd/reorder.py) -- for a square graph whose dense
+        operand is larger than the Infinity Cache (n k 4 > 256 MiB) and HAS community structure, else [] (the plain
+        kernel in index order).  Looked for once per side (~0.2 s for the ogbn-products shape); ISPLIB_REORDER=0 never
+        looks.  The result is the same bits either way."""
+        import os
+        m, n = self._sparse_sizes
+        if m != n or n * k * 4 <= (256 << 20) or os.environ.get("ISPLIB_REORDER", "1") == "0" or self._col.numel() == 0:
+            return []
+        cache = self.__dict__.setdefault("_row_orders", {})
+        if transposed not in cache:
+            from . import reorder
+            rp, cl = (self.colptr(), self.row_t()) if transposed else (self._rowptr, self._col)
+            cache[transposed] = reorder.useful_order(rp, cl)
+        return [] if cache[transposed] is None else [cache[transposed]]
+
     def plan_t(self, n_slices: int):
         """The same for A^T (CSC operands)."""
         if n_slices <= 0:

@@ -360,3 +360,54 @@ def test_ordered_plain_kernel_is_bitwise_the_plain_kernel(gpu, oracle_mod, k):
     ref, _ = oracle_mod.spmm_fw(rowptr2.cpu().numpy(), col2.cpu().numpy(), val.cpu().numpy(), x.cpu().numpy(), "max")
     got, _ = cabi.spmm_ordered(rowptr2, col2, val, order, x, "max")
     assert np.array_equal(got.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+
+
+def test_native_label_propagation_equals_the_torch_statement(gpu):
+    """isplib_community_order_hip (rocPRIM sorts + kernels) against isplib_amd/reorder.py (torch ops): the same labels after
+    the same number of rounds, the same order; on a graph with blocks the order groups them, on one without it finds
+    nothing worth keeping."""
+    from isplib_amd import cabi, reorder, synth
+    rowptr, col, member = synth.sbm_csr(20000, 600000, 20, 0.8, 800, 1.0, 9, device=gpu, return_membership=True)
+    labels_t, rounds_t = reorder.label_propagation(rowptr, col)
+    order, labels, rounds = cabi.community_order(rowptr, col)
+    assert rounds == rounds_t and torch.equal(labels.long(), labels_t)
+    assert torch.equal(order, reorder.community_order(rowptr, col, native=False))
+    # most rows of a block share one label
+    agree = 0
+    for b in range(20):
+        lab = labels_t[member == b]
+        agree += int((lab == torch.mode(lab).values).sum())
+    assert agree >= 0.9 * 20000
+    assert cabi.order_locality(rowptr, col, order, 1024) == pytest.approx(reorder.ordered_gather_locality(rowptr, col, order, 1024), abs=1e-12)
+    assert reorder.useful_order(rowptr, col) is not None
+    rowptr2, col2 = synth.chung_lu_csr(20000, 600000, 800, 1.0, 9, device=gpu)
+    assert reorder.useful_order(rowptr2, col2) is None
+
+
+def test_plugin_and_handle_take_the_community_order_where_the_operand_is_beyond_the_caches(gpu):
+    """A square graph with blocks, mean degree 20 (the slice rule says: plain kernel) and a dense operand of 307 MB (beyond
+    the Infinity Cache): the plug-in passes the community order to the operators, forward and backward, and the C handle
+    finds one itself -- results bit for bit those of the plain kernel."""
+    import isplib_amd
+    from isplib_amd import cabi, synth
+    n, k = 300000, 256
+    rowptr, col = synth.sbm_csr(n, 6000000, 300, 0.8, 2000, 1.0, 4, device=gpu)
+    x = synth.features(n, k, device=gpu)
+    want, _ = cabi.spmm(rowptr, col, None, x, "sum")
+    adj = isplib_amd.SparseTensor.from_csr(rowptr, col, None, (n, n))
+    xg = x.clone().requires_grad_(True)
+    out = isplib_amd.matmul(adj, xg, "sum")
+    assert adj.storage._row_orders[False] is not None, "the plug-in did not look for / keep a row order"
+    assert torch.equal(out.detach(), want)
+    out.backward(x)
+    assert adj.storage._row_orders[True] is not None
+    assert torch.equal(xg.grad, want), "A is symmetric: A^T x == A x, through the transposed side's order"
+    mx = isplib_amd.matmul(adj, x, "max")
+    assert torch.equal(mx, cabi.spmm(rowptr, col, None, x, "max")[0])
+    h = cabi.GraphHandle(rowptr, col, None, n)
+    try:
+        got, _ = h.spmm(x, "sum")
+        assert torch.equal(got, want)
+        assert torch.equal(h.spmm_backward(x, mean=False), want)
+    finally:
+        h.close()
