@@ -56,6 +56,9 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra", action="store_true", help="skip the other BASELINE.json configs (the `extra` array)")
     p.add_argument("--no-backward", action="store_true")
+    p.add_argument("--only", default="", help="profiling: run ONE configuration of the `extra` array, named by its key in "
+                   "profiles/traffic.json (reddit-{mean,max,min}-k64-weighted, reddit-sum-k128-weighted, reddit-sddmm-k128, "
+                   "products-{chunglu,sbm}-sum-k256-{plain,ordered}), and print it instead of the metric line")
     return p.parse_args()
 
 
@@ -124,11 +127,22 @@ def extra_configs(dev, rowptr, col, n, with_cpu_epoch=True):
     col32 = cabi.pack_indices(col)
     w = synth.edge_weights(nnz, device=dev)
 
-    def entry(name, ms, m, nn, e, k, with_arg, schedule):
+    try:
+        measured = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    except Exception:  # noqa: BLE001
+        measured = {}
+
+    def entry(name, ms, m, nn, e, k, with_arg, schedule, key=None, **more):
+        """`key`: this configuration's entry of profiles/traffic.json (fabric-side bytes per launch from separate rocprofv3
+        --pmc passes of `bench.py --only <key>`, and the kernel-trace file its launch time can be recomputed from)."""
         b_alg = synth.algorithmic_bytes(m, nn, e, k, with_arg)
-        out.append({"config": name, "ms": ms, "edges_per_s": e / (ms * 1e-3), "schedule": schedule,
-                    "roofline": {"bound": "hbm", "achieved": b_alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                 "frac": b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": b_alg}})
+        rec = measured.get(key) if key else None
+        roof = {"bound": "hbm", "achieved": b_alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None if not rec else rec.get("fabric_bytes_per_launch"),
+                "kernel_avg_ms": ms, "algorithmic_bytes_per_launch": b_alg}
+        if rec:
+            roof["traffic_source"] = f"profiles/traffic.json[{key}]: " + rec.get("source", "rocprofv3 --pmc, separate passes")
+        out.append(dict({"config": name, "ms": ms, "edges_per_s": e / (ms * 1e-3), "schedule": schedule, "roofline": roof}, **more))
 
     def run(red, k, val, name):
         x = synth.features(n, k, device=dev, integer=red in ("max", "min"))
@@ -153,21 +167,39 @@ def extra_configs(dev, rowptr, col, n, with_cpu_epoch=True):
             ws = plan.workspace(red, k)
             ms = _time_launches(lambda: cabi.fusedMM_csr_tasks_hip(msg, rowptr, col, val, plan, x, z, arg, ws))
             sched = f"task list, {sl} slices"
-        entry(name, ms, n, n, nnz, k, arg is not None, sched)
+        entry(name, ms, n, n, nnz, k, arg is not None, sched, key=f"reddit-{red}-k{k}-weighted")
 
+    only = os.environ.get("ISPLIB_BENCH_ONLY", "")          # profiling: one configuration (its traffic.json key) instead of all
     for red in ("mean", "max", "min"):
-        run(red, 64, w, f"config 3: reddit-like SpMM-{red} K=64, U(0,1) weights" + (" (+arg)" if red != "mean" else ""))
-    run("sum", 128, w, "config 2: reddit-like SpMM-sum K=128, U(0,1) weights")
+        if not only or only == f"reddit-{red}-k64-weighted":
+            run(red, 64, w, f"config 3: reddit-like SpMM-{red} K=64, U(0,1) weights" + (" (+arg)" if red != "mean" else ""))
+    if not only or only == "reddit-sum-k128-weighted":
+        run("sum", 128, w, "config 2: reddit-like SpMM-sum K=128, U(0,1) weights")
     # the third leg of config 2's backward when the edge weights are trainable: dA[e] = <X[col[e]], dY[row(e)]>, the SDDMM the
     # reference leaves commented out (csrc/fusedmm.cpp:270), through the graph handle (task list sized for whole rows)
-    h = cabi.GraphHandle(rowptr, col, w, n)
-    xs, gs = synth.features(n, 128, device=dev), synth.features(n, 128, seed=5, device=dev)
-    ms = _time_launches(lambda: h.sddmm(xs, gs))
-    entry("config 2 backward, trainable weights: dA = SDDMM(X, dY) K=128", ms, n, n, nnz, 128, False, "task list through isplib_graph_sddmm")
-    h.close()
-    del w, col32, xs, gs
+    if not only or only == "reddit-sddmm-k128":
+        h = cabi.GraphHandle(rowptr, col, w, n)
+        xs, gs = synth.features(n, 128, device=dev), synth.features(n, 128, seed=5, device=dev)
+        ms = _time_launches(lambda: h.sddmm(xs, gs))
+        entry("config 2 backward, trainable weights: dA = SDDMM(X, dY) K=128", ms, n, n, nnz, 128, False,
+              "task list (16 slices of whole rows) through isplib_graph_sddmm", key="reddit-sddmm-k128")
+        h.close()
+        del xs, gs
+    del w, col32
+    if only and not only.startswith("products"):
+        return out
 
-    # config 5: the GCN epoch of tests/cpu/gcn-sparse.py:55-129 through iSpLibPlugin.patch_pyg (scripts/gcn_epoch.py restates it)
+    if not only:
+        out.append(gcn_epoch_config(dev, rowptr, col, n, with_cpu_epoch))
+    out.extend(products_configs(dev, only))
+    return out
+
+
+def gcn_epoch_config(dev, rowptr, col, n, with_cpu_epoch):
+    """config 5: the GCN epoch of tests/cpu/gcn-sparse.py:55-129 through iSpLibPlugin.patch_pyg (scripts/gcn_epoch.py restates
+    it), with the same epoch on the host cores (the oracle doing every aggregation) beside it."""
+    import numpy as np
+    from isplib_amd import synth
     import importlib.util
     spec = importlib.util.spec_from_file_location("gcn_epoch", os.path.join(ROOT, "scripts", "gcn_epoch.py"))
     ge = importlib.util.module_from_spec(spec)
@@ -242,17 +274,61 @@ def extra_configs(dev, rowptr, col, n, with_cpu_epoch=True):
         rec["cpu_epoch"] = {"ms": statistics.mean(ctimes) * 1e3, "epochs_timed": len(ctimes), "cores": oracle.num_threads(), "kind": "port",
                             "what": "the same model and epoch structure on the host cores, every aggregation by oracle/fusedmm_oracle.c "
                                     "(OpenMP), dense layers and Adam by torch CPU"}
-    out.append(rec)
     del x, y, mask, model, opt, adj
+    return rec
 
-    # config 4's shape on ONE GPU: the dense operand (2.5 GB) is ten times the Infinity Cache; no schedule reuses it
-    # (isplib_suggest_stream / isplib_suggest_slices both say so): plain row-per-wave kernel
-    torch.cuda.empty_cache()
-    p_rowptr, p_col, pn = synth.dataset_like("products", device=dev)
-    px = synth.features(pn, 256, device=dev)
-    pz = torch.empty((pn, 256), dtype=torch.float32, device=dev)
-    ms = _time_launches(lambda: cabi.fusedMM_csr_hip(cabi.MSG_SPMM_SUM, p_rowptr, p_col, None, px, pz))
-    entry("config 4 (one GPU): products-like SpMM-sum K=256, unit weights", ms, pn, pn, p_col.numel(), 256, False, "plain row-per-wave kernel")
+
+def products_configs(dev, only=""):
+    """config 4's shape on ONE GPU: the dense operand (2.5 GB at K=256) is ten times the Infinity Cache, no schedule of this
+    library reuses a gathered row of it (isplib_suggest_stream / isplib_suggest_slices both say so) and the plain
+    row-per-wave kernel runs at the rate HBM serves random 1-KiB rows.  The only reuse there is lies in the graph: with the
+    rows taken in a community order (isplib_amd/reorder.py, fusedMM_csr_ordered_hip; bit-identical results) the rows of a
+    community are worked on together behind one XCD's L2.  Reported on BOTH graphs of this shape: the Chung-Lu graph
+    BASELINE's generator makes (no structure: the order search finds none, nothing changes) and a degree-corrected
+    stochastic block model of the same N, nnz and degree law (2,449 blocks, 80 % of the edges inside)."""
+    from isplib_amd import cabi, reorder, synth
+    try:
+        measured = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    except Exception:  # noqa: BLE001
+        measured = {}
+    out = []
+    k = 256
+    for tag, make in (("chunglu", lambda: synth.dataset_like("products", device=dev)), ("sbm", lambda: synth.sbm_like("products", device=dev))):
+        if only and not only.startswith(f"products-{tag}"):
+            continue
+        torch.cuda.empty_cache()
+        p_rowptr, p_col, pn = make()
+        e = p_col.numel()
+        px = synth.features(pn, k, device=dev)
+        pz = torch.empty((pn, k), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        order = reorder.useful_order(p_rowptr, p_col)
+        torch.cuda.synchronize()
+        search_ms = (time.perf_counter() - t0) * 1e3
+        graph = ("Chung-Lu graph (BASELINE's generator: no community structure)" if tag == "chunglu" else
+                 "degree-corrected SBM of the same N, nnz and degree law, 2,449 blocks, 80 % of the edges inside")
+        runs = [("plain row-per-wave kernel, rows in index order", None, f"products-{tag}-sum-k256-plain")]
+        if order is not None:
+            runs.append(("plain row-per-wave kernel, rows in the community order (label propagation, found once in "
+                         f"{search_ms:.0f} ms; bit-identical result)", order, f"products-{tag}-sum-k256-ordered"))
+        for sched, o, key in runs:
+            if only and only != key:
+                continue
+            ms = _time_launches(lambda: cabi.fusedMM_csr_ordered_hip(cabi.MSG_SPMM_SUM, p_rowptr, p_col, None, o, px, pz))
+            b_alg = synth.algorithmic_bytes(pn, pn, e, k, False)
+            rec = measured.get(key)
+            roof = {"bound": "hbm", "achieved": b_alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None if not rec else rec.get("fabric_bytes_per_launch"),
+                    "kernel_avg_ms": ms, "algorithmic_bytes_per_launch": b_alg,
+                    "gather_model_GBps": synth.gather_bytes(pn, e, k) / (ms * 1e-3) / 1e9}
+            if rec:
+                roof["traffic_source"] = f"profiles/traffic.json[{key}]: " + rec.get("source", "rocprofv3 --pmc, separate passes")
+            out.append({"config": f"config 4 (one GPU): products-like SpMM-sum K=256, unit weights, N={pn}, nnz={e}; {graph}",
+                        "ms": ms, "edges_per_s": e / (ms * 1e-3), "schedule": sched, "roofline": roof,
+                        "order_search": ("a community order was kept" if order is not None else
+                                         f"looked for a community order ({search_ms:.0f} ms, once): none worth keeping, index order")})
+        del p_rowptr, p_col, px, pz, order
     return out
 
 
@@ -574,6 +650,18 @@ def main():
     local_rank = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if a.only and not multi:
+        # one configuration of the `extra` array on its own (what scripts/prof_pmc.sh and rocprofv3 --kernel-trace are
+        # pointed at to fill profiles/traffic.json and the per-configuration kernel statistics)
+        from isplib_amd import synth as _synth
+        os.environ["ISPLIB_BENCH_ONLY"] = a.only
+        if a.only.startswith("products"):
+            extra = products_configs(dev, a.only)
+        else:
+            g_rowptr, g_col, g_n = _synth.dataset_like("reddit", device=dev)
+            extra = extra_configs(dev, g_rowptr, g_col, g_n, with_cpu_epoch=False)
+        print(json.dumps({"only": a.only, "extra": extra}), flush=True)
+        return
     import torch.distributed as dist
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -487,7 +487,9 @@ int    fusedMM_csr_hybrid_hip(int32_t imessage /* ISPLIB_MSG_SPMM_SUM | _MEAN */
  *   2  consecutive tasks per wave of the task kernel (0=auto) 4  column-panel width of the task entries, sum / mean (64)
  *   5  the same for max / min (64)                            8  per-slice footprint of whole rows (KiB) up to which a
  *      returns ISPLIB_FAIL for an unknown key                    task plan runs in one pass (9216; 0 = always panels)
- *   9  column-panel width of the sweep schedule: 32, 64 (default) or 128 */
+ *   9  column-panel width of the sweep schedule: 32, 64 (default) or 128
+ *  10  1: all generations of a stream pass in one launch (measured slower: 2.73 against 2.68 ms; default 0)
+ *  11  1: isplib_graph_sddmm takes the forward's stream plan (isplib_sddmm_stream_hip; measured slower; default 0) */
 int isplib_hip_tune(int key, int value);
 
 /* Warm-up hook with the reference's name; launches one empty kernel. */

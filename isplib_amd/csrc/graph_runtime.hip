@@ -16,6 +16,8 @@
 
 #include "common.h"
 
+namespace isplib { extern int g_sddmm_on_stream_plan; }   // tuning knob 11 (spmm_sweep.hip)
+
 using namespace isplib;
 
 namespace {
@@ -607,9 +609,12 @@ extern "C" int isplib_graph_sddmm(isplib_graph *g, int mean, int64_t k, const fl
    if (!g) return fail(ISPLIB_FAIL, "isplib_graph_sddmm: null handle");
    hipStream_t st = (hipStream_t)stream;
    Side &s = g->fwd;
-   // the forward's stream plan where there is one (same edges, same gathers: the SpMM's front end with g's rows in LDS;
-   // dA does not read the weights, a plan that carries some is used as it is)
-   if (k >= 4 && s.nnz < (1LL << 31)) {
+   // The forward's stream plan could serve dA too (isplib_sddmm_stream_hip: same edges, same gathers, g's rows in LDS where
+   // the SpMM keeps its accumulators) -- built, parity-tested, and SLOWER than the task list below on every shape measured
+   // (Reddit shape K=128: 4.04 ms against 3.54; K=64: 1.90 / 1.85; K=32: 1.42 / 1.07): per-edge
+   // results leave the CU through the plan's permutation, 4 bytes at a time, and the address pipeline the gathers are
+   // bound by pays for every one of them.  Opt-in for experiments: isplib_hip_tune(11, 1).
+   if (g_sddmm_on_stream_plan && k >= 4 && s.nnz < (1LL << 31)) {
       Side::Stream *sp = nullptr;
       const float *val_new = (s.val && weights_are_unit(s, st) != 1) ? s.val : nullptr;      // what a plan built here should carry
       const int rc = side_stream_plan(g, s, val_new, k, ldy, st, &sp);

@@ -1150,6 +1150,7 @@ static int launch_stream_minmax(const SweepArgs &a, hipStream_t st, int streams)
 
 int g_stream_merge_gens = 0; // tuning knob (isplib_hip_tune(10, 1)): all generations of a stream pass in ONE launch (a grid of
                              // gens x resident waves: a later generation's workgroup starts when an earlier one's ends)
+int g_sddmm_on_stream_plan = 0;   // tuning knob (isplib_hip_tune(11, 1)): isplib_graph_sddmm takes the forward's stream plan
 int g_sweep_panel = 64;     // tuning knob (isplib_hip_tune(9, w)): column-panel width of the sweep schedule, 32 / 64 / 128
 
 }  // namespace isplib

@@ -187,15 +187,17 @@ std::mutex g_graph_mutex;
 std::unordered_map<GraphKey, GraphCacheEntry, GraphKeyHash> g_graphs;
 // Handles whose graph is gone or has changed.  isplib_graph_destroy synchronises the device (nothing of the handle's may
 // still be in flight when its memory goes), which must not happen inside somebody's forward call: retired handles wait
-// here until graph_cache_clear() -- or, should a process retire graphs by the dozen, until the list is 32 long.
+// here until the next NEW graph gets its handle -- a point where the call synchronises anyway (the plan builders do) and
+// is about to allocate what the dead handles hold (plans of A and A^T, packed ids, CSC arrays, workspaces: several GB
+// for a Reddit-sized graph): a job that cycles through large graphs never holds more than the graphs retired since the
+// last one was created -- or until graph_cache_clear().  graph_cache_size() counts them in.
 std::vector<isplib_graph *> g_retired;
 
-void retire_handle_locked(isplib_graph *h) {
-   g_retired.push_back(h);
-   if (g_retired.size() >= 32) {
-      for (isplib_graph *r : g_retired) isplib_graph_destroy(r);
-      g_retired.clear();
-   }
+void retire_handle_locked(isplib_graph *h) { g_retired.push_back(h); }
+
+void destroy_retired_locked() {
+   for (isplib_graph *r : g_retired) isplib_graph_destroy(r);
+   g_retired.clear();
 }
 
 // the handle of the structure (rowptr, col) with N dense rows; g_graph_mutex must be held.  with_values: the call is
@@ -219,6 +221,7 @@ isplib_graph *graph_handle_locked(const Tensor &rowptr, const Tensor &col, const
             ++dead;
          }
       }
+      destroy_retired_locked();
       const Tensor first = with_values ? value : Tensor();
       GraphCacheEntry e(rowptr, col, first);
       check_status(isplib_graph_create(M, N, nnz, rowptr.data_ptr<int64_t>(), col.data_ptr<int64_t>(),
@@ -763,14 +766,13 @@ std::tuple<Tensor, Tensor> fusedmm_spmm_min(Tensor rowptr, Tensor col, optional<
 // introspection / housekeeping of the per-graph handle cache of the reference-schema operators
 int64_t graph_cache_size() {
    std::lock_guard<std::mutex> lock(g_graph_mutex);
-   return (int64_t)g_graphs.size();
+   return (int64_t)(g_graphs.size() + g_retired.size());
 }
 void graph_cache_clear() {
    std::lock_guard<std::mutex> lock(g_graph_mutex);
    for (auto &kv : g_graphs) isplib_graph_destroy(kv.second.handle);
    g_graphs.clear();
-   for (isplib_graph *r : g_retired) isplib_graph_destroy(r);
-   g_retired.clear();
+   destroy_retired_locked();
 }
 
 void performDummySpMM(int64_t flag) { performDummySpMM_hip(flag, (void *)c10::hip::getCurrentHIPStream().stream()); }

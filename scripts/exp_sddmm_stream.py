@@ -48,6 +48,9 @@ for b in range(0, nnz, step):
     mag[b:b + step] = (x[col[b:b + step]].abs() * g[row[b:b + step]].abs()).sum(1)
 print(f"   stream vs task list: max |diff| / (1e-5 sum|x||g|) = {float((err / (1e-5 * mag + 1e-30)).max()):.3f}", flush=True)
 h = cabi.GraphHandle(rowptr, col, None, n)
+print(f"   isplib_graph_sddmm (default: task list): {clock(lambda: h.sddmm(x, g)):.3f} ms", flush=True)
+cabi.lib().isplib_hip_tune(11, 1)
 hv = h.sddmm(x, g)
-print("   isplib_graph_sddmm takes the stream plan:", bool(torch.equal(hv, got)), f"{clock(lambda: h.sddmm(x, g)):.3f} ms", flush=True)
+print("   isplib_graph_sddmm with isplib_hip_tune(11, 1) takes the stream plan:", bool(torch.equal(hv, got)), f"{clock(lambda: h.sddmm(x, g)):.3f} ms", flush=True)
+cabi.lib().isplib_hip_tune(11, 0)
 h.close()
