@@ -52,10 +52,6 @@
 #ifndef ISPLIB_HYB4_HWR
 #define ISPLIB_HYB4_HWR 4
 #endif
-// second version (hot steps between the cold ones, two table buffers): rows of ONE table buffer; 64-column slots
-#ifndef ISPLIB_HYB2_HT
-#define ISPLIB_HYB2_HT 64
-#endif
 #ifndef ISPLIB_HYB8_NV
 #define ISPLIB_HYB8_NV 128
 #endif
@@ -923,202 +919,6 @@ __global__ __launch_bounds__(512, 2) void spmm_hybrid_kernel(const SweepArgs a) 
    }
 }
 
-// ---- hybrid form, second version: hot steps BETWEEN the cold ones ----------------------------------------------------
-// What the first version measured: the schedule is worth -13 %, serving the hot edges in one chunk per
-// phase costs more than that -- all eight waves of the CU sit in their chunk at the same time, issue no gathers and the
-// address pipeline runs dry.  What the drain experiments of round 3 showed: a wave that stalls costs nothing as long as the
-// CU's address pipeline has gathers queued.  So: the same tables and hot words, but (i) TWO table buffers of HT rows, slice
-// p+1 staged (LDS-DMA) while slice p is in use -- one barrier per phase, at its end, where every load has landed anyway;
-// (ii) the chunk's hot steps spread over the phase's first batch, one after every (U / HS)-th cold step, each a plain
-// synchronous LDS read-modify-write of the accumulator row (or a register add when the cold stream happens to hold that
-// row) -- its two LDS round trips stall the wave, not the CU.  A chunk is at most HS = 64 / G steps (one word register).
-template <int LPR, int NVMAX, int NBW, int HT>
-__global__ __launch_bounds__(512, 2) void spmm_hybrid2_kernel(const SweepArgs a) {
-   constexpr int WAVES = 8, G = 64 / LPR, PANEL = LPR * 4, U = 64 * NBW / G;
-   constexpr int PER = NVMAX / G, WAVE_FLOATS = NVMAX * PANEL;
-   constexpr int HS = 64 / G;                             // hot steps of a chunk: one word register
-   constexpr int EVERY = 2 * U / HS;                      // one hot slot after every EVERY-th cold step of the phase's first PAIR of batches
-   constexpr int SHARE = HT / WAVES, SI = SHARE / G;      // table rows / DMA instructions of one wave per slice
-   static_assert(NVMAX <= 256 && NVMAX % G == 0 && HT % (WAVES * G) == 0 && SHARE <= 64 && (2 * U) % HS == 0 && EVERY >= 1 && U % EVERY == 0, "geometry");
-   static_assert(U + NBW <= 63, "counted vmcnt wait");
-   static_assert((WAVES * WAVE_FLOATS + 2 * HT * PANEL) * 4 <= 163840, "accumulators + two tables must fit the CU's LDS");
-   __shared__ __attribute__((aligned(16))) float s_all[WAVES * WAVE_FLOATS + 2 * HT * PANEL];
-   const int lane = threadIdx.x & 63;
-   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-   const int g = lane / LPR, lc = lane % LPR;
-   const int wl = (int)blockIdx.x * WAVES + wave;         // the entry launches whole workgroups: wave_count % 8 == 0
-   const int64_t w = (int64_t)a.wave_base + wl;
-   float *my = s_all + wave * WAVE_FLOATS;
-   float *tables = s_all + WAVES * WAVE_FLOATS;
-   for (int i = lane * 4; i < WAVE_FLOATS; i += 256)
-      *reinterpret_cast<float4 *>(my + i) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-   for (int i = lane * 4; i < 2 * SHARE * PANEL; i += 256) // both tables: their last row (and rows no slice fills) must read 0
-      *reinterpret_cast<float4 *>(tables + wave * 2 * SHARE * PANEL + i) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-   __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.y), 0, (int)a.ybytes, 0x00020000);
-   const bool cok = lc * 4 < a.k;
-   int ccol = lc * 4, vfirst = 0;
-   if (cok && ccol + 4 > (int)a.k) { vfirst = ccol + 4 - (int)a.k; ccol = (int)a.k - 4; }
-   const unsigned cbyte = (unsigned)ccol * 4u, poison = cok ? 0u : BUF_OOB;
-   float *lane_base = my + lc * 4;
-   const unsigned long long ybase = (unsigned long long)a.y;
-   const v4i_rsrc_t rsrc_dma = {(int)(unsigned)ybase, (int)((ybase >> 32) & 0xFFFFu), (int)a.ybytes, 0x00020000};
-   const unsigned tables_lds = (unsigned)(size_t)(__attribute__((address_space(3))) float *)tables;
-   const int64_t s0 = a.wave_step_off[w], s1 = a.wave_step_off[w + 1];
-   const int64_t nwords = (s1 - s0) * G;
-   const int32_t *wp = a.words + s0 * G;
-   const unsigned ldyb = (unsigned)a.ldy * 4u;
-   const unsigned pad_word = ((unsigned)((lane % G) * PER) << 24) | a.null_word;
-   const unsigned pad_hot = ((unsigned)((lane % G) * PER) << 24) | (unsigned)(HT - 1);
-   auto load_words = [&](int64_t first, unsigned (&word)[NBW]) {
-#pragma unroll
-      for (int q = 0; q < NBW; q++) {
-         const int64_t i = first + q * 64 + lane;
-         word[q] = i < nwords ? (unsigned)wp[i] : pad_word;
-      }
-   };
-   unsigned wA[NBW], wB[NBW];                              // even / odd batches, used in turn and never copied: no wait the
-   v4i_t t[U];                                             // compiler adds drains the pipeline (a CU whose eight waves meet at a
-                                                           // barrier every phase would drain it for all of them at once)
-   unsigned la[U];
-   auto issue = [&](int u, const unsigned (&word_l)[NBW]) {
-      const unsigned word = (unsigned)__shfl((int)word_l[(u * G) / 64], (u * G) % 64 + g);
-      const unsigned o = (__umul24(word & 0xFFFFFFu, ldyb) + cbyte) | poison;
-      la[u] = (word >> 24) * (unsigned)PANEL;
-      t[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)o, 0, 0);
-   };
-   const int S = a.slices;
-   const int64_t *hoff = a.hot_step_off + w * S;
-   const int64_t hbase = hoff[0];
-   const int hbase_lo = (int)hbase;
-   auto load_hblock = [&](int p0) -> int { return p0 + lane <= S ? reinterpret_cast<const int *>(hoff)[2 * (p0 + lane)] : 0; };
-   int hp0 = 0;
-   int hblk = load_hblock(0), hblk_next = load_hblock(63);
-   // the chunk of phase p: its step count (uniform) and its words (one register: lane i = step i / G, slot i % G)
-   auto load_hot = [&](int p, int &steps) -> unsigned {
-      if (p >= S) { steps = 0; return pad_hot; }
-      if (p - hp0 >= 63) {
-         hp0 += 63;
-         hblk = hblk_next;
-         hblk_next = load_hblock(hp0 + 63);
-      }
-      const int o0 = __builtin_amdgcn_readlane(hblk, p - hp0) - hbase_lo, o1 = __builtin_amdgcn_readlane(hblk, p - hp0 + 1) - hbase_lo;
-      steps = o1 - o0;
-      const int32_t *hp = a.hot_words + (hbase + o0) * G;
-      return lane < steps * G ? (unsigned)hp[lane] : pad_hot;
-   };
-   auto load_ids = [&](int p) -> int {
-      return (p < S && lane < SHARE) ? a.hot_rows[(size_t)p * HT + wave * SHARE + lane] : (int)a.null_word;
-   };
-   auto stage = [&](int ids, int buf) {
-#pragma unroll
-      for (int j = 0; j < SI; j++) {
-         const unsigned cid = (unsigned)__shfl(ids, j * G + g);
-         const unsigned o = (__umul24(cid, ldyb) + cbyte) | poison;
-         lds_dma_b128(rsrc_dma, o, tables_lds + (unsigned)((buf * HT + wave * SHARE + j * G) * PANEL * 4));
-      }
-   };
-   unsigned cur = (unsigned)(g * PER * PANEL);
-   float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-   auto flush = [&]() {
-      float4 *p = reinterpret_cast<float4 *>(lane_base + cur);
-      float4 o = *p;
-      o.x += acc[0]; o.y += acc[1]; o.z += acc[2]; o.w += acc[3];
-      *p = o;
-   };
-   load_words(0, wA);
-   load_words(64 * NBW, wB);
-#pragma unroll
-   for (int u = 0; u < U; u++) issue(u, wA);
-   load_words(128 * NBW, wA);
-   int ids = load_ids(0);
-   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // own zeroing of the tables first: DMA writes are not ordered behind ds_writes
-   stage(ids, 0);
-   ids = load_ids(1);
-   int hn = 0, hn_next = 0;
-   unsigned hwb = load_hot(0, hn), hwn = pad_hot;
-   __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(0));
-   asm volatile("s_barrier" ::: "memory");
-   const int64_t npairs = ((nwords + 64 * NBW - 1) / (64 * NBW) + 1) / 2;
-   const int pairs_q = (int)(npairs / S), pairs_r = (int)(npairs % S);
-   int pairs_err = 0;
-   int64_t b = 0;                                          // pairs done
-   const float *table_lane = tables + lc * 4;
-   // one batch; HOT: the chunk's hot slots first + j0, first + j0 + 1, ... ride on every EVERY-th cold step
-   auto run_batch = [&](int64_t bb, unsigned (&wnext)[NBW], bool hot, int first) {
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-         if (la[u] != cur) {
-            flush();
-            cur = la[u];
-            acc[0] = acc[1] = acc[2] = acc[3] = 0.0f;
-         }
-#pragma unroll
-         for (int v = 0; v < 4; v++) acc[v] += __int_as_float(t[u][v]);
-         __builtin_amdgcn_sched_barrier(0);                // the old t[u] is consumed before the new one is issued: no copy
-         issue(u, wnext);
-         if (hot && (u % EVERY) == EVERY - 1) {
-            const int j = first + u / EVERY;
-            if (j < hn) {                                  // uniform
-               const unsigned wd = (unsigned)__shfl((int)hwb, j * G + g);
-               const float4 tv = *reinterpret_cast<const float4 *>(table_lane + (wd & 0xFFFFu) * (unsigned)PANEL);
-               const unsigned lrow = (wd >> 24) * (unsigned)PANEL;
-               if (lrow == cur) {                          // the cold stream holds this row in registers: add there
-                  acc[0] += tv.x; acc[1] += tv.y; acc[2] += tv.z; acc[3] += tv.w;
-               } else {
-                  float4 *pr = reinterpret_cast<float4 *>(lane_base + lrow);
-                  float4 o = *pr;
-                  o.x += tv.x; o.y += tv.y; o.z += tv.z; o.w += tv.w;
-                  *pr = o;
-               }
-            }
-         }
-      }
-      load_words((bb + 3) * 64 * NBW, wnext);
-   };
-   for (int p = 0; p < S; p++) {
-      table_lane = tables + (p & 1) * HT * PANEL + lc * 4;
-      if (p + 1 < S) stage(ids, (p + 1) & 1);             // the other buffer: everyone left it at the end of phase p - 1
-      ids = load_ids(p + 2);
-      hwn = load_hot(p + 1, hn_next);
-      int quota = pairs_q;
-      pairs_err += pairs_r;
-      if (pairs_err >= S) { pairs_err -= S; quota++; }
-      const int64_t b_end = b + (quota > 0 ? quota : 1);   // never none: the chunk rides on a pair (padding gathers if need be)
-      // the phase's first pair of batches carries the chunk's hot steps
-      run_batch(2 * b, wB, true, 0);
-      run_batch(2 * b + 1, wA, true, U / EVERY);
-      while (++b < b_end) {
-         run_batch(2 * b, wB, false, 0);
-         run_batch(2 * b + 1, wA, false, 0);
-      }
-      // table p+1 (staged before the phase's first pair) and the next chunk's words are older than the last batch's U
-      // gathers and NBW word loads: a counted wait says they have landed and leaves the gathers in flight
-      __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(U + NBW));
-      hwb = hwn;
-      hn = hn_next;
-      asm volatile("s_barrier" ::: "memory");              // table p+1 complete, everyone done with table p
-   }
-   flush();
-#pragma unroll 1
-   for (int jj = 0; jj < PER; jj++) {
-      const int lrow = g * PER + jj;
-      const int row = a.wave_row[(size_t)w * NVMAX + lrow];
-      if (row < 0 || !cok) continue;
-      const int part = a.wave_part[(size_t)w * NVMAX + lrow];
-      const float4 t4 = *reinterpret_cast<const float4 *>(lane_base + lrow * PANEL);
-      float v[4] = {t4.x, t4.y, t4.z, t4.w};
-      int bi[4] = {INT_MAX, INT_MAX, INT_MAX, INT_MAX};
-      const int c = ccol;
-      if (part >= 0) {
-         store_tail<4>(a.part_val + (size_t)part * (size_t)a.k + c, v, vfirst);
-         continue;
-      }
-      int64_t arg[4];
-      finish_row<OP_ADD>(a, row, c, v, bi, arg);
-      store_tail<4>(a.z + (size_t)row * (size_t)a.ldz + c, v, vfirst);
-   }
-}
-
 // max / min on the stream schedule.  The running sum becomes the best value so far and the WORD INDEX (position in the
 // wave's stream) at which it was met; a second LDS plane keeps those indices beside the values.  "Strictly better
 // wins" in stream order: the plan walks the edges of a row slice by slice and, inside a slice, in CSR order, so for rows
@@ -1793,9 +1593,7 @@ extern "C" int fusedMM_csr_hybrid_hip(int32_t imessage, int64_t m, int64_t n, in
    if (plan->rows != m || plan->cols != n) return fail(ISPLIB_FAIL, "fusedMM_csr_hybrid_hip: the plan was built for another shape");
    if (n >= (1LL << 24) || ldy >= (1LL << 22)) return fail(ISPLIB_FAIL, "fusedMM_csr_hybrid_hip: n must be < 2^24 and ldy < 2^22 (24-bit address arithmetic)");
    if (plan->streams != 4 && plan->streams != 8) return fail(ISPLIB_FAIL, "fusedMM_csr_hybrid_hip: bad plan geometry (streams 4 or 8)");
-   HybridGeom ge = hybrid_geom(plan->streams);
-   const bool v2 = plan->streams == 4 && hp->table_rows == ISPLIB_HYB2_HT;      // the second version: two buffers of this many rows
-   if (v2) { ge.ht = ISPLIB_HYB2_HT; ge.hwr = 1; }
+   const HybridGeom ge = hybrid_geom(plan->streams);
    if (plan->gens < 1 || plan->waves_per_gen < 8 || (plan->waves_per_gen % 8) != 0 || plan->rows_per_wave != ge.nvmax ||
        hp->table_rows != ge.ht || hp->hot_cap > ge.hwr * (64 / plan->streams) || plan->slices < 1)
       return fail(ISPLIB_FAIL, "fusedMM_csr_hybrid_hip: bad plan geometry (isplib_spmm_hybrid_geometry reports rows per wave, table rows and the hot-step cap; waves_per_gen must be a multiple of 8)");
@@ -1844,9 +1642,7 @@ extern "C" int fusedMM_csr_hybrid_hip(int32_t imessage, int64_t m, int64_t n, in
          p.wave_base = gen * plan->waves_per_gen;
          p.wave_count = plan->waves_per_gen;
          const unsigned blocks = (unsigned)(p.wave_count / 8);
-         if (v2)
-            hipLaunchKernelGGL((spmm_hybrid2_kernel<16, ISPLIB_HYB4_NV, ISPLIB_HYB4_NBW, ISPLIB_HYB2_HT>), dim3(blocks), dim3(512), 0, st, p);
-         else if (plan->streams == 4)
+         if (plan->streams == 4)
             hipLaunchKernelGGL((spmm_hybrid_kernel<16, ISPLIB_HYB4_NV, ISPLIB_HYB4_NBW, ISPLIB_HYB4_HT, ISPLIB_HYB4_HWR>), dim3(blocks), dim3(512), 0, st, p);
          else
             hipLaunchKernelGGL((spmm_hybrid_kernel<8, ISPLIB_HYB8_NV, ISPLIB_HYB8_NBW, ISPLIB_HYB8_HT, ISPLIB_HYB8_HWR>), dim3(blocks), dim3(512), 0, st, p);
