@@ -17,7 +17,7 @@ import torch  # noqa: E402
 
 import oracle  # noqa: E402
 from isplib_amd import cabi  # noqa: E402
-from isplib_amd.plan import build_stream_plan, build_sweep_plan, build_task_plan  # noqa: E402
+from isplib_amd.plan import build_hybrid_plan, build_stream_plan, build_sweep_plan, build_task_plan  # noqa: E402
 from tests import cases  # noqa: E402
 
 
@@ -82,10 +82,16 @@ def main():
                 mplan = build_stream_plan(d_rowptr, d_col, d_val, n, s_geom[0], s_geom[1], None, mstreams, s_geom[2], minmax=True)
             if k % 4 == 0 and ld % 4 == 0:
                 wplan = build_sweep_plan(d_rowptr, d_col, n, s_geom[0], s_geom[1], int(rng.choice([8, 16])), s_geom[2], int(rng.choice([1, 8])))
+        # round 3: the hybrid form (unit weights; hot rows of y from an LDS table) and the plain kernel in a random row order
+        hplan = None
+        if k >= 4 and col.size and unit:
+            hplan = build_hybrid_plan(d_rowptr, d_col, n, int(rng.choice([1, 3, 7, 20])), int(rng.choice([4, 8])), int(rng.choice([64, 300, 2048])),
+                                      waves_per_gen=8 * int(rng.integers(1, 3)), min_refs=int(rng.choice([1, 2, 5])))
+        order = torch.randperm(m, device=dev).to(torch.int32) if rng.random() < 0.8 else None
         for red in cases.REDUCES:
             ref, ref_arg = oracle.spmm_fw(rowptr, col, hv, x, red)
             outs = {}
-            for name in ("plain", "sliced", "tasks", "stream", "sweep"):
+            for name in ("plain", "sliced", "tasks", "stream", "sweep", "ordered", "hybrid"):
                 out = torch.full((m, ld), 7.0, device=dev)[:, :k]
                 arg = torch.full((m, ld), -5, dtype=torch.int64, device=dev)[:, :k] if red in ("max", "min") else None
                 if name == "plain":
@@ -101,9 +107,17 @@ def main():
                     cabi.fusedMM_csr_stream_minmax_hip(cabi.MESSAGE[red], d_rowptr, col.size, mplan, d_x, out, arg, mplan.workspace(minmax=True))
                 elif name == "sweep" and wplan is not None:
                     cabi.fusedMM_csr_sweep_hip(cabi.MESSAGE[red], d_rowptr, d_col, d_val, wplan, d_x, out, arg, wplan.workspace(red, k))
+                elif name == "ordered":
+                    cabi.fusedMM_csr_ordered_hip(cabi.MESSAGE[red], d_rowptr, d_col, d_val, order, d_x, out, arg)
+                elif name == "hybrid" and hplan is not None and red in ("sum", "mean"):
+                    cabi.fusedMM_csr_hybrid_hip(cabi.MESSAGE[red], d_rowptr, col.size, hplan, d_x, out, hplan.workspace())
                 else:
                     continue
                 outs[name] = (out.cpu().numpy(), None if arg is None else arg.cpu().numpy())
+            if "ordered" in outs and not (np.array_equal(outs["ordered"][0].view(np.uint32), outs["plain"][0].view(np.uint32))
+                                          and (outs["plain"][1] is None or np.array_equal(outs["ordered"][1], outs["plain"][1]))):
+                bad += 1
+                print(f"MISMATCH case {case}: ordered/{red} is not bit for bit the plain kernel, m={m} n={n} k={k}", flush=True)
             for name, (o, ar) in outs.items():
                 if red in ("max", "min"):
                     ok = np.array_equal(o.view(np.uint32), ref.view(np.uint32)) and np.array_equal(ar, ref_arg)
@@ -119,7 +133,8 @@ def main():
                     bad += 1
                     print(f"MISMATCH case {case}: {name}/{red} m={m} n={n} k={k} ld={ld} deg={deg} hub={hub} slices={slices} "
                           f"chunk={chunk} short={short} unit={unit} integer={integer}"
-                          + (f" streams={streams} stream geometry={s_geom} native={native}" if name in ("stream", "sweep") else ""), flush=True)
+                          + (f" streams={streams} stream geometry={s_geom} native={native}" if name in ("stream", "sweep") else "")
+                          + (f" hybrid: {hplan.cold.streams} streams, {hplan.cold.slices} slices, {hplan.hot_edges} hot edges" if name == "hybrid" else ""), flush=True)
         if native and splan is not None:
             splan.close()
         if native and mplan is not None:
@@ -152,6 +167,12 @@ def main():
             if plan is not None:
                 checks.append(("sddmm_tasks", bool(np.all(np.abs(cabi.sddmm_tasks(d_rowptr, d_col, plan, d_xc, d_g).cpu().numpy() - da64)
                                                           <= 1e-5 * xg + 1e-30))))
+            if k >= 4:                                  # dA on a stream plan of the SpMM (any slot width, any geometry)
+                sp2 = build_stream_plan(d_rowptr, d_col, None, n, int(rng.choice([1, 2, 5, 9])), int(rng.integers(1, 9)), None,
+                                        int(rng.choice([2, 4, 8])), int(rng.choice([64, 300, 2048])))
+                da = cabi.sddmm_stream(d_rowptr, col.size, sp2, d_xc, d_g)
+                checks.append(("sddmm_stream", bool(np.all(np.abs(da.cpu().numpy() - da64) <= 1e-5 * xg + 1e-30))))
+                checks.append(("sddmm_stream/reproducible", bool(torch.equal(da, cabi.sddmm_stream(d_rowptr, col.size, sp2, d_xc, d_g)))))
             _, arg_h = oracle.spmm_fw(rowptr, col, hv, x, "max")
             gv_h, gm_h = oracle.spmm_minmax_bw(col, hv, x, arg_h, g)
             gv, gm = cabi.spmm_minmax_bw(d_col, None if unit else t(val), d_xc, t(arg_h), d_g)
