@@ -64,6 +64,19 @@
 #ifndef ISPLIB_HYB8_HWR
 #define ISPLIB_HYB8_HWR 8
 #endif
+// the same for the 32-column stream kernel (8-lane slots, k <= 32).  Round 3: 128 rows per wave x 2 workgroups per CU hold
+// the Reddit shape's 246 K (virtual) rows in ONE generation of 2,048 waves -- one dispatch per pass instead of two -- with
+// 32 gathers in flight per wave: K=32 0.715 ms against 0.813 with 64 rows / 16 in flight / 3 workgroups per CU (128 rows
+// with 16 or 24 in flight: 0.760 / 0.729; 96 rows: 0.778)
+#ifndef ISPLIB_STREAM_NV8
+#define ISPLIB_STREAM_NV8 128
+#endif
+#ifndef ISPLIB_STREAM_NBW8
+#define ISPLIB_STREAM_NBW8 4
+#endif
+#ifndef ISPLIB_STREAM_WGS8
+#define ISPLIB_STREAM_WGS8 2
+#endif
 // the same for max / min (a second LDS plane holds the winners' positions: half the rows per wave of the sum kernel);
 // 64-column slots, and 32-column slots (k <= 32: eight rows per gather, 32 gathers in flight from four batch registers)
 #ifndef ISPLIB_STREAM_MM_NV
@@ -1113,7 +1126,7 @@ static StreamGeom stream_geom(int streams, bool minmax = false) {
                                    : StreamGeom{ISPLIB_STREAM_MM_NV, ISPLIB_STREAM_MM_NBW, ISPLIB_STREAM_MM_WGS};
    if (streams == 2) return {32, 1, 2};     // 128-column panels: U = 32 gathers of 1 KiB per wave
    if (streams == 4) return {ISPLIB_STREAM_NV4, ISPLIB_STREAM_NBW4, ISPLIB_STREAM_WGS4};
-   return {64, 2, 3};                       // 32-column panels: U = 16
+   return {ISPLIB_STREAM_NV8, ISPLIB_STREAM_NBW8, ISPLIB_STREAM_WGS8};   // 32-column panels
 }
 
 static int stream_resident_waves(int streams, int cus, bool minmax = false) {
@@ -1139,7 +1152,7 @@ static int launch_stream(const SweepArgs &a_in, hipStream_t st) {
    if (blocks == 0) return ISPLIB_SUCCESS;
    if constexpr (LPR == 32) hipLaunchKernelGGL((spmm_stream_kernel<32, HAS_VAL, 32, 1, 2>), dim3(blocks), dim3(256), 0, st, a);
    else if constexpr (LPR == 16) hipLaunchKernelGGL((spmm_stream_kernel<16, HAS_VAL, ISPLIB_STREAM_NV4, ISPLIB_STREAM_NBW4, ISPLIB_STREAM_WGS4>), dim3(blocks), dim3(256), 0, st, a);
-   else hipLaunchKernelGGL((spmm_stream_kernel<8, HAS_VAL, 64, 2, 3>), dim3(blocks), dim3(256), 0, st, a);
+   else hipLaunchKernelGGL((spmm_stream_kernel<8, HAS_VAL, ISPLIB_STREAM_NV8, ISPLIB_STREAM_NBW8, ISPLIB_STREAM_WGS8>), dim3(blocks), dim3(256), 0, st, a);
    return check_launch("spmm_stream_kernel");
 }
 
@@ -1495,7 +1508,7 @@ static int launch_sddmm_stream(const SweepArgs &a, hipStream_t st) {
    if (blocks == 0) return ISPLIB_SUCCESS;
    if constexpr (LPR == 32) hipLaunchKernelGGL((sddmm_stream_kernel<32, 32, 1, 2, ACCUM>), dim3(blocks), dim3(256), 0, st, a);
    else if constexpr (LPR == 16) hipLaunchKernelGGL((sddmm_stream_kernel<16, ISPLIB_STREAM_NV4, ISPLIB_STREAM_NBW4, ISPLIB_STREAM_WGS4, ACCUM>), dim3(blocks), dim3(256), 0, st, a);
-   else hipLaunchKernelGGL((sddmm_stream_kernel<8, 64, 2, 3, ACCUM>), dim3(blocks), dim3(256), 0, st, a);
+   else hipLaunchKernelGGL((sddmm_stream_kernel<8, ISPLIB_STREAM_NV8, ISPLIB_STREAM_NBW8, ISPLIB_STREAM_WGS8, ACCUM>), dim3(blocks), dim3(256), 0, st, a);
    return check_launch("sddmm_stream_kernel");
 }
 
