@@ -14,6 +14,7 @@ Everything is built on the device through the C ABI (``isplib_spmm_slices_build_
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -320,7 +321,13 @@ def stream_plan_arrays(rowptr: torch.Tensor, col: torch.Tensor, ncols: int, slic
         hub_off[1:] = torch.cumsum(nchunk[hub_rows], 0).to(torch.int32)
     # the edges, stream by stream: (stream, slice, row of the stream) then CSR order (stable sort)
     width = -(-ncols // slices)
-    key = (sid[ev] * slices + col // width) * per + rnd[ev]
+    if os.environ.get("ISPLIB_EXP_STREAM_ORDER") == "col":
+        # experiment (scripts/exp_colorder.py): inside a (stream, slice) group the words in COLUMN order instead of row by row --
+        # the 32 streams of a CU then sweep a slice's columns together and popular rows of y are gathered by several of them
+        # within a few steps of each other (L1 reuse?); the price is a change of accumulator row at nearly every step
+        key = (sid[ev] * slices + col // width) * width + col % width
+    else:
+        key = (sid[ev] * slices + col // width) * per + rnd[ev]
     perm = torch.sort(key, stable=True).indices
     del key
     e_sid = sid[ev][perm]
