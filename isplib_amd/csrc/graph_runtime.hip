@@ -41,7 +41,14 @@ struct Side {                    // A, or A^T, as CSR
    std::map<int, Plan> plans;
    // stream plans (sum / mean) per (streams, slices, chunk); the weights they were last given (the plans own a copy in
    // stream order: `val` of the side, or the mean backward's weights)
-   struct Stream { isplib_stream_plan plan; const float *vals_of = nullptr; bool has_vals = false; uint64_t gen = 0; };
+   // `other`: a second copy of the weights in stream order, for the side that serves two kinds of them in turn (A^T: the
+   // sum backward's val[csr2csc] and the mean backward's val[csr2csc] / deg): a model that mixes sum and mean aggregation
+   // on one weighted graph swaps the two copies instead of re-gathering nnz weights at every backward
+   struct Stream {
+      isplib_stream_plan plan;
+      const float *vals_of = nullptr; bool has_vals = false; uint64_t gen = 0;
+      float *other = nullptr; const float *other_of = nullptr; uint64_t other_gen = 0;
+   };
    std::map<uint64_t, Stream> streams;
    // plain-kernel rows in a community order (reorder.hip), for dense operands larger than the Infinity Cache: found on
    // first need (order_state 0 -> 1: tried and kept in `order`, or 2: tried, no structure found / not applicable), or
@@ -77,7 +84,7 @@ void free_side(Side &s, bool owns_arrays) {
       (void)hipFree(kv.second.seg_off); (void)hipFree(kv.second.task_b);
    }
    s.plans.clear();
-   for (auto &kv : s.streams) isplib_stream_plan_free(&kv.second.plan);
+   for (auto &kv : s.streams) { isplib_stream_plan_free(&kv.second.plan); (void)hipFree(kv.second.other); }
    s.streams.clear();
    (void)hipFree(s.col32);
    if (s.order_state == 1) (void)hipFree(s.order);
@@ -404,8 +411,23 @@ static int run_side(isplib_graph *g, Side &s, const float *val, int32_t imessage
       if (sp) {
          if (sp->vals_of != val || sp->has_vals != (val != nullptr) || (val && sp->gen != g->val_gen)) {
             // other weights than last time (sum vs mean backward), or new contents (isplib_graph_set_values)
-            rc = isplib_stream_plan_set_values_hip(&sp->plan, val, st);
-            if (rc) return rc;
+            if (val && sp->has_vals && sp->plan.vals) {
+               // both weighted: the copy being replaced is parked in `other`; if `other` already holds what is wanted
+               // (same source array, same generation) the two are swapped and nothing is gathered
+               float *parked = const_cast<float *>(sp->plan.vals);
+               const float *parked_of = sp->vals_of;
+               const uint64_t parked_gen = sp->gen;
+               const bool hit = sp->other && sp->other_of == val && sp->other_gen == g->val_gen;
+               sp->plan.vals = sp->other;                  // NULL: set_values allocates a fresh array
+               if (!hit) {
+                  rc = isplib_stream_plan_set_values_hip(&sp->plan, val, st);
+                  if (rc) { sp->plan.vals = parked; return rc; }
+               }
+               sp->other = parked; sp->other_of = parked_of; sp->other_gen = parked_gen;
+            } else {
+               rc = isplib_stream_plan_set_values_hip(&sp->plan, val, st);
+               if (rc) return rc;
+            }
             sp->vals_of = val; sp->has_vals = val != nullptr; sp->gen = g->val_gen;
          }
          const size_t need = isplib_spmm_stream_workspace_bytes(&sp->plan);

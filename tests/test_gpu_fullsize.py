@@ -396,6 +396,11 @@ def test_fullsize_weighted_nonsymmetric_backward(gpu, reddit, oracle_mod):
     try:
         dx_sum = h.spmm_backward(dy, mean=False)
         dx_mean = h.spmm_backward(dy, mean=True)
+        # the two backward kinds share the plan of A^T and swap two parked copies of their weights: alternating must keep
+        # giving the same bits (round-2 advisor: no re-gather per switch; a stale or mixed-up copy would show here)
+        for _ in range(2):
+            assert torch.equal(h.spmm_backward(dy, mean=False), dx_sum)
+            assert torch.equal(h.spmm_backward(dy, mean=True), dx_mean)
         dval = h.sddmm(x, dy, mean=False)
         dval_mean = h.sddmm(x, dy, mean=True)
         torch.cuda.synchronize()
