@@ -935,6 +935,14 @@ class GraphHandle:
     def set_slices(self, slices: int) -> None:
         _check(lib().isplib_graph_set_slices(self._h, int(slices)), "isplib_graph_set_slices")
 
+    def set_row_order(self, order, order_t=None) -> None:
+        """The plain kernel's row order of A / of A^T (int32, position -> row; None = index order, and no search for one)."""
+        self.order = None if order is None else _dev(order, "order", torch.int32)           # borrowed by the handle: keep them alive
+        self.order_t = None if order_t is None else _dev(order_t, "order_t", torch.int32)
+        assert self.order is None or self.order.numel() == self.m
+        assert self.order_t is None or self.order_t.numel() == self.n
+        _check(lib().isplib_graph_set_row_order(self._h, _ptr(self.order), _ptr(self.order_t)), "isplib_graph_set_row_order")
+
     def set_values(self, val) -> None:
         """New weights for the same structure (another array, the same one edited in place, or None = unit weights)."""
         self.val = None if val is None else _dev(val, "val", torch.float32)

@@ -357,6 +357,19 @@ def test_ordered_plain_kernel_is_bitwise_the_plain_kernel(gpu, oracle_mod, k):
             assert torch.equal(got.view(torch.int32), want.view(torch.int32)), (red, k)
             if want_arg is not None:
                 assert torch.equal(got_arg, want_arg), (red, k)
+    # the handle with an order given by the caller (and forced onto the plain kernel), forward and backward
+    h = cabi.GraphHandle(rowptr2, col2, val, n)
+    try:
+        h.set_slices(0)
+        h.set_row_order(shuffled, order)
+        for red in ("sum", "max"):
+            got, got_arg = h.spmm(x, red)
+            want, want_arg = cabi.spmm(rowptr2, col2, val, x, red)
+            assert torch.equal(got, want) and (want_arg is None or torch.equal(got_arg, want_arg)), red
+        colptr, _, row_t, val_t = cabi.csr2csc(rowptr2, col2, val, n, want_perm=False)
+        assert torch.equal(h.spmm_backward(x, mean=False), cabi.spmm(colptr, row_t, val_t, x, "sum")[0])
+    finally:
+        h.close()
     ref, _ = oracle_mod.spmm_fw(rowptr2.cpu().numpy(), col2.cpu().numpy(), val.cpu().numpy(), x.cpu().numpy(), "max")
     got, _ = cabi.spmm_ordered(rowptr2, col2, val, order, x, "max")
     assert np.array_equal(got.cpu().numpy().view(np.uint32), ref.view(np.uint32))
