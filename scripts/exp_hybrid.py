@@ -43,8 +43,8 @@ for spec in os.environ.get("HYB", default).split(","):
     f = [int(v) for v in spec.split(":")]
     st, sl, refs = f[0], f[1], (f[2] if len(f) > 2 else 2)
     rpw, resident, ht, cap = cabi.hybrid_geometry(st)
-    if len(f) > 4:                       # st:slices:refs:table_rows:hot_cap -- the second version's geometry (64 rows x 2 buffers, 16 steps)
-        ht, cap = f[3], f[4]
+    if len(f) > 4:                       # st:slices:refs:table_rows:hot_cap -- another geometry than the built kernel's (the second
+        ht, cap = f[3], f[4]             # version of commit 810ada5 took 64 rows x 2 buffers, 16 steps; today's entry refuses it)
     chunk_h = max(256, int(nnz / (-(-n // (rpw * resident)) * resident * st) / 3.4))
     try:
         hp = build_hybrid_plan(rowptr, col, n, sl, st, chunk_h, min_refs=refs, table_rows=ht, hot_cap=cap)
