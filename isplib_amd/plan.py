@@ -300,12 +300,19 @@ def stream_plan_arrays(rowptr: torch.Tensor, col: torch.Tensor, ncols: int, slic
     sid = torch.empty(nv, **i64)
     rnd = torch.empty(nv, **i64)
     loads = torch.zeros(ns, **i64)
+    # experiment (scripts/exp_xcd_bias.py): workgroups on even XCDs run 1-2 % slower than the mean:
+    # count an edge dealt to one of their streams as 1 + bias edges, so that they get fewer
+    bias = float(os.environ.get("ISPLIB_EXP_XCD_BIAS", "0"))
+    cost = None
+    if bias != 0.0:
+        blk = (torch.arange(ns, **i64) // streams % waves_per_gen) // 4          # workgroup of the stream inside its launch
+        cost = torch.where(blk % 2 == 0, 1024 + int(round(1024 * bias)), 1024 - int(round(1024 * bias))).to(torch.int64)
     for r in range(-(-nv // ns)):
         items = order[r * ns:(r + 1) * ns]
         to = torch.sort(loads, stable=True).indices[:items.numel()]
         sid[items] = to
         rnd[items] = r
-        loads[to] += vlen[items]
+        loads[to] += vlen[items] if cost is None else vlen[items] * cost[to]
     wave, slot = sid // streams, sid % streams
     lrow = slot * per + rnd                                      # local row inside the wave
     is_hub = nchunk[vrow] > 1

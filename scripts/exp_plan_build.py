@@ -36,6 +36,18 @@ nat = cabi.NativeStreamPlan(rowptr, col, val, n, streams, slices, chunk)
 print("native set_values           :", [f"{t:.2f}" for t in clock(lambda: nat.set_values(val))], "ms", flush=True)
 print("task plan (8 slices)        :", [f"{t:.1f}" for t in clock(lambda: build_task_plan(rowptr, col, n, 8))], "ms", flush=True)
 print("csr2csc (weights)           :", [f"{t:.1f}" for t in clock(lambda: cabi.csr2csc(rowptr, col, val, n, want_perm=False))], "ms", flush=True)
+# what the plug-in pays on the first call per graph: SparseStorage.stream_plan (round 3: the native builder behind zero-copy views)
+import isplib_amd  # noqa: E402
+from isplib_amd.plan import build_stream_plan_native  # noqa: E402
+print("plug-in builder (native, views):", [f"{t:.1f}" for t in clock(lambda: build_stream_plan_native(rowptr, col, n, slices, streams, chunk))], "ms", flush=True)
+
+
+def first_call():
+    adj = isplib_amd.SparseTensor.from_csr(rowptr, col, None, (n, n), validate=False)
+    return adj.storage.stream_plan(False, (streams, slices, chunk))
+
+
+print("SparseStorage.stream_plan, first call on a fresh graph object:", [f"{t:.1f}" for t in clock(first_call)], "ms", flush=True)
 x = synth.features(n, k, device=dev)
 out = torch.empty((n, k), device=dev)
 ws = nat.workspace()
