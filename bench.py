@@ -354,7 +354,7 @@ def replicated_graph(make, dev, rank, world):
     return rowptr, col, n
 
 
-def dist_extra_configs(dev, rank, world, rowptr, col, n):
+def dist_extra_configs(dev, rank, world, rowptr, col, n, guard=None):
     """The two configurations of BASELINE.json that exist only on several GPUs, run on the ranks of this job after the
     headline (outside its timed region): config 5 -- the 2-layer GCN epoch on the 1-D row-partitioned graph
     (isplib_amd.dist.DistGraph: one all-gather of the layer input per aggregation, forward and backward; replicated
@@ -444,7 +444,8 @@ def dist_extra_configs(dev, rank, world, rowptr, col, n):
             handles.append(dist.all_gather_into_tensor(rb, sb, async_op=True))
         for (c0, c1), rb, h in zip(panels, p_recv, handles):
             h.wait()
-            cabi.fusedMM_csr_hip(cabi.MSG_SPMM_SUM, part.rowptr, part.col_padded, None, rb, z[:, c0:c1])
+            part._kernel(cabi.fusedMM_csr_hip, cabi.MSG_SPMM_SUM, part.rowptr, part.col_padded, None, rb, z[:, c0:c1])
+        part._raise_parked()          # (a local failure is raised only after every panel's collective has been waited for)
 
     candidates = {"gather + plain kernel": gather_plain, "pipelined x4 (64-column panels, plain kernel)": pipelined_plain}
 
@@ -533,6 +534,204 @@ def dist_extra_configs(dev, rank, world, rowptr, col, n):
     return out
 
 
+# ---- failure containment for N > 1 ---------------------------------------------------------------------------------------
+# A multi-rank run can fail in ways a single rank cannot: a collective that one rank never joins blocks the others for
+# ever, a rank that dies takes the launcher's SIGTERM to the rest.  The rules here: (i) the north_star form (ONE all-gather
+# of X + the local SpMM) is validated, timed for exactly K steps and turned into a complete result FIRST; (ii) every other
+# exchange schedule is optional -- it runs under its own deadline, a failure drops it on EVERY rank, and whatever happens
+# while exploring, rank 0 still prints the result of (i); (iii) without any result the job exits non-zero inside a
+# deadline instead of hanging until the driver kills it.  Nothing here touches the GPU: it is exercised on the CPU with
+# gloo by tests/test_host.py.
+
+def _env_seconds(name: str, default: float) -> float:
+    try:
+        return float(os.environ.get(name, default))
+    except ValueError:
+        return float(default)
+
+
+class Guard:
+    """Watchdog of one rank: a daemon thread that owns the deadlines and the launcher's SIGTERM.
+
+    `arm(phase, seconds)` sets the deadline of the phase the main thread is in.  When it passes -- or when the launcher
+    sends SIGTERM because another rank died -- the thread dumps every Python stack to stderr and ends the process: with
+    exit code 0 and, on rank 0, the JSON line of the result offered so far (`offer`) if there is one; with exit code 5
+    and no line otherwise.  The signal is taken through `signal.set_wakeup_fd`, so it is seen even while the main thread
+    sits inside a blocking collective or `torch.cuda.synchronize()` (a Python-level handler would wait for it to return).
+    `emit` is the normal way out: it prints the line exactly once and switches the deadlines off."""
+
+    def __init__(self, rank: int, world: int, out=None):
+        import signal
+        import threading
+        self.rank, self.world = rank, world
+        self.t0 = time.monotonic()
+        self._out = sys.stdout if out is None else out
+        self._lock = threading.Lock()
+        self._deadline, self._phase = None, "start"
+        self._result, self._have, self._done = None, False, False
+        self._r, w = os.pipe()
+        os.set_blocking(self._r, False)
+        os.set_blocking(w, False)
+        try:
+            signal.set_wakeup_fd(w, warn_on_full_buffer=False)
+            signal.signal(signal.SIGTERM, lambda *_: None)        # the C handler writes the signal number to the pipe
+            self._sigterm = int(signal.SIGTERM)
+        except ValueError:                                        # not the main thread (unit tests): deadlines only
+            self._sigterm = None
+        self._thread = threading.Thread(target=self._run, name="bench-guard", daemon=True)
+        self._thread.start()
+
+    def elapsed(self) -> float:
+        return time.monotonic() - self.t0
+
+    def arm(self, phase: str, seconds: float) -> None:
+        with self._lock:
+            self._phase, self._deadline = phase, time.monotonic() + max(0.0, seconds)
+
+    def disarm(self) -> None:
+        with self._lock:
+            self._deadline = None
+
+    def offer(self, result) -> None:
+        """A complete headline result exists from here on (every rank calls this; only rank 0 passes the dict)."""
+        with self._lock:
+            self._have = True
+            if result is not None:
+                self._result = result
+
+    def emit(self, result) -> None:
+        with self._lock:
+            if self._done:
+                return
+            self._done, self._deadline = True, None
+        if self.rank == 0 and result is not None:
+            print(json.dumps(result), file=self._out, flush=True)
+
+    def _run(self):
+        import select
+        while True:
+            try:
+                ready, _, _ = select.select([self._r], [], [], 0.2)
+            except (OSError, ValueError):
+                ready = []
+            reason = None
+            if ready:
+                try:
+                    data = os.read(self._r, 64)
+                except OSError:
+                    data = b""
+                if self._sigterm is not None and self._sigterm in data:
+                    reason = "terminated by the launcher (SIGTERM: another rank failed?)"
+            with self._lock:
+                if self._done:
+                    return
+                if reason is None and self._deadline is not None and time.monotonic() > self._deadline:
+                    reason = f"deadline passed in phase '{self._phase}' ({self.elapsed():.0f} s after start)"
+            if reason is not None:
+                self._bail(reason)
+
+    def _bail(self, reason: str):
+        import faulthandler
+        with self._lock:
+            if self._done:
+                return
+            self._done = True
+            have, result = self._have, self._result
+        print(f"[bench] rank {self.rank}: {reason}; " + ("the result already measured stands" if have else "no result yet"),
+              file=sys.stderr, flush=True)
+        try:
+            faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+        except Exception:  # noqa: BLE001
+            pass
+        if have and self.rank == 0 and result is not None:
+            result = dict(result)
+            result["abandoned"] = reason
+            print(json.dumps(result), file=self._out, flush=True)
+        sys.stderr.flush()
+        os._exit(0 if have else 5)
+
+
+def injected_fault(name: str, rank: int):
+    """ISPLIB_BENCH_INJECT = "<kind>:<schedule name>:<rank>[,...]" rehearses the containment inside the real bench.py:
+    kind `raise` (this rank raises before the schedule's first collective: its peers block in it), `kernel` (a local kernel
+    call of the schedule fails: the error is parked by isplib_amd.dist and the collectives still complete), `hang` (this rank
+    never comes back).  Returns the kind that applies to (name, rank), or None."""
+    for item in filter(None, os.environ.get("ISPLIB_BENCH_INJECT", "").split(",")):
+        kind, _, rest = item.partition(":")
+        sched, _, who = rest.rpartition(":")
+        if sched == name and who.lstrip("-").isdigit() and int(who) == rank:
+            return kind
+    return None
+
+
+class OutOfStep(RuntimeError):
+    """A rank left a schedule part-way through its collectives (or never reported): the ranks may no longer be issuing the
+    same collectives, so nothing more may be sent through the process group."""
+
+
+class StoreAgreement:
+    """Verdicts of all ranks through the rendezvous key-value store (the TCPStore every rank already holds) instead of a
+    collective: it works whatever state the process group's communicator or the GPU stream is in, so a rank that FAILED
+    can say so while its peers are still inside the collective it never joined.  `agree(v)` -> min over ranks of the
+    integers every rank posted for this round; raises OutOfStep when a rank does not post within `timeout_s`."""
+
+    def __init__(self, store, rank: int, world: int, timeout_s: float = 60.0, prefix: str = "isplib/bench/verdict"):
+        self.store, self.rank, self.world, self.timeout_s, self.prefix, self.round = store, rank, world, timeout_s, prefix, 0
+
+    def __call__(self, verdict: int) -> int:
+        from datetime import timedelta
+        self.round += 1
+        keys = [f"{self.prefix}/{self.round}/{r}" for r in range(self.world)]
+        self.store.set(keys[self.rank], str(int(verdict)))
+        try:
+            self.store.wait(keys, timedelta(seconds=self.timeout_s))
+        except Exception as e:  # noqa: BLE001 - a timeout of the store's wait
+            raise OutOfStep(f"a rank did not report its verdict within {self.timeout_s:.0f} s ({type(e).__name__})") from e
+        return min(int(self.store.get(k_)) for k_ in keys)
+
+
+def explore_candidates(cands, *, check, clock, agree, guard, rank, per_candidate_s, until_s, note=lambda msg: None, on_fault=None):
+    """Optional exchange schedules, one at a time.  `check(name, fn)` -> does this rank's result match (may raise);
+    `agree(v)` -> min over ALL ranks of their verdicts v (1 good, 0 bad but every collective of the schedule was issued,
+    -1 failed part-way: StoreAgreement, which needs no collective); `clock(fn)` -> ms per step, max over ranks.
+    A schedule any rank rejects is dropped on every rank and the next one is tried; if a rank may be out of step with
+    its peers (a verdict of -1, or none at all) OutOfStep is raised -- the caller finishes with the result it holds.  A
+    schedule that hangs is ended by the guard's deadline (which prints that result).  Exploring stops when less than one
+    schedule's allowance is left before `until_s` (seconds since the guard started).  Returns {name: ms}."""
+    times = {}
+    for name, fn in cands.items():
+        if guard.elapsed() + per_candidate_s > until_s:
+            note(f"no time left for schedule '{name}' (and the ones after it)")
+            break
+        guard.arm(f"optional schedule '{name}'", per_candidate_s)
+        note(f"checking schedule '{name}'")
+        verdict = 1
+        try:
+            kind = injected_fault(name, rank)
+            if kind == "hang":
+                time.sleep(1e6)
+            if kind == "raise":
+                raise RuntimeError("injected failure before the schedule's first collective")
+            if kind == "kernel" and on_fault is not None:
+                on_fault(RuntimeError("injected failure of a local kernel call"))
+            verdict = 1 if check(name, fn) else 0
+        except Exception as e:  # noqa: BLE001
+            verdict = 0 if getattr(e, "collectives_complete", False) else -1
+            print(f"[bench] rank {rank}: schedule '{name}' raised {type(e).__name__}: {e}"
+                  + ("" if verdict == 0 else " -- part-way through its collectives"), file=sys.stderr, flush=True)
+        everyone = agree(verdict)
+        if everyone < 0:
+            raise OutOfStep(f"schedule '{name}' failed on a rank part-way through its collectives: the ranks may be out of step")
+        if everyone == 0:
+            if rank == 0:
+                print(f"[bench] schedule '{name}' dropped on every rank (mismatch or error on at least one)", file=sys.stderr, flush=True)
+            continue
+        note(f"timing schedule '{name}'")
+        times[name] = clock(fn)
+    guard.disarm()
+    return times
+
+
 def launcher_command(gpus: int, argv, port: int):
     """The command `python bench.py --gpus N ...` turns into when no launcher set WORLD_SIZE: one fresh process per
     GPU under torch.distributed.run, rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
@@ -588,7 +787,12 @@ def self_launch(a, argv) -> int:
     """`--gpus N` with N > 1 and no WORLD_SIZE: this process becomes the launcher.  It must not touch the GPU (a
     process that has initialised HIP may neither fork ranks nor be replaced): it only counts devices, starts the
     ranks as children, relays rank 0's JSON line and returns non-zero if any child failed.  Devices are counted from
-    sysfs (visible_gpu_count): torch.cuda.device_count() goes through amdsmi or hipGetDeviceCount, i.e. may load HIP."""
+    sysfs (visible_gpu_count): torch.cuda.device_count() goes through amdsmi or hipGetDeviceCount, i.e. may load HIP.
+    The children run in their own session under a time limit (ISPLIB_BENCH_LAUNCH_TIMEOUT, default 540 s): when it passes
+    the whole process group is ended (SIGTERM, then SIGKILL) and the launcher returns 124.  A run that ends without a JSON
+    line is tried ONCE more as a fresh set of children restricted to the north_star form (ISPLIB_OVERLAP=0: one all-gather
+    + the local SpMM, no optional exchange schedules) -- never by re-using a process that has touched the GPU."""
+    import signal
     import socket
     import subprocess
     backend = os.environ.get("ISPLIB_BENCH_BACKEND", "nccl")
@@ -597,26 +801,52 @@ def self_launch(a, argv) -> int:
         print(f"bench.py: --gpus {a.gpus} but only {have} GPU(s) visible: refusing to print a number for fewer ranks "
               "(ISPLIB_BENCH_BACKEND=gloo rehearses N ranks on one GPU, labelled as a rehearsal)", file=sys.stderr)
         return 2
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = launcher_command(a.gpus, argv, port)
-    print("[bench] launching: " + " ".join(cmd), file=sys.stderr)
-    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
-    line = None
-    for ln in proc.stdout.splitlines():
-        if ln.startswith("{") and '"metric"' in ln:
-            line = ln
-        else:
-            print(ln, file=sys.stderr)
-    if proc.returncode != 0 or line is None:
-        print(f"bench.py: the {a.gpus}-rank run failed (exit {proc.returncode}, JSON line {'present' if line else 'missing'})", file=sys.stderr)
-        return proc.returncode or 3
-    if json.loads(line).get("n_gpus") != a.gpus:
-        print(f"bench.py: the ranks reported n_gpus={json.loads(line).get('n_gpus')}, expected {a.gpus}", file=sys.stderr)
-        return 4
-    print(line, flush=True)
-    return 0
+    limit = float(os.environ.get("ISPLIB_BENCH_LAUNCH_TIMEOUT", "540"))
+    t_start = time.monotonic()
+    last_rc = 3
+    for attempt, extra_env in enumerate(({}, {"ISPLIB_OVERLAP": "0", "ISPLIB_BENCH_NO_DIST_EXTRA": "1"})):
+        left = limit - (time.monotonic() - t_start)
+        if attempt and (left < 90 or os.environ.get("ISPLIB_BENCH_NO_RETRY") == "1"):
+            break
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = launcher_command(a.gpus, argv, port)
+        print("[bench] launching" + (" again, north_star form only" if attempt else "") + ": " + " ".join(cmd), file=sys.stderr, flush=True)
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, start_new_session=True, env=dict(os.environ, **extra_env))
+        timed_out = False
+        try:
+            stdout, _ = proc.communicate(timeout=max(left, 1.0))
+        except subprocess.TimeoutExpired:
+            timed_out = True
+            for sig, wait in ((signal.SIGTERM, 15), (signal.SIGKILL, 10)):
+                try:
+                    os.killpg(proc.pid, sig)                          # the launcher AND every rank it started
+                except ProcessLookupError:
+                    break
+                try:
+                    stdout, _ = proc.communicate(timeout=wait)
+                    break
+                except subprocess.TimeoutExpired:
+                    stdout = ""
+        line = None
+        for ln in (stdout or "").splitlines():
+            if ln.startswith("{") and '"metric"' in ln:
+                line = ln
+            else:
+                print(ln, file=sys.stderr)
+        if line is not None and json.loads(line).get("n_gpus") != a.gpus:
+            print(f"bench.py: the ranks reported n_gpus={json.loads(line).get('n_gpus')}, expected {a.gpus}", file=sys.stderr)
+            return 4
+        if line is not None:                          # a measured result stands even if a rank failed later (rank 0 says so in it)
+            if timed_out or proc.returncode != 0:
+                print(f"bench.py: the {a.gpus}-rank run ended abnormally (exit {proc.returncode}{', time limit' if timed_out else ''}) "
+                      "after its result was measured", file=sys.stderr)
+            print(line, flush=True)
+            return 0
+        last_rc = 124 if timed_out else (proc.returncode or 3)
+        print(f"bench.py: the {a.gpus}-rank run failed (exit {last_rc}{', time limit' if timed_out else ''}, no JSON line)", file=sys.stderr, flush=True)
+    return last_rc
 
 
 def main():
@@ -626,11 +856,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        # a rank stuck in a collective says where: every thread's Python stack on stderr after ISPLIB_BENCH_WATCHDOG
-        # seconds (default 240) without finishing, and again every so many seconds
-        import faulthandler
-        faulthandler.dump_traceback_later(float(os.environ.get("ISPLIB_BENCH_WATCHDOG", "240")), repeat=True, file=sys.stderr)
+    # N > 1: a watchdog thread per rank owns the deadlines and the launcher's SIGTERM (class Guard): no phase can hang the job
+    # until the driver kills it, and once the north_star form has been measured its result is printed whatever happens later
+    guard = None
+    if world > 1 or os.environ.get("ISPLIB_BENCH_FORCE_DIST") == "1":
+        guard = Guard(rank, world)
+        guard.arm("start-up, graph, plans and the north_star form (one all-gather + local SpMM)", _env_seconds("ISPLIB_BENCH_T_SAFE", 300))
+    t_candidate = _env_seconds("ISPLIB_BENCH_T_CANDIDATE", 45)      # one optional exchange schedule: validation + timing
+    t_total = _env_seconds("ISPLIB_BENCH_DEADLINE", 420)            # everything, seconds since this rank started
 
     def note(msg):
         if world > 1 and rank == 0:
@@ -665,10 +898,12 @@ def main():
     import torch.distributed as dist
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        from datetime import timedelta
+        pg_timeout = timedelta(seconds=int(_env_seconds("ISPLIB_BENCH_PG_TIMEOUT", 90)))      # a collective a peer never joins
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=pg_timeout)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=pg_timeout)
         if rank == 0:
             print(f"[bench] process group up: backend={dist.get_backend()} world_size={dist.get_world_size()} "
                   f"(RCCL ranks: {dist.get_world_size() if backend == 'nccl' else 0})", file=sys.stderr)
@@ -789,107 +1024,232 @@ def main():
         else:
             cabi.fusedMM_csr_hip(msg, rp, cl, vl, xin, o, ar)
 
-    # N > 1: one step = the exchange of X plus the local SpMM.  Candidate schedules (isplib_amd/dist.py):
-    #   gather+spmm      : one all-gather, then the SpMM (task list when a plan exists)
+    # N > 1: one step = the exchange of X plus the local SpMM.  Schedules (isplib_amd/dist.py):
+    #   gather+spmm      : one all-gather, then the SpMM (task list when a plan exists)          } the north_star form:
+    #   gather+stream    : one all-gather, then the stream schedule                              } measured FIRST
     #   overlapped sliced: local column slices aggregated while the all-gather is in flight
     #   pipelined xC     : X travels in C column panels; panel c is aggregated while panels c+1.. travel
     #   direct xB        : P-1 per-peer send / receive pairs in B groups, a group's shards aggregated as it lands
-    #   gather+stream    : one all-gather, then the stream schedule
     #   pipelined stream xC : the pipelined exchange with the stream schedule on every panel
-    # Every candidate is first checked against gather+spmm of the same kernel family (bit for bit, except that
-    # panelled sums are held to the parity tests' 1e-5 bound: their summation order differs), then all
-    # are timed for a few steps (max over ranks) and the fastest is kept: which one wins depends on how
-    # long the collective takes on this node.  ISPLIB_OVERLAP=0 keeps gather+spmm.
+    # Order of events (the containment rules above `class Guard`): the two north_star forms are validated against each
+    # other and timed, the faster runs the warm-up and EXACTLY K timed steps and becomes a complete result, which the
+    # guard holds from then on.  Only then are the other schedules tried, each under its own deadline, each checked against
+    # gather+spmm of the same kernel family (bit for bit, except that panelled sums are held to the parity tests' 1e-5
+    # bound: their summation order differs) and timed for a few steps (max over ranks).  If one of them is faster it
+    # runs its own K timed steps and replaces the result.  ISPLIB_OVERLAP=0 keeps the north_star form.
     chosen = "single GPU"
-    step_fn = None
+    times = {}
+    broken = None          # N > 1: why the run stopped short of its optional parts (the measured result still stands)
+
+    def run_timed(step):
+        """W warm-up steps, then exactly K timed steps between barrier + synchronize on both sides; seconds, max over ranks."""
+        for _ in range(a.warmup):
+            step()
+        torch.cuda.synchronize()
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            step(i)
+        torch.cuda.synchronize()
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+        secs = time.perf_counter() - t0
+        if multi:
+            t = torch.tensor([secs], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            secs = float(t.item())
+        return secs, [s_.elapsed_time(e_) for s_, e_ in ev]
+
+    def single_step(i=None):
+        if i is not None:
+            ev[i][0].record()
+        spmm(l_rowptr, l_col, l_val, table, x_in, out, arg)
+        if i is not None:
+            ev[i][1].record()
+
+    swork_t = None
+
+    def build_result(elapsed, kern_ms, chosen, times, cold_ms=None, copy_gbps=None, bwd=None):
+        """The JSON line (rank 0; None elsewhere)."""
+        if rank != 0:
+            return None
+        stream_now = use_stream if not multi else chosen == "gather+stream"
+        tasks_now = use_tasks if not multi else (tplan is not None and chosen in ("gather+spmm",) or chosen.startswith("pipelined x"))
+        kern_avg_ms = sum(kern_ms) / len(kern_ms)
+        ms_per_step = elapsed / a.steps * 1e3
+        with_arg = a.reduce in ("max", "min")
+        # dominant kernel = the SpMM launch of this rank (rank 0's slice when partitioned)
+        b_alg = synth.algorithmic_bytes(m_local, n, l_col.numel(), k, with_arg)
+        achieved = b_alg / (kern_avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        # measured offline (separate --pmc passes cannot run inside this process): profiles/traffic.json
+        if os.path.exists(tpath) and not multi and a.scale == 1.0 and not a.weighted and a.generator == "chunglu" \
+                and (a.chunk, a.short) == (1024, 128):
+            try:
+                rec = json.load(open(tpath)).get(f"{a.workload}-{a.reduce}-k{k}-" + (f"stream{splan.slices}" if stream_now else
+                                                 f"s{a.slices}" + ("-tasks" if tplan is not None else "")))
+                traffic = rec.get("fabric_bytes_per_launch", rec.get("hbm_bytes_per_launch")) if rec else None
+            except Exception:  # noqa: BLE001
+                traffic = None
+        overlapped = multi and chosen not in ("gather+spmm", "gather+stream")
+        if chosen.startswith("pipelined stream"):
+            kernel_label = f"spmm_stream_kernel + sweep_hub_fold_kernel per column panel ({chosen}), exchange included in the events"
+        elif stream_now:
+            pw = 256 // splan.streams
+            kernel_label = (f"spmm_stream_kernel x {splan.gens} generation(s) + sweep_hub_fold_kernel, "
+                            f"{-(-k // pw)} pass(es) of {pw} columns per launch")
+        elif tasks_now:
+            kernel_label = "spmm_task_kernel + combine_tasks_kernel"
+            if x_in.size(0) * k * 4 / max(a.slices, 1) > 9216 * 1024:          # else a whole-row plan: one pass
+                if k >= 96 and k % 32 == 0:
+                    kernel_label += f", {-(-k // 64)} passes of 64 columns per launch"
+                elif k >= 192:
+                    kernel_label += f", {-(-k // 128)} passes of 128 columns per launch"
+        else:
+            kernel_label = "spmm_csr_kernel" + (f"<sliced x{sliced_slices}> + combine_slices_kernel" if a.slices > 0 else "")
+        if overlapped and not chosen.startswith("pipelined stream"):
+            kernel_label += f" ({chosen}: exchange included in the events)"
+        res = {
+            "metric": "edges_aggregated_per_sec", "value": nnz / (elapsed / a.steps), "unit": "edges/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" + (" (REHEARSAL of the N>1 path on one rank, not a result)" if forced else "" if backend == "nccl" else f" (REHEARSAL over {backend}, not a result)"),
+            "config": {
+                "workload": f"{a.workload}-like graph ({a.generator}, N={n}, nnz={nnz}), SpMM-{a.reduce} forward, K={k}, fp32"
+                            + (", U(0,1) weights" if a.weighted else ", unit weights")
+                            + ("" if a.scale == 1.0 else f", SCALED x{a.scale} (debug)"),
+                "schedule": (f"stream: {splan.streams} streams x {splan.rows_per_wave // splan.streams} rows per wave, {splan.slices} column slices, "
+                             f"{splan.gens} generation(s) of {splan.waves_per_gen} waves, rows > {splan.chunk} edges dealt to {splan.n_parts} virtual rows"
+                             if stream_now else
+                             f"stream schedule per column panel ({chosen})" if chosen.startswith("pipelined stream") else
+                             f"task list: {a.slices} column slices, {tplan.n_tasks} tasks of <= {a.chunk} edges, rows < {a.short} unsliced"
+                             if tasks_now else
+                             f"{sliced_slices} column slices, XCD-affine" if a.slices > 0 else "row-per-wave, unsliced"),
+                "partition": "none" if not multi else f"1-D rows by nnz, {world} ranks, one all-gather(X) per step"
+                             + f", schedule: {chosen}",
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                "traffic_source": None if traffic is None else "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled (gfx950), per launch; these are the bytes leaving the XCD L2s, Infinity-Cache hits included",
+                "kernel": kernel_label,
+                "kernel_avg_ms": kern_avg_ms, "kernel_median_ms": sorted(kern_ms)[len(kern_ms) // 2], "kernel_min_ms": min(kern_ms),
+                "kernel_cold_cache_ms": cold_ms, "peak_measured_copy": copy_gbps,
+                "frac_of_measured_copy": None if not copy_gbps else achieved / copy_gbps,
+                "algorithmic_bytes_per_launch": b_alg,
+                "gather_model_GBps": synth.gather_bytes(m_local, l_col.numel(), k) / (kern_avg_ms * 1e-3) / 1e9,
+            },
+        }
+        if multi:
+            res["candidates_ms"] = {n_: round(t_, 4) for n_, t_ in times.items()}
+        if bwd:
+            res["backward"] = bwd
+        return res
+
+    res = None
     if multi:
-        def all_ranks_agree(good):
+        def agree(good):
             flag = torch.tensor([1 if good else 0], device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             return bool(flag.item())
 
-        def checked(name, fn, want_fn, exact=True):
-            note(f"checking schedule '{name}'")
+        def local_base():                       # the local SpMM of gather+spmm: task list when a plan exists
+            if tplan is not None:
+                cabi.fusedMM_csr_tasks_hip(msg, l_rowptr, l_col, l_val, tplan, x_in, out, arg, twork)
+            elif table is not None:
+                cabi.fusedMM_csr_sliced_hip(msg, l_rowptr, l_col, l_val, table, sliced_slices, x_in, out, arg, work)
+            else:
+                cabi.fusedMM_csr_hip(msg, l_rowptr, l_col, l_val, x_in, out, arg)
+
+        def local_sliced():
+            if table is not None:
+                cabi.fusedMM_csr_sliced_hip(msg, l_rowptr, l_col, l_val, table, sliced_slices, x_in, out, arg, work)
+            else:
+                cabi.fusedMM_csr_hip(msg, l_rowptr, l_col, l_val, x_in, out, arg)
+
+        def local_stream():
+            cabi.fusedMM_csr_stream_hip(msg, l_rowptr, l_col.numel(), splan, x_in, out, swork)
+
+        def after_the_collective(kernel):
+            """a local kernel call that follows the step's one all-gather: if it fails, this rank is still in step"""
             try:
-                want_fn()
-                want = out.clone()
-                out.zero_()
-                fn()
-                torch.cuda.synchronize()
-                if exact:
-                    good = torch.equal(out, want)
-                else:           # other summation order: 1e-5 of sum |a||x| per element, the parity tests' bound
-                    good = bool(((out - want).abs() <= 1e-5 * magnitude() + 1e-30).all())
+                return kernel()
             except Exception as e:  # noqa: BLE001
-                print(f"[bench] schedule '{name}' raised {type(e).__name__}: {e}", file=sys.stderr)
-                good = False
-            good = all_ranks_agree(good)
-            if not good and rank == 0:
-                print(f"[bench] schedule '{name}' disabled (mismatch or error)", file=sys.stderr)
-            return good
+                e.collectives_complete = True
+                raise
+
+        def gather_then_base():
+            gather()
+            after_the_collective(local_base)
 
         def gather_then_sliced():
             gather()
-            spmm(l_rowptr, l_col, l_val, table, x_in, out, arg)
-
-        def gather_then_tasks():
-            gather()
-            cabi.fusedMM_csr_tasks_hip(msg, l_rowptr, l_col, l_val, tplan, x_in, out, arg, twork)
-
-        def magnitude():
-            gather()
-            keep = out.clone()
-            cabi.fusedMM_csr_hip(msg, l_rowptr, l_col, None if l_val is None else l_val.abs(), x_in.abs(), out, arg)
-            if a.reduce == "mean":
-                out.mul_((l_rowptr[1:] - l_rowptr[:-1]).clamp(min=1).unsqueeze(1))
-            mag = out.abs().clone()
-            out.copy_(keep)
-            return mag
+            after_the_collective(local_sliced)
 
         def gather_then_stream():
             gather()
-            cabi.fusedMM_csr_stream_hip(msg, l_rowptr, l_col.numel(), splan, x_in, out, swork)
+            after_the_collective(local_stream)
 
-        base = gather_then_tasks if tplan is not None else gather_then_sliced
-        candidates = {"gather+spmm": base}
-        if splan is not None and checked("gather+stream", gather_then_stream, base, exact=False):
-            candidates["gather+stream"] = gather_then_stream
-        if os.environ.get("ISPLIB_OVERLAP", "1") != "0":
-            if plan is not None:
-                fn = lambda: part.spmm_overlapped(x_shard, x_in, out, plan, a.reduce, arg)  # noqa: E731
-                if checked("overlapped sliced", fn, gather_then_sliced):
-                    candidates["overlapped sliced"] = fn
-            # (over gloo a point-to-point transfer of a shard takes seconds: the rehearsal leaves these to tests/test_gpu_dist.py)
-            if plan is not None and world > 1 and (backend == "nccl" or os.environ.get("ISPLIB_BENCH_DIRECT") == "1"):
-                for nb in sorted({1, 2, world - 1}):
-                    if nb > world - 1:
-                        continue
-                    fn = (lambda b: lambda: part.spmm_direct(x_shard, x_in, out, plan, a.reduce, arg, batches=b))(nb)
-                    if checked(f"direct x{nb}", fn, gather_then_sliced):
-                        candidates[f"direct x{nb}"] = fn
-            if tplan is not None:
-                for panels in (2, 4):
-                    if k // panels < 16:
-                        continue
-                    state = part.pipeline_state(k, panels, a.reduce)        # own plan: slice count for the panel width
-                    if not all_ranks_agree(state is not None):              # (a collective: every rank asks, whatever it got)
-                        continue
-                    fn = (lambda st: lambda: part.spmm_pipelined(x_shard, out, st, a.reduce, arg))(state)
-                    if checked(f"pipelined x{panels}", fn, gather_then_tasks, exact=a.reduce in ("max", "min")):
-                        candidates[f"pipelined x{panels}"] = fn
+        def magnitude():
+            gather()
 
-            if splan is not None and "gather+stream" in candidates:
-                for panels in (2, 4):
-                    if k // panels < 32:
-                        continue
-                    state = part.pipeline_state(k, panels, a.reduce, stream=True)
-                    if not all_ranks_agree(state is not None):
-                        continue
-                    fn = (lambda st: lambda: part.spmm_pipelined(x_shard, out, st, a.reduce, arg))(state)
-                    if checked(f"pipelined stream x{panels}", fn, gather_then_stream, exact=False):
-                        candidates[f"pipelined stream x{panels}"] = fn
+            def rest():
+                keep = out.clone()
+                cabi.fusedMM_csr_hip(msg, l_rowptr, l_col, None if l_val is None else l_val.abs(), x_in.abs(), out, arg)
+                if a.reduce == "mean":
+                    out.mul_((l_rowptr[1:] - l_rowptr[:-1]).clamp(min=1).unsqueeze(1))
+                mag = out.abs().clone()
+                out.copy_(keep)
+                return mag
+            return after_the_collective(rest)
 
-        def timed(fn, reps=4):
+        def same_result(fn, want_fn, exact):
+            """This rank's verdict.  Every stage issues its collectives even if an earlier stage failed locally (a failure
+            that is marked `collectives_complete`): the first error is raised at the end, still marked, so that a local
+            failure on one rank never leaves it a collective behind its peers."""
+            errors = []
+
+            def stage(f):
+                try:
+                    return f()
+                except Exception as e:  # noqa: BLE001
+                    if not getattr(e, "collectives_complete", False):
+                        raise
+                    errors.append(e)
+                    return None
+            stage(want_fn)
+            want = out.clone()
+            out.zero_()
+            stage(fn)
+            torch.cuda.synchronize()
+            if exact:
+                good = torch.equal(out, want)
+            else:       # other summation order: 1e-5 of sum |a||x| per element, the parity tests' bound
+                mag = stage(magnitude)
+                good = mag is not None and bool(((out - want).abs() <= 1e-5 * mag + 1e-30).all())
+            if errors:
+                raise errors[0]
+            return good
+
+        # verdicts travel through the rendezvous store, not through the process group (class StoreAgreement)
+        try:
+            verdicts = StoreAgreement(dist.distributed_c10d._get_default_store(), rank, world, timeout_s=t_candidate + 15)
+            verdicts(1)
+        except OutOfStep:
+            raise
+        except Exception as e:  # noqa: BLE001 - no store to be had: fall back to a collective (symmetric failures only)
+            print(f"[bench] rank {rank}: no rendezvous store for the verdicts ({type(e).__name__}: {e}); using all-reduce", file=sys.stderr)
+
+            def verdicts(v):
+                flag = torch.tensor([int(v)], device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                return int(flag.item())
+
+        def clock(fn, reps=4):
             def clocked(count):
                 torch.cuda.synchronize()
                 dist.barrier()
@@ -903,59 +1263,126 @@ def main():
             first = clocked(1)                # (also the warm-up; the same value on every rank, so is the branch below)
             return first if first > 250.0 else clocked(reps)      # a schedule this slow is not worth four more steps
 
-        times = {}
-        for name, fn in candidates.items():
+        def make_step(name, fn):
+            """north_star forms: the events bracket the local SpMM only (the dominant kernel's own time); overlapped
+            schedules interleave exchange and compute, so the events bracket both"""
+            local = {"gather+spmm": local_base, "gather+stream": local_stream}.get(name)
+
+            def step(i=None):
+                if local is not None:
+                    gather()
+                if i is not None:
+                    ev[i][0].record()
+                (local or fn)()
+                if i is not None:
+                    ev[i][1].record()
+            return step
+
+        # ---- 1. the north_star form, measured first: from here on there is a result -------------------------------------
+        safe = {"gather+spmm": gather_then_base}
+        if splan is not None:
+            note("checking schedule 'gather+stream'")
+            v = 0
+            try:
+                v = 1 if same_result(gather_then_stream, gather_then_base, exact=False) else 0
+            except Exception as e:  # noqa: BLE001
+                v = 0 if getattr(e, "collectives_complete", False) else -1
+                print(f"[bench] rank {rank}: schedule 'gather+stream' raised {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+            v = verdicts(v)
+            if v < 0:
+                raise SystemExit("bench.py: a rank failed inside a collective of the north_star form: no result")
+            if v == 1:
+                safe["gather+stream"] = gather_then_stream
+            elif rank == 0:
+                print("[bench] schedule 'gather+stream' dropped on every rank (mismatch or error on at least one)", file=sys.stderr)
+        for name, fn in safe.items():
             note(f"timing schedule '{name}'")
-            times[name] = timed(fn)
+            times[name] = clock(fn)
         chosen = min(times, key=times.get)
-        use_tasks = tplan is not None and chosen != "overlapped sliced"
-        use_stream = chosen == "gather+stream"
-        if chosen.startswith("pipelined stream"):
-            use_tasks = False
-        if chosen.startswith("direct"):
-            use_tasks = False
-        if chosen not in ("gather+spmm", "gather+stream"):
-            step_fn = candidates[chosen]
+        note(f"north_star form: {chosen}; {a.warmup} warm-up + {a.steps} timed steps")
+        elapsed, kern_ms = run_timed(make_step(chosen, safe[chosen]))
+        res = build_result(elapsed, kern_ms, chosen, times)
+        guard.offer(res)
+        note(f"result held by the guard: {elapsed / a.steps * 1e3:.3f} ms/step ({chosen})")
+
+        # ---- 2. optional exchange schedules: each under its own deadline, none of them can lose the result ----------
+        def explore(explore_until):
+            nonlocal chosen, elapsed, kern_ms, res
+            if os.environ.get("ISPLIB_OVERLAP", "1") == "0" or guard.elapsed() + t_candidate >= explore_until:
+                return
+            guard.arm("plans of the optional exchange schedules", t_candidate)
+            optional, meta = {}, {}
+
+            def offer_candidate(name, fn, want_fn, exact):
+                optional[name] = fn
+                meta[name] = (want_fn, exact)
+
+            if plan is not None:
+                offer_candidate("overlapped sliced", lambda: part.spmm_overlapped(x_shard, x_in, out, plan, a.reduce, arg), gather_then_sliced, True)
+            if tplan is not None:
+                for panels in (2, 4):
+                    if k // panels < 16:
+                        continue
+                    state = None
+                    try:
+                        state = part.pipeline_state(k, panels, a.reduce)        # own plan: slice count for the panel width
+                    except Exception as e:  # noqa: BLE001
+                        print(f"[bench] rank {rank}: pipeline_state({panels}) raised {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+                    if not agree(state is not None):                            # (a collective: every rank asks, whatever it got)
+                        continue
+                    offer_candidate(f"pipelined x{panels}", (lambda st: lambda: part.spmm_pipelined(x_shard, out, st, a.reduce, arg))(state),
+                                    gather_then_base, a.reduce in ("max", "min"))
+            if splan is not None and "gather+stream" in safe:
+                for panels in (2, 4):
+                    if k // panels < 32:
+                        continue
+                    state = None
+                    try:
+                        state = part.pipeline_state(k, panels, a.reduce, stream=True)
+                    except Exception as e:  # noqa: BLE001
+                        print(f"[bench] rank {rank}: pipeline_state({panels}, stream) raised {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+                    if not agree(state is not None):
+                        continue
+                    offer_candidate(f"pipelined stream x{panels}", (lambda st: lambda: part.spmm_pipelined(x_shard, out, st, a.reduce, arg))(state),
+                                    gather_then_stream, False)
+            # last: the point-to-point exchange.  Over gloo a shard takes seconds per peer, so the rehearsal only enters it on a
+            # scaled graph (or when asked to: ISPLIB_BENCH_DIRECT=1)
+            direct_ok = backend == "nccl" or os.environ.get("ISPLIB_BENCH_DIRECT") == "1" or part.max_rows * k * 4 <= (8 << 20)
+            if plan is not None and world > 1 and direct_ok:
+                for nb in sorted({1, 2, world - 1}):
+                    if nb <= world - 1:
+                        offer_candidate(f"direct x{nb}", (lambda b_: lambda: part.spmm_direct(x_shard, x_in, out, plan, a.reduce, arg, batches=b_))(nb),
+                                        gather_then_sliced, True)
+            opt_times = explore_candidates(optional, check=lambda name, fn: same_result(fn, *meta[name]), clock=clock, agree=verdicts,
+                                           guard=guard, rank=rank, per_candidate_s=t_candidate, until_s=explore_until, note=note,
+                                           on_fault=lambda e: setattr(part, "fail_next_kernel", e))
+            times.update(opt_times)
+            best = min(times, key=times.get)
+            if best != chosen and times[best] < 0.97 * times[chosen]:
+                guard.arm(f"timed steps of '{best}'", t_candidate)
+                note(f"'{best}' is faster ({times[best]:.3f} against {times[chosen]:.3f} ms): {a.warmup} warm-up + {a.steps} timed steps")
+                elapsed2, kern2 = run_timed(make_step(best, optional[best]))
+                if elapsed2 < elapsed:
+                    chosen, elapsed, kern_ms = best, elapsed2, kern2
+                    res = build_result(elapsed, kern_ms, chosen, times)
+                    guard.offer(res)
+                elif res is not None:
+                    res["candidates_ms"] = {n_: round(t_, 4) for n_, t_ in times.items()}
+            elif res is not None:
+                res["candidates_ms"] = {n_: round(t_, 4) for n_, t_ in times.items()}
+            guard.disarm()
+
+        explore_until = t_total - _env_seconds("ISPLIB_BENCH_T_EXTRA", 150) if (world > 1 and not a.no_extra) else t_total - 20
+        try:
+            explore(explore_until)
+        except Exception as e:  # noqa: BLE001 - the communicator's state is unknown from here on: finish with what is measured
+            broken = f"exploring the optional exchange schedules raised {type(e).__name__}: {e}"
+            print(f"[bench] rank {rank}: {broken}", file=sys.stderr, flush=True)
         if rank == 0:
             print(f"[bench] N={world}: " + ", ".join(f"{n_} {t_:.3f} ms/step" for n_, t_ in times.items()) + f" -> {chosen}",
-                  file=sys.stderr)
-
-    def step(i=None):
-        if step_fn is not None:              # exchange and compute are interleaved: the events bracket both
-            if i is not None:
-                ev[i][0].record()
-            step_fn()
-            if i is not None:
-                ev[i][1].record()
-            return
-        if gather is not None:
-            gather()
-        if i is not None:
-            ev[i][0].record()
-        spmm(l_rowptr, l_col, l_val, table, x_in, out, arg)
-        if i is not None:
-            ev[i][1].record()
-
-    for _ in range(a.warmup):
-        step()
-    torch.cuda.synchronize()
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(i)
-    torch.cuda.synchronize()
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if multi:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    kern_ms = [s.elapsed_time(e) for s, e in ev]
-    kern_avg_ms = sum(kern_ms) / len(kern_ms)
+                  file=sys.stderr, flush=True)
+    else:
+        elapsed, kern_ms = run_timed(single_step)
 
     # SURVEY.md 8(d) extras, outside the timed region, N=1 only: (i) the same launch with L2 + Infinity Cache
     # flushed first (a 1 GiB fill evicts the 256 MiB MALL), (ii) this box's device-to-device copy rate, the
@@ -986,7 +1413,6 @@ def main():
 
     # backward of SpMM-sum = the same kernel on A^T (csrc/fusedmm.cpp:285); reported beside the metric
     bwd = None
-    swork_t = None
     if not multi and not a.no_backward and a.reduce == "sum":
         colptr, _, row_t, val_t = cabi.csr2csc(rowptr, col, val, n, want_perm=False, want_val=val is not None)
         dy = synth.features(n, k, seed=5, device=dev)
@@ -1011,94 +1437,53 @@ def main():
         bwd = {"ms": bms, "edges_per_s": nnz / (bms * 1e-3)}
         del colptr, row_t, val_t, dy, dx
 
-    res = None
-    if rank == 0:
-        ms_per_step = elapsed / a.steps * 1e3
-        with_arg = a.reduce in ("max", "min")
-        # dominant kernel = the SpMM launch of this rank (rank 0's slice when partitioned)
-        b_alg = synth.algorithmic_bytes(m_local, n, l_col.numel(), k, with_arg)
-        achieved = b_alg / (kern_avg_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        # measured offline (separate --pmc passes cannot run inside this process): profiles/traffic.json
-        if os.path.exists(tpath) and not multi and a.scale == 1.0 and not a.weighted and a.generator == "chunglu" \
-                and (a.chunk, a.short) == (1024, 128):
-            try:
-                rec = json.load(open(tpath)).get(f"{a.workload}-{a.reduce}-k{k}-" + (f"stream{splan.slices}" if use_stream else
-                                                 f"s{a.slices}" + ("-tasks" if tplan is not None else "")))
-                traffic = rec.get("fabric_bytes_per_launch", rec.get("hbm_bytes_per_launch")) if rec else None
-            except Exception:
-                traffic = None
-        if chosen.startswith("pipelined stream"):
-            kernel_label = f"spmm_stream_kernel + sweep_hub_fold_kernel per column panel ({chosen}), exchange included in the events"
-        elif use_stream:
-            pw = 256 // splan.streams
-            kernel_label = (f"spmm_stream_kernel x {splan.gens} generation(s) + sweep_hub_fold_kernel, "
-                            f"{-(-k // pw)} pass(es) of {pw} columns per launch")
-        elif use_tasks:
-            kernel_label = "spmm_task_kernel + combine_tasks_kernel"
-            if x_in.size(0) * k * 4 / max(a.slices, 1) > 9216 * 1024:          # else a whole-row plan: one pass
-                if k >= 96 and k % 32 == 0:
-                    kernel_label += f", {-(-k // 64)} passes of 64 columns per launch"
-                elif k >= 192:
-                    kernel_label += f", {-(-k // 128)} passes of 128 columns per launch"
-        else:
-            kernel_label = "spmm_csr_kernel" + (f"<sliced x{sliced_slices}> + combine_slices_kernel" if a.slices > 0 else "")
-        res = {
-            "metric": "edges_aggregated_per_sec", "value": nnz / (elapsed / a.steps), "unit": "edges/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic" + (" (REHEARSAL of the N>1 path on one rank, not a result)" if forced else "" if backend == "nccl" else f" (REHEARSAL over {backend}, not a result)"),
-            "config": {
-                "workload": f"{a.workload}-like graph ({a.generator}, N={n}, nnz={nnz}), SpMM-{a.reduce} forward, K={k}, fp32"
-                            + (", U(0,1) weights" if a.weighted else ", unit weights")
-                            + ("" if a.scale == 1.0 else f", SCALED x{a.scale} (debug)"),
-                "schedule": (f"stream: {splan.streams} streams x {splan.rows_per_wave // splan.streams} rows per wave, {splan.slices} column slices, "
-                             f"{splan.gens} generation(s) of {splan.waves_per_gen} waves, rows > {splan.chunk} edges dealt to {splan.n_parts} virtual rows"
-                             if use_stream else
-                             f"stream schedule per column panel ({chosen})" if chosen.startswith("pipelined stream") else
-                             f"task list: {a.slices} column slices, {tplan.n_tasks} tasks of <= {a.chunk} edges, rows < {a.short} unsliced"
-                             if use_tasks else
-                             f"{sliced_slices} column slices, XCD-affine" if a.slices > 0 else "row-per-wave, unsliced"),
-                "partition": "none" if not multi else f"1-D rows by nnz, {world} ranks, one all-gather(X) per step"
-                             + f", schedule: {chosen}",
-            },
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                "traffic_source": None if traffic is None else "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled (gfx950), per launch; these are the bytes leaving the XCD L2s, Infinity-Cache hits included",
-                "kernel": kernel_label,
-                "kernel_avg_ms": kern_avg_ms, "kernel_median_ms": sorted(kern_ms)[len(kern_ms) // 2], "kernel_min_ms": min(kern_ms),
-                "kernel_cold_cache_ms": cold_ms, "peak_measured_copy": copy_gbps,
-                "frac_of_measured_copy": None if not copy_gbps else achieved / copy_gbps,
-                "algorithmic_bytes_per_launch": b_alg,
-                "gather_model_GBps": synth.gather_bytes(m_local, l_col.numel(), k) / (kern_avg_ms * 1e-3) / 1e9,
-            },
-        }
-        if bwd:
-            res["backward"] = bwd
-        if not multi and not a.no_cpu_baseline:
+    if not multi:
+        res = build_result(elapsed, kern_ms, chosen, times, cold_ms, copy_gbps, bwd)
+        if not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(rowptr, col, x, nnz)
-        if not multi and not a.no_extra and a.workload == "reddit" and a.scale == 1.0 and a.generator == "chunglu":
+        if not a.no_extra and a.workload == "reddit" and a.scale == 1.0 and a.generator == "chunglu":
             del x, out
             torch.cuda.empty_cache()
             res["extra"] = extra_configs(dev, rowptr, col, n, with_cpu_epoch=not a.no_cpu_baseline)
-    if world > 1 and not a.no_extra and a.workload == "reddit" and a.scale == 1.0 and a.generator == "chunglu":
-        # every rank: the multi-GPU-only configurations, after the headline and outside its timed region
-        step_fn = candidates = splan = tplan = plan = swork = twork = table = work = None
+    want_dist_extra = world > 1 and not a.no_extra and a.workload == "reddit" and a.scale == 1.0 and a.generator == "chunglu" \
+        and os.environ.get("ISPLIB_BENCH_NO_DIST_EXTRA") != "1"
+    if want_dist_extra and t_total - guard.elapsed() < 60:
+        want_dist_extra = False                  # (the same decision on every rank only approximately: the guard covers the rest)
+        note("no time left for the multi-GPU extra configurations")
+    if want_dist_extra and broken is None:
+        # every rank: the multi-GPU-only configurations, after the headline and outside its timed region; if they fail or
+        # run out of time, the headline result is printed without them
+        guard.arm("multi-GPU extra configurations (configs 4 and 5)", t_total - guard.elapsed())
+        safe = optional = meta = splan = tplan = plan = swork = twork = table = work = None
         del x_in, out, x_shard, part, x
         torch.cuda.empty_cache()
-        dist_extra = dist_extra_configs(dev, rank, world, rowptr, col, n)
-        if rank == 0:
-            res["extra"] = dist_extra
-    if rank == 0:
+        try:
+            dist_extra = dist_extra_configs(dev, rank, world, rowptr, col, n, guard)
+            if rank == 0:
+                res["extra"] = dist_extra
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] rank {rank}: the multi-GPU extra configurations raised {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+            if rank == 0:
+                res["extra_error"] = f"{type(e).__name__}: {e}"
+    if broken is not None and res is not None:
+        res["abandoned"] = broken
+    if guard is not None:
+        guard.emit(res)                          # the one JSON line (rank 0), exactly once
+    elif rank == 0:
         print(json.dumps(res), flush=True)
     if multi:
+        # shutdown must not hang on a peer that is gone: the line is out, so a stuck barrier ends the process with exit 0
+        import threading
+        sys.stdout.flush()
+        sys.stderr.flush()
+        if broken is not None:
+            os._exit(0)
+        bomb = threading.Timer(_env_seconds("ISPLIB_BENCH_T_SHUTDOWN", 30), lambda: os._exit(0))
+        bomb.daemon = True
+        bomb.start()
         dist.barrier()
         dist.destroy_process_group()
-    if world > 1:
-        import faulthandler
-        faulthandler.cancel_dump_traceback_later()
+        bomb.cancel()
 
 
 if __name__ == "__main__":

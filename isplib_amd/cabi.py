@@ -830,10 +830,14 @@ def suggest_stream(m: int, n: int, nnz: int, k: int):
 
 
 class _DevView:
-    """A device array the C library owns, seen through __cuda_array_interface__ (no copy; tests and debugging)."""
+    """A device array the C library owns, seen through __cuda_array_interface__ (no copy).  `owner` is the object whose
+    destructor frees the array: torch.as_tensor keeps THIS object alive for as long as the tensor's storage lives (its
+    deleter holds the reference), so holding the owner here ties the library's memory to every tensor that looks at it
+    -- including the copies autograd saves for a backward that runs after the graph object is gone."""
 
-    def __init__(self, ptr: int, count: int, typestr: str):
+    def __init__(self, ptr: int, count: int, typestr: str, owner=None):
         self.__cuda_array_interface__ = {"shape": (count,), "typestr": typestr, "data": (ptr, False), "version": 2}
+        self._owner = owner
 
 
 class NativeStreamPlan:
@@ -882,8 +886,9 @@ class NativeStreamPlan:
         return torch.as_tensor(_DevView(ptr, count, typestr), device=self.device).clone()
 
     def view(self, name: str, dtype: torch.dtype) -> torch.Tensor:
-        """One of the plan's device arrays as a tensor WITHOUT a copy: the memory belongs to this plan object, which
-        the caller keeps alive for as long as the tensor is used (plan.py: build_stream_plan_native does)."""
+        """One of the plan's device arrays as a tensor WITHOUT a copy.  The memory belongs to this plan object; the tensor
+        holds a reference to it (through its _DevView), so the arrays are freed only when the last tensor looking at them
+        is gone -- never under a backward pass that still has them saved.  (close() is for owners that hand out no views.)"""
         nw = self.gens * self.waves_per_gen
         count, typestr = {"words": (self.n_steps * self.streams, "<i4"), "perm": (self.n_steps * self.streams, "<i4"),
                           "wave_step_off": (nw + 1, "<i8"), "wave_row": (nw * self.rows_per_wave, "<i4"),
@@ -892,7 +897,7 @@ class NativeStreamPlan:
         ptr = getattr(self._s, name)
         if not ptr or count == 0:
             return torch.empty(0, dtype=dtype, device=self.device)
-        t = torch.as_tensor(_DevView(ptr, count, typestr), device=self.device)
+        t = torch.as_tensor(_DevView(ptr, count, typestr, owner=self), device=self.device)
         assert t.dtype == dtype and t.data_ptr() == ptr, "zero-copy view of a library array"
         return t
 

@@ -14,6 +14,8 @@
 
 namespace isplib {
 
+int g_sddmm_panel_cols = 0;   // tuning knob (isplib_hip_tune(12, cols)): column-panel width of the task-list SDDMM; 0 = whole rows
+
 // One thread per (row, feature) element of arg/grad_out; consecutive lanes hold
 // consecutive features of one row, so the reads are coalesced and each wave's
 // atomics to one destination row are contiguous where args agree.
@@ -143,7 +145,18 @@ struct SddmmTaskArgs {
    int64_t lane_off[9];
 };
 
-template <int LPR, int NCH, int WAVES>
+// lane (inside its slot) -> index of the step value whose finished sum reduce_transposed<U, LPR> leaves in it
+template <int U, int LPR> __device__ __forceinline__ int transposed_mine(int lc) {
+   int mine = 0, o = LPR / 2;
+#pragma unroll
+   for (int n = U; n > 1; n >>= 1, o >>= 1) mine |= (lc & o) ? (n >> 1) : 0;
+   return mine;
+}
+
+// ACCUM: a later column panel of the same call -- the dot products of this panel are added to what the earlier panels
+// stored (the old values are fetched before the step's gathers are issued, so their latency hides behind them; a task's
+// results are consecutive CSR positions, read and written coalesced)
+template <int LPR, int NCH, int WAVES, bool ACCUM>
 __global__ __launch_bounds__(WAVES * 64, NCH == 1 ? 8 : 1) void sddmm_task_kernel(const SddmmTaskArgs a) {
    constexpr int G = 64 / LPR, U = 4;
    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -171,6 +184,8 @@ __global__ __launch_bounds__(WAVES * 64, NCH == 1 ? 8 : 1) void sddmm_task_kerne
       for (int v = 0; v < 4; v++) gv[j][v] = (ok && v >= vfirst) ? gr[v] : 0.0f;
    }
    const unsigned ldyb = (unsigned)a.ldy * 4u;
+   const int mine_c = transposed_mine<U, LPR>(lc);
+   const bool writer = (lc & (LPR / U - 1)) == 0;
    for (int64_t base = b; base < e; base += 64) {
       const int64_t p = base + lane;
       const unsigned off_l = p < e ? (a.indx32 ? (unsigned)a.indx32[p] : (unsigned)a.indx[p]) * ldyb : SD_BUF_OOB;
@@ -178,6 +193,11 @@ __global__ __launch_bounds__(WAVES * 64, NCH == 1 ? 8 : 1) void sddmm_task_kerne
       const int cnt = left < 64 ? (int)left : 64;
 #pragma unroll 1
       for (int s = 0; s < cnt; s += G * U) {
+         float old = 0.0f;
+         if (ACCUM) {
+            const int eo = s + mine_c * G + g;
+            if (writer && eo < cnt) old = a.dval[base + eo];
+         }
          sd_v4i_t yv[U][NCH];
 #pragma unroll
          for (int u = 0; u < U; u++) {
@@ -200,20 +220,21 @@ __global__ __launch_bounds__(WAVES * 64, NCH == 1 ? 8 : 1) void sddmm_task_kerne
          int mine;
          const float sum = reduce_transposed<U, LPR>(d, lc, mine);
          const int ei = s + mine * G + g;
-         if ((lc & (LPR / U - 1)) == 0 && ei < cnt) a.dval[base + ei] = sum * scale;
+         if (writer && ei < cnt) a.dval[base + ei] = ACCUM ? old + sum * scale : sum * scale;
       }
    }
 }
 
 template <int LPR, int NCH>
-static int launch_sddmm_tasks(const SddmmTaskArgs &a, hipStream_t st) {
+static int launch_sddmm_tasks(const SddmmTaskArgs &a, hipStream_t st, bool accum = false) {
    constexpr int WAVES = 4;
    int64_t most = 0;
    for (int x = 0; x < 8; x++) most = (a.lane_off[x + 1] - a.lane_off[x]) > most ? (a.lane_off[x + 1] - a.lane_off[x]) : most;
    const int64_t gx = 8 * ((most + WAVES - 1) / WAVES);
    if (gx > 0x7fffffffLL) return ISPLIB_FAIL;
    if (gx == 0) return ISPLIB_SUCCESS;
-   hipLaunchKernelGGL((sddmm_task_kernel<LPR, NCH, WAVES>), dim3((unsigned)gx), dim3(WAVES * 64), 0, st, a);
+   if (accum) hipLaunchKernelGGL((sddmm_task_kernel<LPR, NCH, WAVES, true>), dim3((unsigned)gx), dim3(WAVES * 64), 0, st, a);
+   else hipLaunchKernelGGL((sddmm_task_kernel<LPR, NCH, WAVES, false>), dim3((unsigned)gx), dim3(WAVES * 64), 0, st, a);
    return check_launch("sddmm_task_kernel");
 }
 
@@ -298,11 +319,31 @@ extern "C" int isplib_sddmm_csr_tasks_hip(int64_t m, int64_t n, int64_t k, const
    for (int x = 0; x < 9; x++) a.lane_off[x] = lane_off_host[x];
    if (a.lane_off[0] != 0 || a.lane_off[8] != n_tasks) return fail(ISPLIB_FAIL, "isplib_sddmm_csr_tasks_hip: lane_off must run from 0 to n_tasks");
    hipStream_t st = (hipStream_t)stream;
-   const int64_t w = (k + 3) / 4;
-   if (w <= 8) return launch_sddmm_tasks<8, 1>(a, st);
-   if (w <= 16) return launch_sddmm_tasks<16, 1>(a, st);
-   if (w <= 32) return launch_sddmm_tasks<32, 1>(a, st);
-   if (w <= 64) return launch_sddmm_tasks<64, 1>(a, st);
-   if (w <= 128) return launch_sddmm_tasks<64, 2>(a, st);
-   return launch_sddmm_tasks<64, 4>(a, st);
+   // Column panels (isplib_hip_tune(12, cols); 0 = whole rows): a dot product is a sum over columns, so panel c adds its
+   // share to what panels 0..c-1 stored.  A panel of the dense operand is cols / k of its size: the slices of a whole-row
+   // plan then fit the L2 (Reddit shape, K=128, 16 slices: 7.5 MB whole, 3.7 MB per 64-column panel).  Every panel but the
+   // last is `cols` wide (whole cache lines when cols is a multiple of 32); a tail under 4 columns joins the panel before it.
+   const int64_t pw = (g_sddmm_panel_cols >= 32 && (g_sddmm_panel_cols % 32) == 0 && k >= 2 * (int64_t)g_sddmm_panel_cols &&
+                       (ldy % 32) == 0 && (ldg % 32) == 0) ? g_sddmm_panel_cols : k;
+   for (int64_t c0 = 0; c0 < k;) {
+      int64_t c1 = c0 + pw;
+      if (c1 + 4 > k) c1 = k;
+      SddmmTaskArgs p = a;
+      p.k = c1 - c0;
+      p.y = y + c0;
+      p.g = g + c0;
+      p.ybytes = (unsigned)(yb - (unsigned long long)c0 * 4ull);
+      const int64_t w = (p.k + 3) / 4;
+      const bool acc = c0 > 0;
+      int rc;
+      if (w <= 8) rc = launch_sddmm_tasks<8, 1>(p, st, acc);
+      else if (w <= 16) rc = launch_sddmm_tasks<16, 1>(p, st, acc);
+      else if (w <= 32) rc = launch_sddmm_tasks<32, 1>(p, st, acc);
+      else if (w <= 64) rc = launch_sddmm_tasks<64, 1>(p, st, acc);
+      else if (w <= 128) rc = launch_sddmm_tasks<64, 2>(p, st, acc);
+      else rc = launch_sddmm_tasks<64, 4>(p, st, acc);
+      if (rc) return rc;
+      c0 = c1;
+   }
+   return ISPLIB_SUCCESS;
 }

@@ -400,5 +400,6 @@ extern int g_force_lpr, g_addr_mode, g_tasks_per_wave, g_panel_cols, g_panel_col
 extern int g_sweep_panel;    // defined in spmm_sweep.hip
 extern int g_stream_merge_gens;   // defined in spmm_sweep.hip
 extern int g_sddmm_on_stream_plan;   // defined in spmm_sweep.hip
+extern int g_sddmm_panel_cols;       // defined in backward.hip
 
 }  // namespace isplib

@@ -185,13 +185,50 @@ extern "C" int isplib_graph_set_slices(isplib_graph *g, int slices) {
    return ISPLIB_SUCCESS;
 }
 
+// A caller-given row order must be a permutation of [0, rows): an entry out of range would be an out-of-bounds row read and
+// write in the plain kernel, a repeated one a row computed twice and another never.  Checked once, on the device.
+__global__ __launch_bounds__(256) void order_check_kernel(int64_t rows, const int32_t *__restrict__ order, int *__restrict__ seen, int *__restrict__ bad) {
+   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += stride) {
+      const int r = order[i];
+      if (r < 0 || (int64_t)r >= rows) atomicOr(bad, 1);
+      else if (atomicExch(&seen[r], 1) != 0) atomicOr(bad, 2);
+   }
+}
+
+static int check_row_order(int64_t rows, const int32_t *order) {
+   if (!order || rows <= 0) return ISPLIB_SUCCESS;
+   int *seen = nullptr, host = 0;
+   if (hipMalloc((void **)&seen, ((size_t)rows + 1) * sizeof(int)) != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(ISPLIB_NOT_ENOUGH_MEM, "isplib_graph_set_row_order: device allocation failed");
+   }
+   bool ok = hipMemset(seen, 0, ((size_t)rows + 1) * sizeof(int)) == hipSuccess;
+   if (ok) {
+      int64_t blocks = (rows + 255) / 256;
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(order_check_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, rows, order, seen, seen + rows);
+      ok = hipGetLastError() == hipSuccess && hipMemcpy(&host, seen + rows, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+   }
+   (void)hipFree(seen);
+   if (!ok) return hip_fail(hipGetLastError(), "isplib_graph_set_row_order: checking the order");
+   if (host) return fail(ISPLIB_FAIL, host & 1 ? "isplib_graph_set_row_order: an entry of the order is outside [0, rows)"
+                                               : "isplib_graph_set_row_order: the order is not a permutation (a row appears twice)");
+   return ISPLIB_SUCCESS;
+}
+
 extern "C" int isplib_graph_set_row_order(isplib_graph *g, const int32_t *order, const int32_t *order_t) {
    // The order the plain kernel takes the rows of A (order) / of A^T (order_t) in: borrowed device arrays of m / n int32,
-   // position -> row; NULL = index order and no search for one.  Speed only.
+   // position -> row; NULL = index order and no search for one.  Speed only.  Each given order is checked once, here, to
+   // be a permutation (one pass on the device, synchronous); a bad one is refused and nothing changes.
    clear_error();
    if (!g) return fail(ISPLIB_FAIL, "isplib_graph_set_row_order: null handle");
    Side *sides[2] = {&g->fwd, &g->bwd};
    const int32_t *given[2] = {order, order_t};
+   for (int i = 0; i < 2; i++) {
+      const int rc = check_row_order(sides[i]->m > 0 ? sides[i]->m : (i == 0 ? g->fwd.m : g->fwd.n), given[i]);
+      if (rc) return rc;
+   }
    for (int i = 0; i < 2; i++) {
       if (sides[i]->order_state == 1) (void)hipFree(sides[i]->order);
       sides[i]->order = const_cast<int32_t *>(given[i]);
@@ -421,7 +458,12 @@ static int run_side(isplib_graph *g, Side &s, const float *val, int32_t imessage
                sp->plan.vals = sp->other;                  // NULL: set_values allocates a fresh array
                if (!hit) {
                   rc = isplib_stream_plan_set_values_hip(&sp->plan, val, st);
-                  if (rc) { sp->plan.vals = parked; return rc; }
+                  if (rc) {
+                     // a fresh array may have been allocated before the gather failed: it is neither `parked` nor `other`
+                     if (sp->plan.vals && sp->plan.vals != parked && sp->plan.vals != sp->other) (void)hipFree(const_cast<float *>(sp->plan.vals));
+                     sp->plan.vals = parked;
+                     return rc;
+                  }
                }
                sp->other = parked; sp->other_of = parked_of; sp->other_gen = parked_gen;
             } else {

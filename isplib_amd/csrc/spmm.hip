@@ -535,6 +535,7 @@ extern "C" int isplib_hip_tune(int key, int value) {
    if (key == 9 && (value == 32 || value == 64 || value == 128)) { g_sweep_panel = value; return ISPLIB_SUCCESS; }
    if (key == 10) { g_stream_merge_gens = value ? 1 : 0; return ISPLIB_SUCCESS; }
    if (key == 11) { g_sddmm_on_stream_plan = value ? 1 : 0; return ISPLIB_SUCCESS; }
+   if (key == 12 && value >= 0) { g_sddmm_panel_cols = value; return ISPLIB_SUCCESS; }
    return ISPLIB_FAIL;
 }
 

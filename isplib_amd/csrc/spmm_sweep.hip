@@ -938,14 +938,29 @@ __global__ __launch_bounds__(512, 2) void spmm_hybrid_kernel(const SweepArgs a) 
 // whose columns ascend the stream order of a row IS its CSR order and the first of equal candidates -- the lowest CSR
 // position, the reference's tie rule -- is the one that stays (the plan builders refuse graphs with unsorted rows for
 // this kernel).  No position travels with the gathers: the word index is arithmetic (batch, step, slot), and only the
-// M x K winners are translated to CSR positions, through the plan's `perm`, when a row is written out.  Padding words
-// (column n: the gather returns 0, which could beat negative values) are steered to a spare LDS row of the wave.
+// M x K winners are translated to CSR positions, through the plan's `perm`, when a row is written out.
+//
+// Round 4: the registers CARRY the row's pair.  Rounds 2-3 started every visit of a row from the identity and merged
+// the visit's winners into the row's LDS pair when the stream left it (read both planes, four compare-selects, write both
+// planes, reset eight registers: ~20 vector instructions per change of row on top of ~25 per step -- the ISA showed 40-45
+// vector instructions per step against 13 for the sum kernel, i.e. more vector-ALU cycles per step than the 26 the
+// address pipeline needs for the gather: the kernel was ALU-bound and wanted FEW changes of row, 8 slices of 7.5 MB,
+// 67 % L2 hits).  Now a change of row is a SWAP: the pair in the registers is stored to the row it belongs to, the pair
+// of the new row is loaded and the compare simply goes on -- two 16-byte LDS writes and two reads, no vector ALU work at
+// all -- so the row's best so far meets every later candidate directly ("strictly better" against the EARLIER stream
+// position keeps the tie rule), and the slices can be as small as the sum kernel's.  Padding words (column n: the gather
+// returns 0, which would beat negative values) carry the local row NVMAX, a spare LDS row of the wave that is never
+// written out: the plan builders emit it for max / min plans, so the loop neither tests for padding nor masks the column.
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+
 template <int OP, int LPR, bool HAS_VAL, int NVMAX, int NBW, int WGS>
 __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, 2 * (NVMAX + 1), WGS>())) void spmm_stream_minmax_kernel(const SweepArgs a) {
    constexpr int WAVES = 4, G = 64 / LPR, PANEL = LPR * 4, U = 64 * NBW / G;
    constexpr int PER = NVMAX / G;
    constexpr int WAVE_FLOATS = (NVMAX + 1) * PANEL;       // + the spare row of the padding words
-   __shared__ __attribute__((aligned(16))) float s_all[2 * WAVES * WAVE_FLOATS];
+   constexpr int PLANE = WAVES * WAVE_FLOATS;             // dwords from a value to its index: one array, two planes
+   static_assert(NVMAX + 1 <= 256 && NVMAX % G == 0, "the local row (and the spare row) is the top byte of a word");
+   __shared__ __attribute__((aligned(16))) float s_all[2 * PLANE];
    const int lane = threadIdx.x & 63;
    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
    const int g = lane / LPR, lc = lane % LPR;
@@ -953,24 +968,22 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, 2 * (NVMAX + 1), WGS>(
    if (wl >= a.wave_count) return;                       // no barrier anywhere below
    const int64_t w = (int64_t)a.wave_base + wl;
    float *my = s_all + wave * WAVE_FLOATS;
-   int *my_idx = reinterpret_cast<int *>(s_all + WAVES * WAVE_FLOATS) + wave * WAVE_FLOATS;
    for (int i = lane * 4; i < WAVE_FLOATS; i += 256) {
       *reinterpret_cast<float4 *>(my + i) = make_float4(identity<OP>(), identity<OP>(), identity<OP>(), identity<OP>());
-      *reinterpret_cast<int4 *>(my_idx + i) = make_int4(INT_MAX, INT_MAX, INT_MAX, INT_MAX);
+      *reinterpret_cast<int4 *>(my + i + PLANE) = make_int4(INT_MAX, INT_MAX, INT_MAX, INT_MAX);
    }
    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.y), 0, (int)a.ybytes, 0x00020000);
    const bool cok = lc * 4 < a.k;
    int ccol = lc * 4, vfirst = 0;
    if (cok && ccol + 4 > (int)a.k) { vfirst = ccol + 4 - (int)a.k; ccol = (int)a.k - 4; }
    const unsigned cbyte = (unsigned)ccol * 4u, poison = cok ? 0u : BUF_OOB;
-   float *lane_base = my + lc * 4;
-   int *lane_idx = my_idx + lc * 4;
+   float *lane_base = my + lc * 4;                        // a lane's four values of a row; their indices PLANE dwords on
    const int64_t s0 = a.wave_step_off[w], s1 = a.wave_step_off[w + 1];
    const int64_t nwords = (s1 - s0) * G;
    const int32_t *wp = a.words + s0 * G;
    const float *vp = HAS_VAL ? a.vals + s0 * G : nullptr;
    const unsigned ldyb = (unsigned)a.ldy * 4u;
-   const unsigned pad_word = ((unsigned)((lane % G) * PER) << 24) | a.null_word;
+   const unsigned pad_word = ((unsigned)NVMAX << 24) | a.null_word;      // past the end of the wave: the spare row too
    auto load_words = [&](int64_t first, unsigned (&word)[NBW]) {
 #pragma unroll
       for (int q = 0; q < NBW; q++) {
@@ -991,12 +1004,12 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, 2 * (NVMAX + 1), WGS>(
    v4i_t t[U];
    unsigned la[U];
    // (a weight is fetched from its batch register when its gather is consumed, one step ahead -- a ring of U weights
-   // beside the U gathers in flight does not fit the register file)
+   // beside the U gathers in flight does not fit the register file).  The 24-bit multiply reads the column straight out
+   // of the word: its top byte, the local row, is outside the bits the instruction looks at.
    auto issue = [&](int u, const unsigned (&word_l)[NBW]) {
       const unsigned word = (unsigned)__shfl((int)word_l[(u * G) / 64], (u * G) % 64 + g);
-      const unsigned colw = word & 0xFFFFFFu;
-      const unsigned o = (__umul24(colw, ldyb) + cbyte) | poison;
-      la[u] = colw == a.null_word ? (unsigned)(NVMAX * PANEL) : (word >> 24) * (unsigned)PANEL;     // padding: the spare row
+      const unsigned o = (__umul24(word, ldyb) + cbyte) | poison;
+      la[u] = (word >> 24) * (unsigned)PANEL;
       t[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)o, 0, 0);
    };
    load_words(0, w1);
@@ -1011,19 +1024,17 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, 2 * (NVMAX + 1), WGS>(
    int bi[4];
 #pragma unroll
    for (int v = 0; v < 4; v++) { acc[v] = identity<OP>(); bi[v] = INT_MAX; }
-   // the registers hold LATER stream positions than the LDS row they are merged into: the row's entry stays on a tie
-   auto flush = [&]() {
-      float4 *p = reinterpret_cast<float4 *>(lane_base + cur);
-      int4 *pi = reinterpret_cast<int4 *>(lane_idx + cur);
-      float4 o = *p;
-      int4 oi = *pi;
-      bool tk;
-      tk = OP == OP_MAX ? acc[0] > o.x : acc[0] < o.x; o.x = tk ? acc[0] : o.x; oi.x = tk ? bi[0] : oi.x;
-      tk = OP == OP_MAX ? acc[1] > o.y : acc[1] < o.y; o.y = tk ? acc[1] : o.y; oi.y = tk ? bi[1] : oi.y;
-      tk = OP == OP_MAX ? acc[2] > o.z : acc[2] < o.z; o.z = tk ? acc[2] : o.z; oi.z = tk ? bi[2] : oi.z;
-      tk = OP == OP_MAX ? acc[3] > o.w : acc[3] < o.w; o.w = tk ? acc[3] : o.w; oi.w = tk ? bi[3] : oi.w;
-      *p = o;
-      *pi = oi;
+   // change of row: the pair held goes to the row it belongs to, the new row's pair comes in.  The slots of a wave own
+   // disjoint rows (the spare row is written by all and read back by nobody who cares) and a wave's LDS operations execute
+   // in order, so a later visit of a row reads what the last one stored.
+   auto swap_to = [&](unsigned nxt) {
+      *reinterpret_cast<float4 *>(lane_base + cur) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      *reinterpret_cast<int4 *>(lane_base + cur + PLANE) = make_int4(bi[0], bi[1], bi[2], bi[3]);
+      const float4 o = *reinterpret_cast<const float4 *>(lane_base + nxt);
+      const int4 oi = *reinterpret_cast<const int4 *>(lane_base + nxt + PLANE);
+      acc[0] = o.x; acc[1] = o.y; acc[2] = o.z; acc[3] = o.w;
+      bi[0] = oi.x; bi[1] = oi.y; bi[2] = oi.z; bi[3] = oi.w;
+      cur = nxt;
    };
    const int64_t nb = (nwords + 64 * NBW - 1) / (64 * NBW);
    for (int64_t b = 0; b < nb; b++) {
@@ -1033,19 +1044,20 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, 2 * (NVMAX + 1), WGS>(
       for (int u = 0; u < U; u++) {
          const float vcur = vnext;
          if (HAS_VAL && u + 1 < U) vnext = __shfl(v0[((u + 1) * G) / 64], ((u + 1) * G) % 64 + g);
-         if (la[u] != cur) {
-            flush();
-            cur = la[u];
-#pragma unroll
-            for (int v = 0; v < 4; v++) { acc[v] = identity<OP>(); bi[v] = INT_MAX; }
-         }
+         if (la[u] != cur) swap_to(la[u]);              // per lane: the slots of a wave change rows at different steps
          const int widx = widx0 + u * G;
+         v2f_t x01 = {__int_as_float(t[u][0]), __int_as_float(t[u][1])};
+         v2f_t x23 = {__int_as_float(t[u][2]), __int_as_float(t[u][3])};
+         if (HAS_VAL) {                                  // two packed multiplies instead of four
+            const v2f_t vv = {vcur, vcur};
+            x01 *= vv;
+            x23 *= vv;
+         }
+         const float tt[4] = {x01.x, x01.y, x23.x, x23.y};
 #pragma unroll
          for (int v = 0; v < 4; v++) {
-            const float x = __int_as_float(t[u][v]);
-            const float tt = HAS_VAL ? vcur * x : x;
-            const bool win = OP == OP_MAX ? tt > acc[v] : tt < acc[v];      // NaN never wins, as in the oracle
-            acc[v] = win ? tt : acc[v];
+            const bool win = OP == OP_MAX ? tt[v] > acc[v] : tt[v] < acc[v];      // NaN never wins, as in the oracle
+            acc[v] = win ? tt[v] : acc[v];
             bi[v] = win ? widx : bi[v];
          }
          issue(u, w1);
@@ -1055,7 +1067,8 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, 2 * (NVMAX + 1), WGS>(
       load_words((b + 3) * 64 * NBW, w2);
       load_vals((b + 2) * 64 * NBW, v1);
    }
-   flush();
+   *reinterpret_cast<float4 *>(lane_base + cur) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+   *reinterpret_cast<int4 *>(lane_base + cur + PLANE) = make_int4(bi[0], bi[1], bi[2], bi[3]);
    // write-out: the winners' word indices become CSR positions through the plan's permutation
    const int32_t *ids = a.ids + s0 * G;
 #pragma unroll 1
@@ -1065,7 +1078,7 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, 2 * (NVMAX + 1), WGS>(
       if (row < 0 || !cok) continue;
       const int part = a.wave_part[(size_t)w * NVMAX + lrow];
       const float4 t4 = *reinterpret_cast<const float4 *>(lane_base + lrow * PANEL);
-      const int4 i4 = *reinterpret_cast<const int4 *>(lane_idx + lrow * PANEL);
+      const int4 i4 = *reinterpret_cast<const int4 *>(lane_base + lrow * PANEL + PLANE);
       float v[4] = {t4.x, t4.y, t4.z, t4.w};
       int best[4] = {i4.x, i4.y, i4.z, i4.w};
 #pragma unroll

@@ -125,11 +125,14 @@ __global__ __launch_bounds__(256) void sp_edge_keys_kernel(int64_t m, int64_t nn
    }
 }
 
-__global__ __launch_bounds__(256) void sp_pad_kernel(int64_t n_words, int streams, int per, uint32_t null_col, int32_t *__restrict__ words,
+// padding words: column n (the gather reads 0 through the range check); the local row is the first row of the word's own
+// stream (sum / mean: adding 0 changes nothing) or, pad_row >= 0 (max / min plans: a 0 could win), the kernel's spare row
+__global__ __launch_bounds__(256) void sp_pad_kernel(int64_t n_words, int streams, int per, int pad_row, uint32_t null_col, int32_t *__restrict__ words,
                                                      int32_t *__restrict__ perm, float *__restrict__ vals) {
    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += stride) {
-      words[i] = (int32_t)((((uint32_t)(i % streams) * (uint32_t)per) << 24) | null_col);
+      const uint32_t lrow = pad_row >= 0 ? (uint32_t)pad_row : (uint32_t)(i % streams) * (uint32_t)per;
+      words[i] = (int32_t)((lrow << 24) | null_col);
       perm[i] = -1;
       if (vals) vals[i] = 0.0f;
    }
@@ -242,7 +245,7 @@ extern "C" int isplib_stream_plan_set_values_hip(isplib_stream_plan *plan, const
 
 static int stream_plan_build(int64_t m, int64_t n, int64_t nnz, const int64_t *rowptr, const int64_t *col, const float *val,
                              int streams, int rpw, int resident, int slices, int chunk, int waves_per_gen,
-                             isplib_stream_plan *out, void *stream) {
+                             isplib_stream_plan *out, void *stream, int pad_row = -1) {
    if (!out) return fail(ISPLIB_FAIL, "isplib_stream_plan_build_hip: out is NULL");
    memset(out, 0, sizeof(*out));
    if (m <= 0 || n <= 0 || nnz < 0 || !rowptr || (nnz > 0 && !col)) return fail(ISPLIB_FAIL, "isplib_stream_plan_build_hip: bad operand");
@@ -377,7 +380,7 @@ static int stream_plan_build(int64_t m, int64_t n, int64_t nnz, const int64_t *r
                       wave_part, first, hub_idx, hub_off);
    SP_LAUNCHED("sp_wave_rows_kernel");
    if (n_words > 0) {
-      hipLaunchKernelGGL(sp_pad_kernel, dim3(sp_grid(n_words)), dim3(256), 0, st, n_words, streams, per, (uint32_t)n, words, perm, vals);
+      hipLaunchKernelGGL(sp_pad_kernel, dim3(sp_grid(n_words)), dim3(256), 0, st, n_words, streams, per, pad_row, (uint32_t)n, words, perm, vals);
       SP_LAUNCHED("sp_pad_kernel");
    }
    if (nnz > 0) {
@@ -407,7 +410,7 @@ extern "C" int isplib_stream_plan_build_hip(int64_t m, int64_t n, int64_t nnz, c
    clear_error();
    int rpw = 0, resident = 0;
    if (isplib_spmm_stream_geometry(streams, &rpw, &resident) != ISPLIB_SUCCESS) return ISPLIB_FAIL;
-   return stream_plan_build(m, n, nnz, rowptr, col, val, streams, rpw, resident, slices, chunk, waves_per_gen, out, stream);
+   return stream_plan_build(m, n, nnz, rowptr, col, val, streams, rpw, resident, slices, chunk, waves_per_gen, out, stream, /* pad_row = the spare row */ rpw);
 }
 
 // 1 if some row's columns do not ascend (duplicates are fine)
@@ -444,5 +447,5 @@ extern "C" int isplib_stream_plan_build_minmax_hip(int64_t m, int64_t n, int64_t
       if (!ok) return hip_fail(hipGetLastError(), "isplib_stream_plan_build_minmax_hip: sortedness check");
       if (host) return fail(ISPLIB_FAIL, "isplib_stream_plan_build_minmax_hip: rows are not column-sorted (use the task list)");
    }
-   return stream_plan_build(m, n, nnz, rowptr, col, val, streams, rpw, resident, slices, chunk, waves_per_gen, out, stream);
+   return stream_plan_build(m, n, nnz, rowptr, col, val, streams, rpw, resident, slices, chunk, waves_per_gen, out, stream, /* pad_row = the spare row */ rpw);
 }

@@ -79,6 +79,31 @@ class RowPartition:
         owner = torch.searchsorted(xc[1:].contiguous(), self.col, right=True).clamp_(max=world - 1)
         self.col_padded = (owner * self.max_rows + (self.col - xc[owner])).contiguous()
         self.ncols_padded = world * self.max_rows
+        self._parked = None          # first local kernel error of the exchange in progress (_kernel / _raise_parked)
+        self.fail_next_kernel = None  # test hook: an exception the next _kernel call fails with
+
+    # ---- local failures must not break the collective sequence ------------------------------------------------------
+    def _kernel(self, fn, *args, **kw):
+        """One local kernel call inside an exchange schedule.  A failure on THIS rank (an argument check of the C ABI, an
+        allocation) must not keep it from posting the sends / receives / waits its peers are going to block in: the first
+        error is parked, the schedule goes on with its communication (the remaining local kernels are skipped), and
+        `_raise_parked` raises it once the exchange is complete -- every rank has then issued the same collectives, so the
+        caller can tell its peers and all of them can go on (bench.py drops the candidate on every rank)."""
+        if self._parked is not None:
+            return
+        try:
+            if self.fail_next_kernel is not None:
+                e, self.fail_next_kernel = self.fail_next_kernel, None
+                raise e
+            fn(*args, **kw)
+        except Exception as e:  # noqa: BLE001 - re-raised by _raise_parked
+            self._parked = e
+
+    def _raise_parked(self):
+        e, self._parked = self._parked, None
+        if e is not None:
+            e.collectives_complete = True      # for the caller: this rank is still in step with its peers
+            raise e
 
     def shard(self, x_full: torch.Tensor) -> torch.Tensor:
         """This rank's rows of a replicated X, zero-padded to max_rows."""
@@ -157,13 +182,14 @@ class RowPartition:
         # local slices: column ids are in the padded layout, so shift the base onto the shard
         y_local = x_shard.data_ptr() - self.rank * self.max_rows * x_shard.stride(0) * 4
         common = (msg, self.rowptr, self.col_padded, self.val, table, s)
-        cabi.fusedMM_csr_sliced_phase_hip(*common, first, q, False, y_local, self.ncols_padded, k, x_shard.stride(0),
-                                          out, arg, work)
+        self._kernel(cabi.fusedMM_csr_sliced_phase_hip, *common, first, q, False, y_local, self.ncols_padded, k, x_shard.stride(0),
+                     out, arg, work)
         if handle is not None:
             handle.wait()
         # every other slice (the range wraps around modulo s), evenly over the 8 XCDs, then the fold
-        cabi.fusedMM_csr_sliced_phase_hip(*common, (first + q) % s, s - q, True, buf.data_ptr(), self.ncols_padded, k,
-                                          buf.stride(0), out, arg, work)
+        self._kernel(cabi.fusedMM_csr_sliced_phase_hip, *common, (first + q) % s, s - q, True, buf.data_ptr(), self.ncols_padded, k,
+                     buf.stride(0), out, arg, work)
+        self._raise_parked()
         return out
 
 
@@ -215,13 +241,14 @@ class RowPartition:
         works = self.post_direct(x_shard, buf, batches)
         # own shard: column ids are in the padded layout, so shift the base onto the shard
         y_local = x_shard.data_ptr() - r * self.max_rows * x_shard.stride(0) * 4
-        cabi.fusedMM_csr_sliced_phase_hip(*common, r * q, q, P == 1, y_local, self.ncols_padded, k, x_shard.stride(0), out, arg, work)
+        self._kernel(cabi.fusedMM_csr_sliced_phase_hip, *common, r * q, q, P == 1, y_local, self.ncols_padded, k, x_shard.stride(0), out, arg, work)
         for i, (d0, d1, reqs) in enumerate(works):
             for req in reqs:
                 req.wait()
             first = ((r - (d1 - 1)) % P) * q                 # shards r-d1+1 .. r-d0, ascending modulo P
-            cabi.fusedMM_csr_sliced_phase_hip(*common, first, (d1 - d0) * q, i == len(works) - 1, buf.data_ptr(), self.ncols_padded,
-                                              k, buf.stride(0), out, arg, work)
+            self._kernel(cabi.fusedMM_csr_sliced_phase_hip, *common, first, (d1 - d0) * q, i == len(works) - 1, buf.data_ptr(),
+                         self.ncols_padded, k, buf.stride(0), out, arg, work)
+        self._raise_parked()
         return out
 
     # ---- pipelined form: K is cut into panels, panel c+1 travels while panel c is aggregated -------
@@ -300,10 +327,11 @@ class RowPartition:
             if handle is not None:
                 handle.wait()
             if hasattr(tplan, "words"):                     # a stream plan (sum / mean)
-                cabi.fusedMM_csr_stream_hip(msg, self.rowptr, self.nnz, tplan, r_buf, out[:, c0:c1], work)
+                self._kernel(cabi.fusedMM_csr_stream_hip, msg, self.rowptr, self.nnz, tplan, r_buf, out[:, c0:c1], work)
             else:
-                cabi.fusedMM_csr_tasks_hip(msg, self.rowptr, self.col_padded, self.val, tplan, r_buf, out[:, c0:c1],
-                                           None if arg is None else arg[:, c0:c1], work)
+                self._kernel(cabi.fusedMM_csr_tasks_hip, msg, self.rowptr, self.col_padded, self.val, tplan, r_buf, out[:, c0:c1],
+                             None if arg is None else arg[:, c0:c1], work)
+        self._raise_parked()
         return out
 
 

@@ -261,7 +261,7 @@ class StreamPlan:
 
 
 def stream_plan_arrays(rowptr: torch.Tensor, col: torch.Tensor, ncols: int, slices: int, waves_per_gen: int,
-                       rows_per_wave: int = 16, streams: int = 4, chunk: int = 2048) -> dict:
+                       rows_per_wave: int = 16, streams: int = 4, chunk: int = 2048, pad_row: Optional[int] = None) -> dict:
     """The arrays of a stream plan; plain torch ops on the device of `col` (once per graph and geometry).
 
       * rows over `chunk` edges are dealt edge by edge, round robin, to ceil(deg / chunk) virtual rows: every
@@ -347,8 +347,13 @@ def stream_plan_arrays(rowptr: torch.Tensor, col: torch.Tensor, ncols: int, slic
     n_steps = int(wave_step_off[-1])
     idx = (wave_step_off[e_sid // streams] + p) * streams + e_sid % streams
     del p, start
-    # padding: column n (reads 0 through the range check), row = the first row of the word's own stream
-    pad = ((torch.arange(streams, **i64) * per) << 24) | int(ncols)
+    # padding: column n (reads 0 through the range check), row = the first row of the word's own stream (sum / mean) or,
+    # for max / min plans -- where a 0 could win -- `pad_row`, the kernel's spare row
+    if pad_row is None:
+        pad = ((torch.arange(streams, **i64) * per) << 24) | int(ncols)
+    else:
+        pad = torch.full((streams,), (int(pad_row) << 24) | int(ncols), **i64)
+    pad = torch.where(pad >= 2 ** 31, pad - 2 ** 32, pad)                        # the top byte may reach the sign bit
     words = pad.to(torch.int32).repeat(n_steps)
     words[idx] = ((lrow[ev][perm] << 24) | col[perm]).to(torch.int32)
     perm_out = torch.full((n_steps * streams,), -1, dtype=torch.int32 if nnz < 2 ** 31 else torch.int64, device=dev)
@@ -381,7 +386,8 @@ def build_stream_plan(rowptr: torch.Tensor, col: torch.Tensor, val: Optional[tor
         rpw, resident = cabi.stream_geometry(streams)
     rows_per_wave = rpw if rows_per_wave is None else rows_per_wave
     waves_per_gen = resident if waves_per_gen is None else waves_per_gen
-    plan = StreamPlan(**stream_plan_arrays(rowptr, col, ncols, slices, waves_per_gen, rows_per_wave, streams, chunk))
+    plan = StreamPlan(**stream_plan_arrays(rowptr, col, ncols, slices, waves_per_gen, rows_per_wave, streams, chunk,
+                                           pad_row=rows_per_wave if minmax else None))
     plan.set_values(val)
     return plan
 
@@ -400,6 +406,9 @@ def build_stream_plan_native(rowptr: torch.Tensor, col: torch.Tensor, ncols: int
         native = cabi.NativeStreamPlan(rowptr, col, None, ncols, streams, slices, chunk, 0, minmax)
     except cabi.IsplibError as e:
         if e.status == cabi.ISPLIB_FAIL:          # outside the builder's domain / unsorted rows: the caller's other schedules
+            return None
+        if e.status == cabi.ISPLIB_NOT_ENOUGH_MEM:    # no room for the plan (3 x 4 B per edge): the task list / plain kernel
+            torch.cuda.empty_cache()                  # serve the call, as the C handle's side_stream_plan does
             return None
         raise
     i32, i64 = torch.int32, torch.int64

@@ -36,10 +36,18 @@ def label_propagation(rowptr: torch.Tensor, col: torch.Tensor, rounds: int = 8, 
         urow, ulab = ukey // n, ukey % n
         del ukey
         tie = ((ulab * 2654435761 + (seed + r) * 40503 + 12345) >> 7) % big
-        score = (cnt * big + tie) * n + ulab               # equal count and hash: the larger label (reorder.hip: ro_mode_kernel)
+        # most frequent label of a row; equal count: the larger hash; equal hash: the larger label (reorder.hip: ro_mode_kernel).
+        # Two stages, so that nothing is packed beyond 63 bits: (count, hash) first -- count < 2^31 edges, hash < 2^20 --
+        # then the label among the winners (one packed key (cnt * 2^20 + tie) * n + label overflows int64 once a row has
+        # 2^22 neighbours under one label at n ~ 2^21)
+        score = cnt * big + tie
         best = torch.full((n,), -1, dtype=torch.int64, device=dev)
         best.scatter_reduce_(0, urow, score, reduce="amax", include_self=True)
-        win = score == best[urow]
+        first = score == best[urow]
+        lab_best = torch.full((n,), -1, dtype=torch.int64, device=dev)
+        lab_best.scatter_reduce_(0, urow[first], ulab[first], reduce="amax", include_self=True)
+        win = first & (ulab == lab_best[urow])
+        del first, lab_best
         new = labels.clone()
         new[urow[win]] = ulab[win]
         changed = int((new != labels).sum())

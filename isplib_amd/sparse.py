@@ -130,9 +130,17 @@ class SparseStorage:
             return []
         cache = self.__dict__.setdefault("_row_orders", {})
         if transposed not in cache:
-            from . import reorder
+            from . import cabi, reorder
             rp, cl = (self.colptr(), self.row_t()) if transposed else (self._rowptr, self._col)
-            cache[transposed] = reorder.useful_order(rp, cl)
+            try:
+                cache[transposed] = reorder.useful_order(rp, cl)
+            except (cabi.IsplibError, torch.OutOfMemoryError) as e:
+                # the search is a speed-up only (~16 nnz + 16 m bytes of workspace, 8 radix sorts): when it cannot run, the
+                # plain kernel in index order serves the call -- and the failure is remembered, not retried per call
+                import warnings
+                warnings.warn(f"isplib_amd: the row-order search was skipped ({type(e).__name__}: {e}); rows stay in index order")
+                cache[transposed] = None
+                torch.cuda.empty_cache()
         return [] if cache[transposed] is None else [cache[transposed]]
 
     def plan_t(self, n_slices: int):

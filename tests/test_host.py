@@ -726,3 +726,163 @@ def test_hybrid_plan_serves_every_edge_once_from_the_table_or_the_gather_stream(
     ref = np.zeros((n, 3))
     np.add.at(ref, np.repeat(np.arange(n), np.diff(rowptr)), x[col])
     assert np.array_equal(out, ref)
+
+
+# ---- bench.py at N > 1: failure containment (class Guard, explore_candidates), on the CPU over gloo ------------------------
+_GUARD_WORKER = r"""
+import importlib.util, json, os, sys, time
+from datetime import timedelta
+sys.path.insert(0, {root!r})
+import torch, torch.distributed as dist
+spec = importlib.util.spec_from_file_location("bench_mod", os.path.join({root!r}, "bench.py"))
+bench = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(bench)
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+mode = os.environ["GUARD_MODE"]
+guard = bench.Guard(rank, world)
+guard.arm("north_star form", float(os.environ.get("T_SAFE", "20")))
+dist.init_process_group("gloo", timeout=timedelta(seconds=30))
+t = torch.ones(4)
+parked = []                                    # what isplib_amd.dist.RowPartition._kernel / _raise_parked do for a real schedule
+
+agree = bench.StoreAgreement(dist.distributed_c10d._get_default_store(), rank, world, timeout_s=float(os.environ.get("T_CAND", "6")) + 4)
+
+def exchange():                                # a schedule: its collectives always complete, a local failure is raised after them
+    dist.all_reduce(t)
+    dist.all_reduce(t)
+    if parked:
+        e = parked.pop()
+        e.collectives_complete = True
+        raise e
+
+def clock(fn):
+    fn()
+    return 1.0
+
+if mode == "hang-before-result" and rank == 1:
+    time.sleep(1e6)
+dist.all_reduce(t)                             # the north_star form, measured: from here on there is a result
+guard.offer({{"metric": "edges_aggregated_per_sec", "value": 1.0, "n_gpus": world}} if rank == 0 else None)
+if mode == "sigterm":
+    guard.arm("holding the result", 120)
+    open(os.path.join(os.environ["HOLD_DIR"], f"holding.{{rank}}"), "w").close()
+    time.sleep(1e6)
+cands = {{"A": exchange, "B": exchange, "C": exchange}}
+broken = None
+times = {{}}
+try:
+    times = bench.explore_candidates(cands, check=lambda name, fn: (fn(), True)[1], clock=clock, agree=agree, guard=guard, rank=rank,
+                                     per_candidate_s=float(os.environ.get("T_CAND", "6")), until_s=120.0, on_fault=parked.append)
+except Exception as e:
+    broken = repr(e)
+res = {{"metric": "edges_aggregated_per_sec", "value": 1.0, "n_gpus": world, "candidates_ms": times}}
+if broken:
+    res["abandoned"] = broken
+guard.emit(res)
+sys.stdout.flush()
+os._exit(0)
+"""
+
+
+def _run_guard_workers(tmp_path, mode, port, inject="", world=2, timeout=90, extra_env=None):
+    script = tmp_path / "guard_worker.py"
+    script.write_text(_GUARD_WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), OMP_NUM_THREADS="1",
+               GUARD_MODE=mode, ISPLIB_BENCH_INJECT=inject, **(extra_env or {}))
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(world)]
+    return procs
+
+
+def _json_lines(text):
+    import json
+    return [json.loads(ln) for ln in text.splitlines() if ln.startswith("{") and '"metric"' in ln]
+
+
+def test_bench_candidate_that_fails_on_one_rank_is_dropped_on_every_rank(tmp_path):
+    """A local kernel failure inside an optional exchange schedule on ONE rank (parked until the schedule's collectives are
+    done, as isplib_amd.dist does): the schedule is dropped on every rank and the job goes on with the remaining ones."""
+    import time as _t
+    t0 = _t.time()
+    procs = _run_guard_workers(tmp_path, "explore", 29571, inject="kernel:B:1")
+    outs = [p.communicate(timeout=90) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
+    lines = _json_lines(outs[0][0])
+    assert len(lines) == 1 and sorted(lines[0]["candidates_ms"]) == ["A", "C"] and "abandoned" not in lines[0]
+    assert _json_lines(outs[1][0]) == [] and "dropped on every rank" in outs[0][1]
+    assert _t.time() - t0 < 60
+
+
+def test_bench_rank_that_never_arrives_ends_the_job_nonzero_within_the_deadline(tmp_path):
+    """Before any result exists a rank that blocks for ever must not hang the job: every rank's guard ends it with a
+    non-zero exit code and no JSON line inside the phase's deadline."""
+    import time as _t
+    t0 = _t.time()
+    procs = _run_guard_workers(tmp_path, "hang-before-result", 29572, extra_env={"T_SAFE": "6"})
+    outs = [p.communicate(timeout=90) for p in procs]
+    assert [p.returncode for p in procs] == [5, 5], [o[1][-2000:] for o in outs]
+    assert _json_lines(outs[0][0]) == [] and "deadline passed in phase 'north_star form'" in outs[0][1]
+    assert "no result yet" in outs[1][1] and _t.time() - t0 < 60
+
+
+@pytest.mark.parametrize("kind", ("hang", "raise"))
+def test_bench_optional_schedule_that_hangs_or_desynchronises_cannot_lose_the_measured_result(tmp_path, kind):
+    """After the north_star form has been measured, an optional schedule in which one rank never comes back (hang) or
+    raises before its first collective while its peers wait in it (raise) ends with exit code 0 and rank 0's ONE JSON
+    line: the result already measured, marked with what was abandoned."""
+    import time as _t
+    t0 = _t.time()
+    procs = _run_guard_workers(tmp_path, "explore", 29573 + (kind == "raise"), inject=f"{kind}:B:1", extra_env={"T_CAND": "5"})
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [(p.returncode, o[1][-2000:]) for p, o in zip(procs, outs)]
+    lines = _json_lines(outs[0][0])
+    assert len(lines) == 1 and lines[0]["value"] == 1.0 and lines[0]["n_gpus"] == 2
+    if kind == "hang":
+        assert "optional schedule 'B'" in lines[0]["abandoned"]
+    assert _json_lines(outs[1][0]) == [] and _t.time() - t0 < 90
+
+
+def test_bench_sigterm_from_the_launcher_prints_the_measured_result(tmp_path):
+    """torchrun ends the surviving ranks with SIGTERM when one rank dies: rank 0's guard takes the signal on its own
+    thread (the main thread may sit in a collective) and prints the result it holds before leaving."""
+    import signal as _sig
+    import time as _t
+    procs = _run_guard_workers(tmp_path, "sigterm", 29575, extra_env={"HOLD_DIR": str(tmp_path)})
+    deadline = _t.time() + 90
+    while not all((tmp_path / f"holding.{r}").exists() for r in range(2)) and _t.time() < deadline:      # both ranks hold the result
+        _t.sleep(0.2)
+    assert all((tmp_path / f"holding.{r}").exists() for r in range(2))
+    for p in procs:
+        p.send_signal(_sig.SIGTERM)
+    outs = [p.communicate(timeout=30) for p in procs]
+    assert [p.returncode for p in procs] == [0, 0], [o[1][-1500:] for o in outs]
+    lines = _json_lines(outs[0][0])
+    assert len(lines) == 1 and "SIGTERM" in lines[0]["abandoned"] and _json_lines(outs[1][0]) == []
+
+
+def test_bench_launcher_has_a_time_limit_and_ends_the_process_group(tmp_path, monkeypatch):
+    """`python bench.py --gpus N` as its own launcher: ranks that never finish are ended (whole process group) when the
+    limit passes, the launcher returns 124 and prints no line; the second attempt (north_star form only) is a fresh set
+    of children, never a re-used process."""
+    import importlib.util
+    import time as _t
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    marker = tmp_path / "started"
+    sleeper = tmp_path / "sleeper.py"
+    sleeper.write_text("import os, sys, time\nopen(sys.argv[1], 'a').write(os.environ.get('ISPLIB_OVERLAP', '1') + '\\n')\ntime.sleep(1e6)\n")
+    monkeypatch.setattr(bench, "launcher_command", lambda gpus, argv, port: [sys.executable, str(sleeper), str(marker)])
+    monkeypatch.setattr(bench, "visible_gpu_count", lambda *a_, **k_: 8)
+    monkeypatch.setenv("ISPLIB_BENCH_LAUNCH_TIMEOUT", "3")
+    t0 = _t.time()
+    rc = bench.self_launch(types.SimpleNamespace(gpus=2), ["--gpus", "2"])
+    assert rc == 124 and _t.time() - t0 < 40
+    assert marker.read_text().split() == ["1"]            # no time left for a second attempt: none was started
+    monkeypatch.setenv("ISPLIB_BENCH_LAUNCH_TIMEOUT", "200")
+    quick = tmp_path / "quick.py"
+    quick.write_text("import os, sys\nopen(sys.argv[1], 'a').write(os.environ.get('ISPLIB_OVERLAP', '1') + '\\n')\nsys.exit(7)\n")
+    marker.write_text("")
+    monkeypatch.setattr(bench, "launcher_command", lambda gpus, argv, port: [sys.executable, str(quick), str(marker)])
+    assert bench.self_launch(types.SimpleNamespace(gpus=2), ["--gpus", "2"]) == 7
+    assert marker.read_text().split() == ["1", "0"]       # first the full run, then once more restricted to the north_star form
