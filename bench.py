@@ -144,12 +144,12 @@ def extra_configs(dev, rowptr, col, n, with_cpu_epoch=True):
             roof["traffic_source"] = f"profiles/traffic.json[{key}]: " + rec.get("source", "rocprofv3 --pmc, separate passes")
         out.append(dict({"config": name, "ms": ms, "edges_per_s": e / (ms * 1e-3), "schedule": schedule, "roofline": roof}, **more))
 
-    def run(red, k, val, name):
+    def run(red, k, val, name, key=None):
         x = synth.features(n, k, device=dev, integer=red in ("max", "min"))
         z = torch.empty((n, k), dtype=torch.float32, device=dev)
         arg = torch.empty((n, k), dtype=torch.int64, device=dev) if red in ("max", "min") else None
         msg = cabi.MESSAGE[red]
-        geom = cabi.suggest_stream(n, n, nnz, k) if red in ("sum", "mean") else None
+        geom = cabi.suggest_stream(n, n, nnz, k, val is not None) if red in ("sum", "mean") else None
         geom_mm = cabi.suggest_stream_minmax(n, n, nnz, k) if red in ("max", "min") else None
         mplan = None if geom_mm is None else build_stream_plan(rowptr, col, val, n, geom_mm[1], None, None, geom_mm[0], geom_mm[2], minmax=True)
         if mplan is not None:
@@ -167,7 +167,7 @@ def extra_configs(dev, rowptr, col, n, with_cpu_epoch=True):
             ws = plan.workspace(red, k)
             ms = _time_launches(lambda: cabi.fusedMM_csr_tasks_hip(msg, rowptr, col, val, plan, x, z, arg, ws))
             sched = f"task list, {sl} slices"
-        entry(name, ms, n, n, nnz, k, arg is not None, sched, key=f"reddit-{red}-k{k}-weighted")
+        entry(name, ms, n, n, nnz, k, arg is not None, sched, key=key or f"reddit-{red}-k{k}-weighted")
 
     only = os.environ.get("ISPLIB_BENCH_ONLY", "")          # profiling: one configuration (its traffic.json key) instead of all
     for red in ("mean", "max", "min"):
@@ -175,6 +175,10 @@ def extra_configs(dev, rowptr, col, n, with_cpu_epoch=True):
             run(red, 64, w, f"config 3: reddit-like SpMM-{red} K=64, U(0,1) weights" + (" (+arg)" if red != "mean" else ""))
     if not only or only == "reddit-sum-k128-weighted":
         run("sum", 128, w, "config 2: reddit-like SpMM-sum K=128, U(0,1) weights")
+    # profiling only (--only): the two widths of config 5's six aggregations, unit weights, on their own
+    for kk in (32, 41):
+        if only == f"reddit-sum-k{kk}-unit":
+            run("sum", kk, None, f"config 5's aggregation width K={kk}: reddit-like SpMM-sum, unit weights", key=only)
     # the third leg of config 2's backward when the edge weights are trainable: dA[e] = <X[col[e]], dY[row(e)]>, the SDDMM the
     # reference leaves commented out (csrc/fusedmm.cpp:270), through the graph handle (task list sized for whole rows)
     if not only or only == "reddit-sddmm-k128":
@@ -186,11 +190,13 @@ def extra_configs(dev, rowptr, col, n, with_cpu_epoch=True):
         h.close()
         del xs, gs
     del w, col32
-    if only and not only.startswith("products"):
+    if only and not only.startswith("products") and only != "gcn-epoch":
         return out
 
-    if not only:
-        out.append(gcn_epoch_config(dev, rowptr, col, n, with_cpu_epoch))
+    if not only or only == "gcn-epoch":
+        out.append(gcn_epoch_config(dev, rowptr, col, n, with_cpu_epoch and not only))
+        if only:
+            return out
     out.extend(products_configs(dev, only))
     return out
 
@@ -312,10 +318,23 @@ def products_configs(dev, only=""):
         if order is not None:
             runs.append(("plain row-per-wave kernel, rows in the community order (label propagation, found once in "
                          f"{search_ms:.0f} ms; bit-identical result)", order, f"products-{tag}-sum-k256-ordered"))
+        plain_result = None
         for sched, o, key in runs:
             if only and only != key:
                 continue
             ms = _time_launches(lambda: cabi.fusedMM_csr_ordered_hip(cabi.MSG_SPMM_SUM, p_rowptr, p_col, None, o, px, pz))
+            identical = None
+            if o is None and len(runs) > 1 and not only:
+                plain_result = pz.clone()                         # (outside the timed launches) what the ordered run must reproduce
+            elif o is not None:
+                if plain_result is None:                          # --only <ordered key>: the plain launch once, untimed
+                    cabi.fusedMM_csr_ordered_hip(cabi.MSG_SPMM_SUM, p_rowptr, p_col, None, None, px, pz)
+                    plain_result = pz.clone()
+                    cabi.fusedMM_csr_ordered_hip(cabi.MSG_SPMM_SUM, p_rowptr, p_col, None, o, px, pz)
+                identical = bool(torch.equal(pz, plain_result))
+                plain_result = None
+                if not identical:
+                    raise SystemExit(f"bench.py: {key}: the community-ordered launch does not reproduce the index-order result bit for bit")
             b_alg = synth.algorithmic_bytes(pn, pn, e, k, False)
             rec = measured.get(key)
             roof = {"bound": "hbm", "achieved": b_alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -326,9 +345,10 @@ def products_configs(dev, only=""):
                 roof["traffic_source"] = f"profiles/traffic.json[{key}]: " + rec.get("source", "rocprofv3 --pmc, separate passes")
             out.append({"config": f"config 4 (one GPU): products-like SpMM-sum K=256, unit weights, N={pn}, nnz={e}; {graph}",
                         "ms": ms, "edges_per_s": e / (ms * 1e-3), "schedule": sched, "roofline": roof,
+                        **({} if identical is None else {"bit_identical_to_index_order": identical, "checked": f"torch.equal over all {pn} x {k} outputs, this run"}),
                         "order_search": ("a community order was kept" if order is not None else
                                          f"looked for a community order ({search_ms:.0f} ms, once): none worth keeping, index order")})
-        del p_rowptr, p_col, px, pz, order
+        del p_rowptr, p_col, px, pz, order, plain_result
     return out
 
 
@@ -972,7 +992,7 @@ def main():
     if a.schedule in ("auto", "stream") and a.reduce in ("sum", "mean"):
         from isplib_amd.plan import build_stream_plan
         geom = tuple(int(v) for v in a.stream_geom.split(":")) if a.stream_geom else \
-            cabi.suggest_stream(m_local, x_in.size(0), l_col.numel(), k)
+            cabi.suggest_stream(m_local, x_in.size(0), l_col.numel(), k, l_val is not None)
         if geom is not None and not a.stream_geom:          # no degree skew: slices closer to the L2 size (the plug-in's rule)
             from isplib_amd.plugin import skew_adjusted as _skew
             geom = (geom[0], _skew(l_rowptr, geom[1], cap=512), geom[2])
@@ -1295,6 +1315,8 @@ def main():
                 safe["gather+stream"] = gather_then_stream
             elif rank == 0:
                 print("[bench] schedule 'gather+stream' dropped on every rank (mismatch or error on at least one)", file=sys.stderr)
+        if injected_fault("north_star", rank) == "hang":       # rehearsal: a rank that never arrives, before any result exists
+            time.sleep(1e6)
         for name, fn in safe.items():
             note(f"timing schedule '{name}'")
             times[name] = clock(fn)

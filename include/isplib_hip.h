@@ -349,7 +349,7 @@ int    fusedMM_csr_sweep_hip(int32_t imessage, int64_t m, int64_t n, int64_t k, 
  */
 typedef struct isplib_stream_plan {
    int64_t rows, cols;              /* m, n of the graph the plan was built for */
-   int32_t slices, gens, waves_per_gen, rows_per_wave, streams /* 2, 4 or 8 */, reserved;
+   int32_t slices, gens, waves_per_gen, rows_per_wave, streams /* 2, 4 or 8 */, chunk /* rows over this many entries were dealt to virtual rows */;
    int64_t n_steps, n_parts, n_hub;
    const int32_t *words;            /* [dev] n_steps*streams: (local row << 24) | column; padding = (own row << 24) | n */
    const float   *vals;             /* [dev] n_steps*streams weights in the same order, or NULL */
@@ -376,6 +376,10 @@ int    isplib_spmm_stream_geometry(int streams, int *rows_per_wave /*out*/, int 
 /* the measured rule: nonzero when the stream schedule is expected to beat the task list for an m x n, nnz-entry SpMM
  * over k columns (sum / mean), with the plan parameters to build it with (streams, column slices, hub-row chunk) */
 int    isplib_suggest_stream(int64_t m, int64_t n, int64_t nnz, int64_t k, int *streams, int *slices, int *chunk);
+/* the same rule told whether the plan will carry edge weights (a weighted launch reads the plan's weight stream once per
+ * column panel: whole multiples of 128 columns then run on 128-column slots, streams = 2); isplib_suggest_stream is this
+ * with weighted = 0 */
+int    isplib_suggest_stream_weighted(int64_t m, int64_t n, int64_t nnz, int64_t k, int weighted, int *streams, int *slices, int *chunk);
 /* max / min on the stream schedule, for graphs whose rows are column-sorted (ascending, duplicates allowed).  The
  * running sum becomes the best value so far and the WORD INDEX at which it was met; a second LDS plane keeps those
  * indices beside the values, and only a strictly better candidate replaces the one held.  The plan walks a row's edges

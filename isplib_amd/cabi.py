@@ -52,7 +52,7 @@ EXPORTS = (
     "isplib_suggest_slices", "isplib_graph_create", "isplib_graph_set_slices", "isplib_graph_set_values", "isplib_graph_spmm", "isplib_graph_spmm_backward",
     "isplib_graph_destroy", "isplib_suggest_slices_whole_rows", "isplib_graph_sddmm",
     "fusedMM_csr_sweep_hip", "isplib_spmm_sweep_workspace_bytes", "isplib_spmm_sweep_resident_waves",
-    "fusedMM_csr_stream_hip", "isplib_spmm_stream_workspace_bytes", "isplib_spmm_stream_geometry", "isplib_suggest_stream", "isplib_stream_plan_build_hip", "isplib_stream_plan_build_minmax_hip", "fusedMM_csr_stream_minmax_hip", "isplib_spmm_stream_minmax_geometry", "isplib_suggest_stream_minmax", "isplib_spmm_stream_minmax_workspace_bytes", "isplib_stream_plan_set_values_hip", "isplib_stream_plan_free", "isplib_spmm_minmax_bw_det_hip", "isplib_spmm_minmax_bw_workspace_bytes",
+    "fusedMM_csr_stream_hip", "isplib_spmm_stream_workspace_bytes", "isplib_spmm_stream_geometry", "isplib_suggest_stream", "isplib_suggest_stream_weighted", "isplib_stream_plan_build_hip", "isplib_stream_plan_build_minmax_hip", "fusedMM_csr_stream_minmax_hip", "isplib_spmm_stream_minmax_geometry", "isplib_suggest_stream_minmax", "isplib_spmm_stream_minmax_workspace_bytes", "isplib_stream_plan_set_values_hip", "isplib_stream_plan_free", "isplib_spmm_minmax_bw_det_hip", "isplib_spmm_minmax_bw_workspace_bytes",
     "fusedMM_csr_hybrid_hip", "isplib_spmm_hybrid_geometry", "isplib_spmm_hybrid_workspace_bytes", "isplib_sddmm_stream_hip",
     "fusedMM_csr_ordered_hip", "isplib_community_order_hip", "isplib_community_order_workspace_bytes", "isplib_order_locality_hip",
     "isplib_graph_set_row_order",
@@ -82,7 +82,7 @@ class SweepPlanStruct(ctypes.Structure):   # isplib_sweep_plan
 class StreamPlanStruct(ctypes.Structure):  # isplib_stream_plan
     _fields_ = [("rows", ctypes.c_int64), ("cols", ctypes.c_int64), ("slices", ctypes.c_int32), ("gens", ctypes.c_int32),
                 ("waves_per_gen", ctypes.c_int32), ("rows_per_wave", ctypes.c_int32), ("streams", ctypes.c_int32),
-                ("reserved", ctypes.c_int32), ("n_steps", ctypes.c_int64), ("n_parts", ctypes.c_int64), ("n_hub", ctypes.c_int64),
+                ("chunk", ctypes.c_int32), ("n_steps", ctypes.c_int64), ("n_parts", ctypes.c_int64), ("n_hub", ctypes.c_int64),
                 ("words", ctypes.c_void_p), ("vals", ctypes.c_void_p), ("wave_step_off", ctypes.c_void_p),
                 ("wave_row", ctypes.c_void_p), ("wave_part", ctypes.c_void_p),
                 ("hub_row", ctypes.c_void_p), ("hub_off", ctypes.c_void_p), ("perm", ctypes.c_void_p)]
@@ -226,6 +226,8 @@ def lib() -> ctypes.CDLL:
                                               ctypes.c_int, _vp, _vp]
         L.isplib_suggest_stream.restype = ctypes.c_int
         L.isplib_suggest_stream.argtypes = [_i64, _i64, _i64, _i64, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+        L.isplib_suggest_stream_weighted.restype = ctypes.c_int
+        L.isplib_suggest_stream_weighted.argtypes = [_i64, _i64, _i64, _i64, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
         L.isplib_spmm_stream_geometry.restype = ctypes.c_int
         L.isplib_spmm_stream_geometry.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
         L.isplib_spmm_stream_workspace_bytes.restype = ctypes.c_size_t
@@ -821,10 +823,11 @@ def spmm_hybrid(rowptr, nnz: int, plan, y, reduce: str = "sum", workspace=None, 
     return out
 
 
-def suggest_stream(m: int, n: int, nnz: int, k: int):
-    """(streams, slices, chunk) when the stream schedule is expected to win for this shape, else None (isplib_suggest_stream)."""
+def suggest_stream(m: int, n: int, nnz: int, k: int, weighted: bool = False):
+    """(streams, slices, chunk) when the stream schedule is expected to win for this shape, else None
+    (isplib_suggest_stream_weighted; `weighted`: the plan will carry edge weights)."""
     st, sl, ch = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
-    if not lib().isplib_suggest_stream(int(m), int(n), int(nnz), int(k), ctypes.byref(st), ctypes.byref(sl), ctypes.byref(ch)):
+    if not lib().isplib_suggest_stream_weighted(int(m), int(n), int(nnz), int(k), int(bool(weighted)), ctypes.byref(st), ctypes.byref(sl), ctypes.byref(ch)):
         return None
     return st.value, sl.value, ch.value
 

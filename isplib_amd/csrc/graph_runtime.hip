@@ -408,7 +408,7 @@ static int side_stream_plan(isplib_graph *g, Side &s, const float *val, int64_t 
    int st_streams = 0, st_slices = 0, st_chunk = 0;
    const bool y_in_one_descriptor = (double)s.n * (double)ldy * 4.0 <= 3.5 * 1073741824.0;      // with the caller's ldy, not k
    if (g->forced_slices >= 0 || s.stream_refused || ldy >= (1LL << 22) || !y_in_one_descriptor ||
-       !isplib_suggest_stream(s.m, s.n, s.nnz, k, &st_streams, &st_slices, &st_chunk))
+       !isplib_suggest_stream_weighted(s.m, s.n, s.nnz, k, val != nullptr, &st_streams, &st_slices, &st_chunk))
       return ISPLIB_SUCCESS;
    st_slices = skew_adjusted(s, st_slices, st, 512);      // no degree skew: slices closer to the L2 size (31 -> 47: 3.21 -> 3.00 ms)
    const uint64_t key = ((uint64_t)st_streams << 48) | ((uint64_t)st_slices << 32) | (uint64_t)(uint32_t)st_chunk;

@@ -951,33 +951,42 @@ __global__ __launch_bounds__(512, 2) void spmm_hybrid_kernel(const SweepArgs a) 
 // position keeps the tie rule), and the slices can be as small as the sum kernel's.  Padding words (column n: the gather
 // returns 0, which would beat negative values) carry the local row NVMAX, a spare LDS row of the wave that is never
 // written out: the plan builders emit it for max / min plans, so the loop neither tests for padding nor masks the column.
+// (Also built in round 4 and dropped: 16-bit row-relative ORDINALS in place of the 32-bit word indices -- 388 bytes of LDS per
+// row instead of 512, 48 rows per wave, three generations on the Reddit shape instead of four, no permutation lookup at
+// write-out; bit-exact, and slower: K=64 weighted 1.89 against 1.81 ms, unit 1.63 against 1.61 -- the swap then packs and
+// unpacks and moves a per-row word count as well, which costs what the saved dispatch gave.)
 typedef float v2f_t __attribute__((ext_vector_type(2)));
 
 template <int OP, int LPR, bool HAS_VAL, int NVMAX, int NBW, int WGS>
 __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, 2 * (NVMAX + 1), WGS>())) void spmm_stream_minmax_kernel(const SweepArgs a) {
    constexpr int WAVES = 4, G = 64 / LPR, PANEL = LPR * 4, U = 64 * NBW / G;
    constexpr int PER = NVMAX / G;
-   constexpr int WAVE_FLOATS = (NVMAX + 1) * PANEL;       // + the spare row of the padding words
-   constexpr int PLANE = WAVES * WAVE_FLOATS;             // dwords from a value to its index: one array, two planes
-   static_assert(NVMAX + 1 <= 256 && NVMAX % G == 0, "the local row (and the spare row) is the top byte of a word");
-   __shared__ __attribute__((aligned(16))) float s_all[2 * PLANE];
+   constexpr int ROWS = NVMAX + 1;                        // + the spare row of the padding words
+   constexpr int WAVE_DWORDS = 2 * ROWS * PANEL;          // a wave's block: the values, then their indices
+   constexpr int IDX0 = ROWS * PANEL;
+   constexpr int NONE = INT_MAX;                          // "no winner yet"
+   static_assert(ROWS <= 256 && NVMAX % G == 0, "the local row (and the spare row) is the top byte of a word");
+   __shared__ __attribute__((aligned(16))) float s_all[WAVES * WAVE_DWORDS];
    const int lane = threadIdx.x & 63;
    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
    const int g = lane / LPR, lc = lane % LPR;
    const int wl = (int)blockIdx.x * WAVES + wave;
    if (wl >= a.wave_count) return;                       // no barrier anywhere below
    const int64_t w = (int64_t)a.wave_base + wl;
-   float *my = s_all + wave * WAVE_FLOATS;
-   for (int i = lane * 4; i < WAVE_FLOATS; i += 256) {
+   float *my = s_all + wave * WAVE_DWORDS;
+   for (int i = lane * 4; i < ROWS * PANEL; i += 256)
       *reinterpret_cast<float4 *>(my + i) = make_float4(identity<OP>(), identity<OP>(), identity<OP>(), identity<OP>());
-      *reinterpret_cast<int4 *>(my + i + PLANE) = make_int4(INT_MAX, INT_MAX, INT_MAX, INT_MAX);
-   }
+   for (int i = lane * 4; i < ROWS * PANEL; i += 256)
+      *reinterpret_cast<int4 *>(my + IDX0 + i) = make_int4(INT_MAX, INT_MAX, INT_MAX, INT_MAX);
    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.y), 0, (int)a.ybytes, 0x00020000);
    const bool cok = lc * 4 < a.k;
    int ccol = lc * 4, vfirst = 0;
    if (cok && ccol + 4 > (int)a.k) { vfirst = ccol + 4 - (int)a.k; ccol = (int)a.k - 4; }
-   const unsigned cbyte = (unsigned)ccol * 4u, poison = cok ? 0u : BUF_OOB;
-   float *lane_base = my + lc * 4;                        // a lane's four values of a row; their indices PLANE dwords on
+   // lanes beyond column k gather nothing: their column term is 2^31, past the end of the descriptor (the entry admits dense
+   // operands under 2 GiB only, so row offset + 2^31 neither stays inside the descriptor nor wraps) -- no OR in the loop
+   const unsigned cbyte = cok ? (unsigned)ccol * 4u : 0x80000000u;
+   float *lane_base = my + lc * 4;                        // a lane's four values of a row ...
+   int *lane_idx = reinterpret_cast<int *>(my + IDX0) + lc * 4;      // ... and their indices
    const int64_t s0 = a.wave_step_off[w], s1 = a.wave_step_off[w + 1];
    const int64_t nwords = (s1 - s0) * G;
    const int32_t *wp = a.words + s0 * G;
@@ -998,6 +1007,7 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, 2 * (NVMAX + 1), WGS>(
          val[q] = HAS_VAL && i < nwords ? vp[i] : 0.0f;
       }
    };
+   const int g4 = g * 4;                                  // byte address of lane g for ds_bpermute
    unsigned w1[NBW], w2[NBW];
    float v0[NBW], v1[NBW];                               // the weights of the batch being consumed and of the next: a weight is
                                                          // needed one batch later than its word, so it is loaded one batch later
@@ -1006,16 +1016,19 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, 2 * (NVMAX + 1), WGS>(
    // (a weight is fetched from its batch register when its gather is consumed, one step ahead -- a ring of U weights
    // beside the U gathers in flight does not fit the register file).  The 24-bit multiply reads the column straight out
    // of the word: its top byte, the local row, is outside the bits the instruction looks at.
-   auto issue = [&](int u, const unsigned (&word_l)[NBW]) {
-      const unsigned word = (unsigned)__shfl((int)word_l[(u * G) / 64], (u * G) % 64 + g);
-      const unsigned o = (__umul24(word, ldyb) + cbyte) | poison;
+   // the slot's word of step u of a batch register set: lane (u * G) % 64 + g of register (u * G) / 64
+   auto fetch = [&](int u, const unsigned (&word_l)[NBW]) {
+      return (unsigned)__builtin_amdgcn_ds_bpermute(g4 + (int)(((u * G) % 64) * 4), (int)word_l[(u * G) / 64]);
+   };
+   auto issue = [&](int u, unsigned word) {
+      const unsigned o = __umul24(word, ldyb) + cbyte;
       la[u] = (word >> 24) * (unsigned)PANEL;
       t[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)o, 0, 0);
    };
    load_words(0, w1);
    load_vals(0, v0);
 #pragma unroll
-   for (int u = 0; u < U; u++) issue(u, w1);
+   for (int u = 0; u < U; u++) issue(u, fetch(u, w1));
    load_words(64 * NBW, w1);
    load_vals(64 * NBW, v1);
    load_words(128 * NBW, w2);
@@ -1023,29 +1036,37 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, 2 * (NVMAX + 1), WGS>(
    float acc[4];
    int bi[4];
 #pragma unroll
-   for (int v = 0; v < 4; v++) { acc[v] = identity<OP>(); bi[v] = INT_MAX; }
+   for (int v = 0; v < 4; v++) { acc[v] = identity<OP>(); bi[v] = NONE; }
    // change of row: the pair held goes to the row it belongs to, the new row's pair comes in.  The slots of a wave own
    // disjoint rows (the spare row is written by all and read back by nobody who cares) and a wave's LDS operations execute
    // in order, so a later visit of a row reads what the last one stored.
+   // (reads first: the wave then waits for the loads only -- the stores just have to be issued)
    auto swap_to = [&](unsigned nxt) {
-      *reinterpret_cast<float4 *>(lane_base + cur) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-      *reinterpret_cast<int4 *>(lane_base + cur + PLANE) = make_int4(bi[0], bi[1], bi[2], bi[3]);
+      asm volatile("" : "+v"(nxt));                      // keeps the LDS address arithmetic inside the branch (one vector instruction per step otherwise)
       const float4 o = *reinterpret_cast<const float4 *>(lane_base + nxt);
-      const int4 oi = *reinterpret_cast<const int4 *>(lane_base + nxt + PLANE);
-      acc[0] = o.x; acc[1] = o.y; acc[2] = o.z; acc[3] = o.w;
+      const int4 oi = *reinterpret_cast<const int4 *>(lane_idx + nxt);
+      *reinterpret_cast<float4 *>(lane_base + cur) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      *reinterpret_cast<int4 *>(lane_idx + cur) = make_int4(bi[0], bi[1], bi[2], bi[3]);
       bi[0] = oi.x; bi[1] = oi.y; bi[2] = oi.z; bi[3] = oi.w;
+      acc[0] = o.x; acc[1] = o.y; acc[2] = o.z; acc[3] = o.w;
       cur = nxt;
    };
    const int64_t nb = (nwords + 64 * NBW - 1) / (64 * NBW);
    for (int64_t b = 0; b < nb; b++) {
       const int widx0 = (int)(b * (64 * NBW)) + g;        // word index of this lane's slot at step 0 of the batch
-      float vnext = HAS_VAL ? __shfl(v0[0], g) : 0.0f;
+      float vnext = HAS_VAL ? __int_as_float(__builtin_amdgcn_ds_bpermute(g4, __float_as_int(v0[0]))) : 0.0f;
+      // the word of the gather that REPLACES step u's is fetched one step ahead: the cross-lane read then has a whole step
+      // (the row check and the compares) to land instead of being waited for straight away
+      unsigned wnext = fetch(0, w1);
 #pragma unroll
       for (int u = 0; u < U; u++) {
          const float vcur = vnext;
-         if (HAS_VAL && u + 1 < U) vnext = __shfl(v0[((u + 1) * G) / 64], ((u + 1) * G) % 64 + g);
+         const unsigned wcur = wnext;
+         if (HAS_VAL && u + 1 < U)
+            vnext = __int_as_float(__builtin_amdgcn_ds_bpermute(g4 + (int)((((u + 1) * G) % 64) * 4), __float_as_int(v0[((u + 1) * G) / 64])));
+         if (u + 1 < U) wnext = fetch(u + 1, w1);
          if (la[u] != cur) swap_to(la[u]);              // per lane: the slots of a wave change rows at different steps
-         const int widx = widx0 + u * G;
+         const int mark = widx0 + u * G;                 // what a winner of this step is remembered by: its word index
          v2f_t x01 = {__int_as_float(t[u][0]), __int_as_float(t[u][1])};
          v2f_t x23 = {__int_as_float(t[u][2]), __int_as_float(t[u][3])};
          if (HAS_VAL) {                                  // two packed multiplies instead of four
@@ -1058,9 +1079,9 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, 2 * (NVMAX + 1), WGS>(
          for (int v = 0; v < 4; v++) {
             const bool win = OP == OP_MAX ? tt[v] > acc[v] : tt[v] < acc[v];      // NaN never wins, as in the oracle
             acc[v] = win ? tt[v] : acc[v];
-            bi[v] = win ? widx : bi[v];
+            bi[v] = win ? mark : bi[v];
          }
-         issue(u, w1);
+         issue(u, wcur);
       }
 #pragma unroll
       for (int q = 0; q < NBW; q++) { w1[q] = w2[q]; v0[q] = v1[q]; }
@@ -1068,7 +1089,7 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, 2 * (NVMAX + 1), WGS>(
       load_vals((b + 2) * 64 * NBW, v1);
    }
    *reinterpret_cast<float4 *>(lane_base + cur) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-   *reinterpret_cast<int4 *>(lane_base + cur + PLANE) = make_int4(bi[0], bi[1], bi[2], bi[3]);
+   *reinterpret_cast<int4 *>(lane_idx + cur) = make_int4(bi[0], bi[1], bi[2], bi[3]);
    // write-out: the winners' word indices become CSR positions through the plan's permutation
    const int32_t *ids = a.ids + s0 * G;
 #pragma unroll 1
@@ -1078,8 +1099,8 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, 2 * (NVMAX + 1), WGS>(
       if (row < 0 || !cok) continue;
       const int part = a.wave_part[(size_t)w * NVMAX + lrow];
       const float4 t4 = *reinterpret_cast<const float4 *>(lane_base + lrow * PANEL);
-      const int4 i4 = *reinterpret_cast<const int4 *>(lane_base + lrow * PANEL + PLANE);
       float v[4] = {t4.x, t4.y, t4.z, t4.w};
+      const int4 i4 = *reinterpret_cast<const int4 *>(lane_idx + lrow * PANEL);
       int best[4] = {i4.x, i4.y, i4.z, i4.w};
 #pragma unroll
       for (int i = 0; i < 4; i++) best[i] = best[i] == INT_MAX ? INT_MAX : ids[best[i]];
@@ -1350,11 +1371,15 @@ static bool stream_domain_ok(int64_t n, int64_t k, int64_t nnz) {
    return (unsigned long long)n * (unsigned long long)k * 4ull <= (unsigned long long)BUF_LIMIT && nnz < (1LL << 31);
 }
 
-extern "C" int isplib_suggest_stream(int64_t m, int64_t n, int64_t nnz, int64_t k, int *streams, int *slices, int *chunk) {
+extern "C" int isplib_suggest_stream_weighted(int64_t m, int64_t n, int64_t nnz, int64_t k, int weighted, int *streams, int *slices, int *chunk) {
    // When does the stream schedule pay, and with which plan?  Measured on MI355X:
    //   * slots of 8 lanes (32-column panels) up to k = 32, of 16 lanes (64-column panels) up to 64 and from 128 on, of
    //     32 lanes (one 128-column pass) in between -- 64 + 36 columns in two passes cost K=100 3.23 ms, one pass 2.63
    //     (task list 3.17); K=72: 2.92 / 2.30 (2.42); K=96: 2.51 / 2.30 (2.56); K=160 wants 64 + 64 + 32: 3.85 / 4.97 (4.15);
+   //   * WEIGHTED graphs at whole multiples of 128 columns: 128-column slots as well -- a pass reads the plan's weight stream
+   //     (4 bytes per edge, as large as the word stream) once per panel, and half as many panels halve that: round 4, same
+   //     box, alternating: K=128 2.90 -> 2.82 ms (63 slices; 72: 2.87), K=256 5.89 -> 5.74; with unit weights the two
+   //     geometries tie (2.69-2.72 against 2.69-2.70), so those stay on 64-column slots;
    //   * a column slice of ~1.9 MB of the panel (Reddit shape: 32 slices at 64 columns, 16 at 32);
    //   * every generation of waves sweeps the whole dense operand once per XCD, so the rows a generation holds must
    //     reuse each row of it often: edges per generation and XCD >= 3 x rows of y (Reddit shape: 31; one rank's shard
@@ -1365,27 +1390,39 @@ extern "C" int isplib_suggest_stream(int64_t m, int64_t n, int64_t nnz, int64_t 
    clear_error();
    if (m <= 0 || n <= 0 || nnz <= 0 || k < 4 || n >= (1LL << 24) || nnz < (1LL << 22)) return 0;
    if (!stream_domain_ok(n, k, nnz)) return 0;         // what the entry and the plan builder would refuse: not offered
-   const int st = k <= 32 ? 8 : (k <= 64 ? 4 : (k < 128 ? 2 : 4));
+   int st = k <= 32 ? 8 : (k <= 64 ? 4 : (k < 128 ? 2 : 4));
+   if (weighted && k >= 128 && (k % 128) == 0) st = 2;
    int rpw = 0, resident = 0;
    if (isplib_spmm_stream_geometry(st, &rpw, &resident) != ISPLIB_SUCCESS || rpw <= 0 || resident <= 0) return 0;
-   if (!suggest_stream_geom(m, n, nnz, st, rpw, resident, 1.9e6, 3.4, slices, chunk)) return 0;
+   if (!suggest_stream_geom(m, n, nnz, st, rpw, resident, 1.9e6, 3.4, slices, chunk)) {
+      if (st != 2 || k < 128) return 0;
+      st = 4;                                          // (fewer rows per wave on the wide slots: the reuse rule may still accept the narrow ones)
+      if (isplib_spmm_stream_geometry(st, &rpw, &resident) != ISPLIB_SUCCESS || rpw <= 0 || resident <= 0) return 0;
+      if (!suggest_stream_geom(m, n, nnz, st, rpw, resident, 1.9e6, 3.4, slices, chunk)) return 0;
+   }
    if (streams) *streams = st;
    return 1;
 }
 
+extern "C" int isplib_suggest_stream(int64_t m, int64_t n, int64_t nnz, int64_t k, int *streams, int *slices, int *chunk) {
+   return isplib_suggest_stream_weighted(m, n, nnz, k, 0, streams, slices, chunk);      // unit weights
+}
+
 extern "C" int isplib_suggest_stream_minmax(int64_t m, int64_t n, int64_t nnz, int64_t k, int *streams, int *slices, int *chunk) {
    // max / min: 32-column slots up to k = 32, 64-column slots above; the same reuse rule; rows must be column-sorted.
-   // Measured on the Reddit shape (K = 64): slices of ~7.5 MB (8 slices: 1.82 ms, 2.02 with weights; 12: 1.82 / 2.08; 16:
-   // 1.88 / 2.14; 31, the sum kernel's count: 2.2; K = 32 on 32-column slots: 4 slices 0.96, 6: 1.00, 12: 1.08 -- every
-   // change of row costs this kernel a read-compare-write of two LDS planes, and more slices mean more changes) and rows cut at ~0.6 of a stream's share (chunk 2048: 1.82 ms, 1028: 1.92, 4096: 1.96); task list: 2.04 ms
-   // (K=41: 1.80 against 2.05, K=128: 3.58 against 3.98)
+   // Round 4 (the row's pair rides in registers, a change of row is an LDS swap without vector-ALU work), Reddit shape,
+   // K = 64, U(0,1) weights / unit weights, ms: 8 slices 1.97 / 1.73, 12: 1.85 / 1.68, 16: 1.81 / 1.63, 20: 1.82 / 1.61,
+   // 24: 1.84 / 1.63, 31: 1.92 / 1.73, 48: 2.01 / 1.82 -- slices of ~3.3 MB of the panel (rounds 2-3, when every change of
+   // row cost a read-compare-write of both planes: 7.5 MB, 2.04 / 1.82); K = 32 on 32-column slots: 8-16 slices 0.87-0.89,
+   // 24: 0.94.  Rows cut at ~0.85 of a stream's share on 64-column slots (chunk 3000: 1.81, 2057: 1.84, 1028: 1.91), ~0.6
+   // on 32-column ones (2057: 0.873, 3000: 0.890).  Task list: 2.35 / 1.96 (K=128 weighted 3.71 against 4.54).
    clear_error();
    if (m <= 0 || n <= 0 || nnz <= 0 || k < 4 || n >= (1LL << 24) || nnz < (1LL << 22) || nnz >= (1LL << 31)) return 0;
-   if (!stream_domain_ok(n, k, nnz)) return 0;
+   if (!stream_domain_ok(n, k, nnz) || (unsigned long long)n * (unsigned long long)k * 4ull >= (1ull << 31)) return 0;   // the max / min entry: under 2 GiB
    const int st = k <= 32 ? 8 : 4;
    int rpw = 0, resident = 0;
    if (isplib_spmm_stream_minmax_geometry(st, &rpw, &resident) != ISPLIB_SUCCESS || rpw <= 0 || resident <= 0) return 0;
-   if (!suggest_stream_geom(m, n, nnz, st, rpw, resident, 7.5e6, 1.7, slices, chunk)) return 0;
+   if (!suggest_stream_geom(m, n, nnz, st, rpw, resident, 3.3e6, st == 8 ? 1.7 : 1.17, slices, chunk)) return 0;
    if (streams) *streams = st;
    return 1;
 }
@@ -1420,6 +1457,8 @@ static int stream_run(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t
    if (mm && plan->n_steps > 0 && !plan->perm) return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: max / min need the plan's perm array (the winners' CSR positions)");
    if (mm && nnz >= (1LL << 31)) return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: max / min need nnz < 2^31");
    if (mm && ep) return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: the epilogue is defined for sum / mean only");
+   if (mm && (unsigned long long)n * (unsigned long long)ldy * 4ull >= (1ull << 31))
+      return fail(ISPLIB_FAIL, "fusedMM_csr_stream_minmax_hip: dense operand of 2 GiB or more (use fusedMM_csr_tasks_hip)");
    if (k < 4) return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: k >= 4 required (use fusedMM_csr_hip)");
    if (ldy < k || ldz < k) return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: leading dimension smaller than k");
    const unsigned long long yb = (unsigned long long)n * (unsigned long long)ldy * 4ull;

@@ -399,7 +399,7 @@ static int stream_plan_build(int64_t m, int64_t n, int64_t nnz, const int64_t *r
 #undef SP_TRY
 #undef SP_LAUNCHED
    out->rows = m; out->cols = n; out->slices = slices; out->gens = (int32_t)gens; out->waves_per_gen = waves_per_gen;
-   out->rows_per_wave = rpw; out->streams = streams; out->reserved = chunk;
+   out->rows_per_wave = rpw; out->streams = streams; out->chunk = chunk;
    out->n_steps = n_steps; out->n_parts = n_parts; out->n_hub = n_hub;
    return ISPLIB_SUCCESS;
 }
@@ -410,7 +410,7 @@ extern "C" int isplib_stream_plan_build_hip(int64_t m, int64_t n, int64_t nnz, c
    clear_error();
    int rpw = 0, resident = 0;
    if (isplib_spmm_stream_geometry(streams, &rpw, &resident) != ISPLIB_SUCCESS) return ISPLIB_FAIL;
-   return stream_plan_build(m, n, nnz, rowptr, col, val, streams, rpw, resident, slices, chunk, waves_per_gen, out, stream, /* pad_row = the spare row */ rpw);
+   return stream_plan_build(m, n, nnz, rowptr, col, val, streams, rpw, resident, slices, chunk, waves_per_gen, out, stream);
 }
 
 // 1 if some row's columns do not ascend (duplicates are fine)

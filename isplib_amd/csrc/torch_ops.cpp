@@ -114,7 +114,7 @@ static inline const int32_t *plan_col32(const Plan &p, const Tensor &col) {
 static isplib_stream_plan stream_plan_of(const Plan &plan) {
    const Tensor &words = plan[0], &vals = plan[1], &step_off = plan[2], &wave_row = plan[3], &wave_part = plan[4],
                 &hub_row = plan[5], &hub_off = plan[6], &meta = plan[7];
-   TORCH_CHECK(!meta.is_cuda() && meta.scalar_type() == at::kLong && meta.numel() == 10, "isplib: stream plan meta must be 10 host int64");
+   TORCH_CHECK(!meta.is_cuda() && meta.scalar_type() == at::kLong && meta.numel() == 11, "isplib: stream plan meta must be 11 host int64");
    TORCH_CHECK(words.is_cuda() && words.scalar_type() == at::kInt && step_off.scalar_type() == at::kLong &&
                    wave_row.scalar_type() == at::kInt && wave_part.scalar_type() == at::kInt &&
                    hub_row.scalar_type() == at::kInt && hub_off.scalar_type() == at::kInt &&
@@ -123,7 +123,7 @@ static isplib_stream_plan stream_plan_of(const Plan &plan) {
    const int64_t *mt = meta.data_ptr<int64_t>();
    isplib_stream_plan sp;
    sp.rows = mt[0]; sp.cols = mt[1]; sp.slices = (int32_t)mt[2]; sp.gens = (int32_t)mt[3]; sp.waves_per_gen = (int32_t)mt[4];
-   sp.rows_per_wave = (int32_t)mt[5]; sp.streams = (int32_t)mt[6]; sp.reserved = 0; sp.n_steps = mt[7]; sp.n_parts = mt[8]; sp.n_hub = mt[9];
+   sp.rows_per_wave = (int32_t)mt[5]; sp.streams = (int32_t)mt[6]; sp.n_steps = mt[7]; sp.n_parts = mt[8]; sp.n_hub = mt[9]; sp.chunk = (int32_t)mt[10];
    TORCH_CHECK(words.numel() == sp.n_steps * sp.streams && step_off.numel() == (int64_t)sp.gens * sp.waves_per_gen + 1 &&
                    wave_row.numel() == (int64_t)sp.gens * sp.waves_per_gen * sp.rows_per_wave && wave_part.numel() == wave_row.numel() &&
                    hub_row.numel() == sp.n_hub && hub_off.numel() == sp.n_hub + 1,
@@ -276,21 +276,36 @@ std::tuple<Tensor, Tensor> spmm_fw(const Tensor &rowptr_, const Tensor &col_, co
    const bool tasks_fit = K >= 4 && (double)N * (double)K * 4.0 <= 3.5 * 1073741824.0;
    // (a stream plan for a shape outside the stream entry's domain -- dense operand over 3.5 GiB, k < 4 -- is not an error:
    // the graph is served by the kernels below, which read `col` / `value`)
-   if (is_stream_plan(plan) && M > 0 && K >= 4 && (double)N * (double)K * 4.0 <= 3.5 * 1073741824.0) {
+   const bool minmax_op = reduction == R_MAX || reduction == R_MIN;      // (the max / min stream entry serves dense operands under 2 GiB)
+   if (is_stream_plan(plan) && M > 0 && K >= 4 && (double)N * (double)K * 4.0 <= 3.5 * 1073741824.0 &&
+       !(minmax_op && (double)N * (double)K * 4.0 >= 2.0 * 1073741824.0)) {
       // the plan carries the edges (and the weights) in its own order: `col` / `value` are not read
       const isplib_stream_plan sp = stream_plan_of(plan);
+      // A line-friendly pitch for 33..47 columns (the GCN's 41 classes): what the address pipeline charges for is the
+      // 128-byte line a gather touches, and a 164-byte row at its packed pitch straddles 2.25 of them on average, at a
+      // 192-byte pitch exactly 2 -- Reddit shape K=41: 1.365 -> 1.285 ms, the copy 0.015 (scripts/exp_round4.py k41;
+      // 176 B: no gain, 256 B: 1.314).  Only the gathered operand is copied; the output stays packed.
+      const float *y = mat.data_ptr<float>();
+      int64_t ldy = K;
+      Tensor pitched;
+      if (K > 32 && K < 48 && N >= (1 << 16) && (double)N * 48.0 * 4.0 < 2.0 * 1073741824.0) {
+         pitched = at::empty({N, 48}, mat.options());
+         pitched.narrow(1, 0, K).copy_(mat);
+         y = pitched.data_ptr<float>();
+         ldy = 48;
+      }
       if (reduction == R_MAX || reduction == R_MIN) {
          TORCH_CHECK(sp.perm != nullptr, "isplib: max / min on a stream plan need its permutation (a 9-element plan)");
          const size_t ws = isplib_spmm_stream_minmax_workspace_bytes(&sp);
          Tensor work = at::empty({(int64_t)ws}, mat.options().dtype(at::kByte));
-         const int st = fusedMM_csr_stream_minmax_hip(msg, M, N, K, nnz, rp, rp + 1, &sp, mat.data_ptr<float>(), K, out.data_ptr<float>(), K,
+         const int st = fusedMM_csr_stream_minmax_hip(msg, M, N, K, nnz, rp, rp + 1, &sp, y, ldy, out.data_ptr<float>(), K,
                                                       arg.data_ptr<int64_t>(), work.data_ptr(), ws, current_stream(mat));
          check_status(st, "fusedMM_csr_stream_minmax_hip");
          return std::make_tuple(out, arg);
       }
       const size_t ws = isplib_spmm_stream_workspace_bytes(&sp);
       Tensor work = at::empty({(int64_t)ws}, mat.options().dtype(at::kByte));
-      const int st = fusedMM_csr_stream_hip(msg, M, N, K, nnz, rp, rp + 1, &sp, mat.data_ptr<float>(), K, out.data_ptr<float>(), K,
+      const int st = fusedMM_csr_stream_hip(msg, M, N, K, nnz, rp, rp + 1, &sp, y, ldy, out.data_ptr<float>(), K,
                                             work.data_ptr(), ws, nullptr, current_stream(mat));
       check_status(st, "fusedMM_csr_stream_hip");
       return std::make_tuple(out, arg);

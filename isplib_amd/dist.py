@@ -277,7 +277,7 @@ class RowPartition:
             if reduce not in ("sum", "mean"):
                 return None
             # stream may also be the plan parameters themselves, (streams, slices, chunk): tests, experiments
-            geom = tuple(stream) if isinstance(stream, (tuple, list)) else cabi.suggest_stream(self.rows, self.ncols_padded, self.nnz, w)
+            geom = tuple(stream) if isinstance(stream, (tuple, list)) else cabi.suggest_stream(self.rows, self.ncols_padded, self.nnz, w, self.val is not None)
             if geom is None:
                 return None
             plans = self.__dict__.setdefault("_stream_plans", {})
@@ -396,7 +396,7 @@ def _spmm_auto(self, x_local: torch.Tensor) -> torch.Tensor:
             # one all-gather, then the single-GPU rule on this rank's shard: stream schedule where isplib_suggest_stream
             # accepts it, else the task list, else the plain kernel (the collective is the same in all three: ranks
             # may decide differently)
-            geom = None if os.environ.get("ISPLIB_STREAM") == "0" else cabi.suggest_stream(self.rows, self.ncols_padded, self.nnz, k)
+            geom = None if os.environ.get("ISPLIB_STREAM") == "0" else cabi.suggest_stream(self.rows, self.ncols_padded, self.nnz, k, self.val is not None)
             if geom is not None:
                 from .plan import build_stream_plan
                 sp = build_stream_plan(self.rowptr, self.col_padded, self.val, self.ncols_padded, geom[1], None, None, geom[0], geom[2])

@@ -238,7 +238,7 @@ class StreamPlan:
     def struct(self) -> "cabi.StreamPlanStruct":
         p = lambda t: t.data_ptr() if t is not None and t.numel() else None  # noqa: E731
         return cabi.StreamPlanStruct(self.rows, self.cols, self.slices, self.gens, self.waves_per_gen, self.rows_per_wave,
-                                     self.streams, 0, self.n_steps, self.n_parts, self.n_hub, p(self.words), p(self.vals),
+                                     self.streams, int(self.chunk), self.n_steps, self.n_parts, self.n_hub, p(self.words), p(self.vals),
                                      p(self.wave_step_off), p(self.wave_row), p(self.wave_part), p(self.hub_row), p(self.hub_off),
                                      p(self.perm) if self.perm.dtype == torch.int32 else None)
 

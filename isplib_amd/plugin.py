@@ -181,8 +181,9 @@ def choose_slices(storage: SparseStorage, rows: int, k: int, minmax: bool = Fals
     return s
 
 
-def choose_stream(storage: SparseStorage, m: int, n: int, k: int):
-    """(streams, slices, chunk) when sum / mean of this shape should run on the stream schedule, else None.
+def choose_stream(storage: SparseStorage, m: int, n: int, k: int, weighted: bool = False):
+    """(streams, slices, chunk) when sum / mean of this shape should run on the stream schedule, else None; `weighted`:
+    the plan will carry edge weights (the rule then prefers wider column panels: the weight stream is read once per panel).
     ISPLIB_STREAM=0 disables it, ISPLIB_SLICES (the task list's override) disables it too: explicit schedules win."""
     if os.environ.get("ISPLIB_STREAM", "1") == "0" or os.environ.get("ISPLIB_SLICES") is not None:
         return None
@@ -192,7 +193,7 @@ def choose_stream(storage: SparseStorage, m: int, n: int, k: int):
     if forced:
         return tuple(int(v) for v in forced.split(":"))
     from . import cabi
-    geom = cabi.suggest_stream(m, n, storage._col.numel(), k)
+    geom = cabi.suggest_stream(m, n, storage._col.numel(), k, weighted)
     return None if geom is None else (geom[0], skew_adjusted(storage, geom[1], cap=512), geom[2])
 
 
@@ -232,7 +233,7 @@ def spmm_autotuned(src, other: torch.Tensor, reduce: str = "sum") -> torch.Tenso
     # sum / mean on graphs with work for the whole chip: the stream schedule (rows resident in LDS, the plan's own copy
     # of the edges; include/isplib_hip.h: fusedMM_csr_stream_hip) -- measured 15-18 % ahead of the task list
     if reduce in ("sum", "add", "mean"):
-        geom = choose_stream(s, m_rows, mat.size(0), k)
+        geom = choose_stream(s, m_rows, mat.size(0), k, s._value is not None)
         plan = s.stream_plan(False, geom) if geom is not None else None
     else:                                                            # max / min: its own kernel geometry, sorted rows only
         geom = choose_stream_minmax(s, m_rows, mat.size(0), k)
@@ -251,7 +252,7 @@ def spmm_autotuned(src, other: torch.Tensor, reduce: str = "sum") -> torch.Tenso
             # 1 / deg of the edge's row in A, which the operator applies to the rows of dY instead: no weights at all
             unit_mean = reduce == "mean" and s._value is None
             val_t = None if unit_mean else (s.mean_val_t() if reduce == "mean" else s.val_t())
-            geom_t = choose_stream(s, mat.size(0), m_rows, k)
+            geom_t = choose_stream(s, mat.size(0), m_rows, k, val_t is not None)
             plan_t = s.stream_plan(True, geom_t, "mean" if reduce == "mean" and not unit_mean else "sum") if geom_t is not None else None
             if plan_t is None:
                 plan_t = s.plan_t(choose_slices(s, m_rows, k, transposed=True))

@@ -185,7 +185,7 @@ class SparseStorage:
             self._streams[key] = plan
             if plan is not None:
                 plan.meta = torch.tensor([plan.rows, plan.cols, plan.slices, plan.gens, plan.waves_per_gen, plan.rows_per_wave,
-                                          plan.streams, plan.n_steps, plan.n_parts, plan.n_hub], dtype=torch.int64)
+                                          plan.streams, plan.n_steps, plan.n_parts, plan.n_hub, plan.chunk], dtype=torch.int64)
         if plan is None:
             return None
         vals = torch.empty(0, dtype=torch.float32, device=plan.words.device)

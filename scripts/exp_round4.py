@@ -33,7 +33,7 @@ def timeit(fn, it=10, warm=3):
 
 if "mm" in what:
     col32 = cabi.pack_indices(col)
-    for k, weighted in ((64, True), (64, False), (128, True), (32, False), (41, False)):
+    for k, weighted in [(int(v.split(":")[0]), v.endswith("w")) for v in os.environ.get("MM_CASES", "64:w,64:u,128:w,32:u,41:u").split(",")]:
         val = w if weighted else None
         x = synth.features(n, k, device=dev, integer=False)
         z = torch.empty((n, k), device=dev)
@@ -89,22 +89,22 @@ if "sddmm" in what:
         del x, g, ref, mag
 
 if "w128" in what:
-    k = 128
-    x = synth.features(n, k, device=dev)
-    z = torch.empty((n, k), device=dev)
     msg = cabi.MESSAGE["sum"]
-    st, sl, ch = cabi.suggest_stream(n, n, nnz, k)
-    plans = {f"rule {st}:{sl}:{ch}": build_stream_plan(rowptr, col, w, n, sl, None, None, st, ch)}
-    for s2 in (63, 72):
-        plans[f"2:{s2}:{ch}"] = build_stream_plan(rowptr, col, w, n, s2, None, None, 2, ch)
-    wss = {name: p.workspace() for name, p in plans.items()}
-    for rnd in range(4):
-        line = []
-        for name, p in plans.items():
-            ms = timeit(lambda: cabi.fusedMM_csr_stream_hip(msg, rowptr, nnz, p, x, z, wss[name]), 20, 3)
-            line.append(f"{name} {ms:.3f}")
-        print(f"[w128] weighted sum K=128, round {rnd}: " + " | ".join(line), flush=True)
-    del plans, wss, x, z
+    for k in (128, 256):
+        x = synth.features(n, k, device=dev)
+        z = torch.empty((n, k), device=dev)
+        st, sl, ch = cabi.suggest_stream(n, n, nnz, k)
+        plans = {f"rule {st}:{sl}:{ch}": build_stream_plan(rowptr, col, w, n, sl, None, None, st, ch)}
+        for s2 in (63, 72):
+            plans[f"2:{s2}:{ch}"] = build_stream_plan(rowptr, col, w, n, s2, None, None, 2, ch)
+        wss = {name: p.workspace() for name, p in plans.items()}
+        for rnd in range(3):
+            line = []
+            for name, p in plans.items():
+                ms = timeit(lambda: cabi.fusedMM_csr_stream_hip(msg, rowptr, nnz, p, x, z, wss[name]), 20, 3)
+                line.append(f"{name} {ms:.3f}")
+            print(f"[w128] weighted sum K={k}, round {rnd}: " + " | ".join(line), flush=True)
+        del plans, wss, x, z
 
 if "k41" in what:
     k = 41

@@ -135,6 +135,35 @@ def test_sddmm_over_task_plan(gpu, oracle_mod, k):
             assert np.max(np.abs(got.cpu().numpy() - ref)) <= 2e-6 * scale * max(1, k / 16)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", (128, 136, 129, 256, 67))
+def test_sddmm_over_task_plan_in_column_panels(gpu, oracle_mod, k):
+    """isplib_hip_tune(12, 64): the task-list SDDMM in 64-column panels -- panel c adds its share of every dot product to
+    what panels 0..c-1 stored (a tail under 4 columns joins the panel before it; rows that are not whole cache lines keep
+    the whole-row form).  Against the oracle, on integer operands exactly, and bitwise reproducible."""
+    from isplib_amd import cabi
+    from isplib_amd.plan import build_task_plan
+    rowptr, col = cases.random_csr(300, 900, 30.0, seed=k, empty_rows=(0, 299), hub=(9, 5000))
+    x, g = cases.dense(900, k, 3), cases.dense(300, k, 5)
+    xi, gi = np.round(x * 4).astype(np.float32), np.round(g * 4).astype(np.float32)
+    d = [_t(a_, gpu) for a_ in (rowptr, col, x, g, xi, gi)]
+    plan = build_task_plan(d[0], d[1], 900, 6, 256, 32)
+    L = cabi.lib()
+    try:
+        for cols in (64, 128):
+            assert L.isplib_hip_tune(12, cols) == 0
+            for mean in (False, True):
+                got = cabi.sddmm_tasks(d[0], d[1], plan, d[2], d[3], mean)
+                ref = oracle_mod.sddmm(rowptr, col, x, g, mean=mean)
+                scale = np.abs(ref).max() + 1e-6
+                assert np.max(np.abs(got.cpu().numpy() - ref)) <= 2e-6 * scale * max(1, k / 16), (cols, mean)
+                assert torch.equal(got, cabi.sddmm_tasks(d[0], d[1], plan, d[2], d[3], mean)), "bitwise reproducible"
+            got = cabi.sddmm_tasks(d[0], d[1], plan, d[4], d[5], False)             # small integers: every order of summation is exact
+            assert np.array_equal(got.cpu().numpy(), oracle_mod.sddmm(rowptr, col, xi, gi, mean=False)), cols
+    finally:
+        L.isplib_hip_tune(12, 0)
+
+
 def test_value_gradient_through_planned_ops(gpu, oracle_mod, monkeypatch):
     import isplib_amd
     monkeypatch.setenv("ISPLIB_SLICES", "8")

@@ -368,6 +368,17 @@ def test_ordered_plain_kernel_is_bitwise_the_plain_kernel(gpu, oracle_mod, k):
             assert torch.equal(got, want) and (want_arg is None or torch.equal(got_arg, want_arg)), red
         colptr, _, row_t, val_t = cabi.csr2csc(rowptr2, col2, val, n, want_perm=False)
         assert torch.equal(h.spmm_backward(x, mean=False), cabi.spmm(colptr, row_t, val_t, x, "sum")[0])
+        # an order that is not a permutation of the rows is refused (checked once, on the device) and changes nothing
+        bad_range, twice = shuffled.clone(), shuffled.clone()
+        bad_range[3] = n
+        twice[5] = twice[6]
+        for bad in (bad_range, twice):
+            with pytest.raises(cabi.IsplibError, match="order"):
+                h.set_row_order(bad, None)
+            with pytest.raises(cabi.IsplibError, match="order"):
+                h.set_row_order(shuffled, bad)
+        got, _ = h.spmm(x, "sum")
+        assert torch.equal(got, cabi.spmm(rowptr2, col2, val, x, "sum")[0])
     finally:
         h.close()
     ref, _ = oracle_mod.spmm_fw(rowptr2.cpu().numpy(), col2.cpu().numpy(), val.cpu().numpy(), x.cpu().numpy(), "max")

@@ -285,6 +285,56 @@ def test_native_stream_plan_equals_the_torch_built_one(gpu, oracle_mod, geom):
         nat.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("streams", (4, 8))
+def test_minmax_plans_pad_with_the_spare_row_in_both_builders(gpu, streams):
+    """Plans of the max / min kernel: padding words carry the local row `rows_per_wave` -- the kernel's spare LDS row, so its
+    loop needs no test for padding -- from the torch builder and the native one alike (identical arrays); sum / mean plans
+    keep the first row of the word's own stream."""
+    from isplib_amd import cabi
+    from isplib_amd.plan import build_stream_plan
+    rowptr, col = cases.random_csr(600, 500, 30.0, seed=5, empty_rows=(0, 300), hub=(7, 3000))
+    d_rowptr, d_col = _t(rowptr, gpu), _t(col, gpu)
+    ref = build_stream_plan(d_rowptr, d_col, None, 500, 5, 6, None, streams, 200, minmax=True)
+    nat = cabi.NativeStreamPlan(d_rowptr, d_col, None, 500, streams, 5, 200, 6, minmax=True)
+    try:
+        rpw = cabi.stream_minmax_geometry(streams)[0]
+        assert ref.rows_per_wave == rpw == nat.rows_per_wave
+        for name in ("words", "perm", "wave_step_off", "wave_row", "wave_part", "hub_row", "hub_off"):
+            assert torch.equal(nat.array(name).to(getattr(ref, name).dtype), getattr(ref, name)), name
+        words, perm = ref.words.cpu().numpy().view(np.uint32), ref.perm.cpu().numpy()
+        pad = perm < 0
+        assert pad.any() and np.all(words[pad] == ((rpw << 24) | 500)) and np.all((words[~pad] >> 24) < rpw)
+        plain = build_stream_plan(d_rowptr, d_col, None, 500, 5, 6, None, streams, 200)
+        w2, p2 = plain.words.cpu().numpy().view(np.uint32), plain.perm.cpu().numpy()
+        per = plain.rows_per_wave // streams
+        assert np.all((w2[p2 < 0] >> 24) == (np.flatnonzero(p2 < 0) % streams) * per)
+    finally:
+        nat.close()
+
+
+@pytest.mark.gpu
+def test_native_plan_arrays_live_as_long_as_a_tensor_looks_at_them(gpu):
+    """The plug-in's stream plans are zero-copy views of arrays the C library owns (plan.build_stream_plan_native), and
+    autograd saves those tensors for backward: the owner must stay alive for as long as ANY such tensor does -- a graph
+    object built inside forward() and dropped before backward() must not take the arrays with it."""
+    import gc
+    import weakref
+    from isplib_amd.plan import build_stream_plan_native
+    rowptr, col = cases.random_csr(300, 300, 20.0, seed=9)
+    plan = build_stream_plan_native(_t(rowptr, gpu), _t(col, gpu), 300, 4, 4, 256)
+    owner = weakref.ref(plan._native)
+    words, copy = plan.words, plan.words.clone()
+    saved = [words.view(-1)[: words.numel()]]           # what ctx.saved_data holds: another tensor on the same storage
+    del plan, words
+    gc.collect()
+    assert owner() is not None, "the library's arrays were freed while a tensor still looks at them"
+    assert torch.equal(saved[0], copy)
+    del saved
+    gc.collect()
+    assert owner() is None, "nothing looks at the arrays any more: the owner goes, and frees them"
+
+
 # ---- max / min on the stream schedule (fusedMM_csr_stream_minmax_hip): (value, CSR position) pairs --------------------
 
 def _stream_minmax_all(gpu, oracle, rowptr, col, val, x, unit=False, geoms=((4, 8, 16, 64), (8, 5, 6, 2048), (4, 3, 3, 300), (8, 2, 4, 100)),
