@@ -906,8 +906,10 @@ def main():
     if a.only and not multi:
         # one configuration of the `extra` array on its own (what scripts/prof_pmc.sh and rocprofv3 --kernel-trace are
         # pointed at to fill profiles/traffic.json and the per-configuration kernel statistics)
-        from isplib_amd import synth as _synth
+        from isplib_amd import cabi as _cabi, synth as _synth
         os.environ["ISPLIB_BENCH_ONLY"] = a.only
+        for kv in filter(None, a.tune.split(",")):
+            _cabi.lib().isplib_hip_tune(int(kv.split("=")[0]), int(kv.split("=")[1]))
         if a.only.startswith("products"):
             extra = products_configs(dev, a.only)
         else:

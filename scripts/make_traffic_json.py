@@ -1,4 +1,4 @@
-"""profiles/traffic.json entries of round 3 from the PMC summaries of scripts/prof_round3.sh (scripts/pmc_summary.py output):
+"""profiles/traffic.json entries of round 4 from the PMC summaries of scripts/prof_round4.sh (scripts/pmc_summary.py output):
 fabric-side bytes per launch = sum over the launch's kernels of dispatches x (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (FETCH_SIZE
 counts 128-byte requests at 64 bytes on gfx950: the guide's correction), TCC hit rate, TA busy share.
 usage: make_traffic_json.py <prof dir> <profiles dir>"""
@@ -23,17 +23,19 @@ def summary(path):
     return out
 
 
-# key -> (kernels of one launch: name fragment -> dispatches per launch)
+# key -> (summary file stem, kernels of one launch: name fragment -> dispatches per launch), round 4
 launch = {
-    "reddit-sum-k128-stream31": ("pmc_bench", {"spmm_stream_kernel<16, false": 4, "sweep_hub_fold_kernel<0": 2}),
+    "reddit-sum-k128-stream31-r04": ("pmc_bench", {"spmm_stream_kernel<16, false": 4, "sweep_hub_fold_kernel<0": 2}),
     "reddit-max-k64-weighted": ("pmc_reddit-max-k64-weighted", {"spmm_stream_minmax_kernel<1, 16, true": 4, "sweep_hub_fold_kernel<1": 1}),
-    "reddit-sum-k128-weighted": ("pmc_reddit-sum-k128-weighted", {"spmm_stream_kernel<16, true": 4, "sweep_hub_fold_kernel<0": 2}),
+    "reddit-min-k64-weighted": ("pmc_reddit-min-k64-weighted", {"spmm_stream_minmax_kernel<2, 16, true": 4, "sweep_hub_fold_kernel<2": 1}),
+    "reddit-mean-k64-weighted": ("pmc_reddit-mean-k64-weighted", {"spmm_stream_kernel<16, true": 2, "sweep_hub_fold_kernel<0": 1}),
+    "reddit-sum-k128-weighted": ("pmc_reddit-sum-k128-weighted", {"spmm_stream_kernel<32, true": 4, "sweep_hub_fold_kernel<0": 1}),
+    "reddit-sum-k32-unit": ("pmc_reddit-sum-k32-unit", {"spmm_stream_kernel<8, false": 1, "sweep_hub_fold_kernel<0": 1}),
+    "reddit-sum-k41-unit": ("pmc_reddit-sum-k41-unit", {"spmm_stream_kernel<16, false": 2, "sweep_hub_fold_kernel<0": 1}),
     "reddit-sddmm-k128": ("pmc_reddit-sddmm-k128", {"sddmm_task_kernel": 1}),
-    "products-chunglu-sum-k256-plain": ("pmc_products-chunglu-sum-k256-plain", {"spmm_csr_kernel": 1}),
-    "products-sbm-sum-k256-plain": ("pmc_products-sbm-sum-k256-plain", {"spmm_csr_kernel": 1}),
-    "products-sbm-sum-k256-ordered": ("pmc_products-sbm-sum-k256-ordered", {"spmm_csr_kernel": 1}),
-    "reddit-sum-k128-hybrid31": ("pmc_hybrid", {"spmm_hybrid_kernel": 4, "sweep_hub_fold_kernel<0": 2}),
+    "reddit-sddmm-k128-panels64": ("pmc_reddit-sddmm-k128-panels64", {"sddmm_task_kernel<16, 1, 4, false": 1, "sddmm_task_kernel<16, 1, 4, true": 1}),
 }
+ROUND = os.environ.get("PROF_ROUND", "r04")
 tpath = os.path.join(dest, "traffic.json")
 table = json.load(open(tpath))
 for key, (name, kernels) in launch.items():
@@ -61,9 +63,9 @@ for key, (name, kernels) in launch.items():
             rec_out["tcc_requests_128B_per_dispatch"] = main["TCC_REQ_sum"]
         if main.get("GRBM_GUI_ACTIVE"):
             rec_out["grbm_ta_busy_over_gui_active"] = main["GRBM_TA_BUSY"] / main["GRBM_GUI_ACTIVE"]
-    rec_out["source"] = f"profiles/r03_{name}_summary.txt (scripts/prof_round3.sh: one rocprofv3 --pmc group per pass; FETCH_SIZE doubled for gfx950); bytes leaving the XCD L2s, Infinity-Cache hits included"
-    if key == "reddit-sum-k128-stream31":
-        key = "reddit-sum-k128-stream31-r03"
+    rec_out["source"] = f"profiles/{ROUND}_{name}_summary.txt (scripts/prof_round4.sh: one rocprofv3 --pmc group per pass; FETCH_SIZE doubled for gfx950); bytes leaving the XCD L2s, Infinity-Cache hits included"
+    if key == "reddit-sum-k128-stream31-r04":
+        table["reddit-sum-k128-stream31"] = rec_out          # what bench.py's headline line looks up
     table[key] = rec_out
     print(key, f"{total / 1e9:.2f} GB", rec_out.get("tcc_hit_rate"))
 json.dump(table, open(tpath, "w"), indent=1)
