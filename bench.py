@@ -882,12 +882,14 @@ def main():
     if world > 1 or os.environ.get("ISPLIB_BENCH_FORCE_DIST") == "1":
         guard = Guard(rank, world)
         guard.arm("start-up, graph, plans and the north_star form (one all-gather + local SpMM)", _env_seconds("ISPLIB_BENCH_T_SAFE", 300))
-    t_candidate = _env_seconds("ISPLIB_BENCH_T_CANDIDATE", 45)      # one optional exchange schedule: validation + timing
+    t_candidate = _env_seconds("ISPLIB_BENCH_T_CANDIDATE", 60)      # one optional exchange schedule: validation + timing
     t_total = _env_seconds("ISPLIB_BENCH_DEADLINE", 420)            # everything, seconds since this rank started
 
+    verbose = os.environ.get("ISPLIB_BENCH_VERBOSE") == "1"          # progress notes from every rank, not just rank 0
+
     def note(msg):
-        if world > 1 and rank == 0:
-            print(f"[bench] {time.strftime('%H:%M:%S')} {msg}", file=sys.stderr, flush=True)
+        if world > 1 and (rank == 0 or verbose):
+            print(f"[bench] {time.strftime('%H:%M:%S')}" + (f" rank {rank}" if verbose else "") + f" {msg}", file=sys.stderr, flush=True)
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or drop WORLD_SIZE and let bench.py start them)")
     # ISPLIB_BENCH_FORCE_DIST=1 under `torch.distributed.run --nproc-per-node 1` walks the N > 1 code (RCCL init,
@@ -999,7 +1001,12 @@ def main():
             from isplib_amd.plugin import skew_adjusted as _skew
             geom = (geom[0], _skew(l_rowptr, geom[1], cap=512), geom[2])
         if geom is not None:
-            splan = build_stream_plan(l_rowptr, l_col, l_val, x_in.size(0), geom[1], None, None, geom[0], geom[2])
+            # the library's own builder (rocPRIM sorts; identical arrays to plan.py's torch construction: tests) -- what the
+            # plug-in and the C handle use
+            from isplib_amd.plan import build_stream_plan_native
+            splan = build_stream_plan_native(l_rowptr, l_col, x_in.size(0), geom[1], geom[0], geom[2])
+            if splan is not None and l_val is not None:
+                splan.set_values(l_val)
             swork = None if splan is None else splan.workspace()
         if splan is None and a.schedule == "stream":
             raise SystemExit("--schedule stream: the stream schedule does not apply to this shape (isplib_suggest_stream)")
@@ -1348,6 +1355,8 @@ def main():
                     if k // panels < 16:
                         continue
                     state = None
+                    guard.arm(f"plan of 'pipelined x{panels}'", t_candidate)
+                    note(f"building the plan of 'pipelined x{panels}'")
                     try:
                         state = part.pipeline_state(k, panels, a.reduce)        # own plan: slice count for the panel width
                     except Exception as e:  # noqa: BLE001
@@ -1361,6 +1370,8 @@ def main():
                     if k // panels < 32:
                         continue
                     state = None
+                    guard.arm(f"plan of 'pipelined stream x{panels}'", t_candidate)
+                    note(f"building the plan of 'pipelined stream x{panels}'")
                     try:
                         state = part.pipeline_state(k, panels, a.reduce, stream=True)
                     except Exception as e:  # noqa: BLE001

@@ -261,6 +261,16 @@ class RowPartition:
             self._col32 = cabi.pack_indices(self.col_padded)
         return build_task_plan(self.rowptr, self.col_padded, self.ncols_padded, slices, chunk, short_row, col32=self._col32)
 
+    def _stream_plan(self, geom):
+        """Stream plan of this rank's rows over the padded gather layout, geom = (streams, slices, chunk): the library's own
+        builder (rocPRIM sorts, ~10 ms at Reddit size; no torch kernel has to be loaded for it), weights gathered through
+        the plan's permutation.  None where the builder declines."""
+        from .plan import build_stream_plan_native
+        plan = build_stream_plan_native(self.rowptr, self.col_padded, self.ncols_padded, geom[1], geom[0], geom[2])
+        if plan is not None and self.val is not None:
+            plan.set_values(self.val)
+        return plan
+
     def pipeline_state(self, k: int, panels: int, reduce: str = "sum", tplan=None, stream: bool = False):
         """Operands of `spmm_pipelined` for width k: panel bounds (multiples of 4 columns), one send and one
         gather buffer per panel, a task plan whose slice count suits the PANEL width (built here unless given;
@@ -273,7 +283,6 @@ class RowPartition:
         w = ((k + panels - 1) // panels + 3) // 4 * 4
         if stream:
             from . import cabi
-            from .plan import build_stream_plan
             if reduce not in ("sum", "mean"):
                 return None
             # stream may also be the plan parameters themselves, (streams, slices, chunk): tests, experiments
@@ -282,8 +291,7 @@ class RowPartition:
                 return None
             plans = self.__dict__.setdefault("_stream_plans", {})
             if geom not in plans:
-                plans[geom] = build_stream_plan(self.rowptr, self.col_padded, self.val, self.ncols_padded, geom[1], None, None,
-                                                geom[0], geom[2])
+                plans[geom] = self._stream_plan(geom)
             tplan = plans[geom]
             if tplan is None:
                 return None
@@ -398,8 +406,7 @@ def _spmm_auto(self, x_local: torch.Tensor) -> torch.Tensor:
             # may decide differently)
             geom = None if os.environ.get("ISPLIB_STREAM") == "0" else cabi.suggest_stream(self.rows, self.ncols_padded, self.nnz, k, self.val is not None)
             if geom is not None:
-                from .plan import build_stream_plan
-                sp = build_stream_plan(self.rowptr, self.col_padded, self.val, self.ncols_padded, geom[1], None, None, geom[0], geom[2])
+                sp = self._stream_plan(geom)
                 ops = None if sp is None else (sp, sp.workspace())
             if ops is None and s > 0:
                 plans = self.__dict__.setdefault("_task_plans", {})

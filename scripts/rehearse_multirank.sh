@@ -16,7 +16,7 @@ common=(--gpus "$ranks" --scale 0.25 --steps 5 --warmup 2 --no-extra)
 run() {   # run <name> <env assignments...>
    local name="$1"; shift
    local t0=$SECONDS
-   env "$@" timeout -k 10 400 python3 "$root/bench.py" "${common[@]}" > "$root/$out/rehearsal_$name.json" 2> "$root/$out/rehearsal_$name.log"
+   env "$@" timeout -k 10 600 python3 "$root/bench.py" "${common[@]}" > "$root/$out/rehearsal_$name.json" 2> "$root/$out/rehearsal_$name.log"
    local rc=$?
    echo "== $name: exit $rc after $((SECONDS - t0)) s, $(grep -c '"metric"' "$root/$out/rehearsal_$name.json") JSON line(s)" | tee -a "$root/$out/rehearsal_summary.txt"
    grep -E "dropped|abandoned|deadline|-> |north_star|out of step|raised" "$root/$out/rehearsal_$name.log" | head -12 | tee -a "$root/$out/rehearsal_summary.txt"
@@ -29,8 +29,8 @@ for ln in open(sys.argv[1]):
 PY
 }
 : > "$root/$out/rehearsal_summary.txt"
-run clean
-run kernel_fault "ISPLIB_BENCH_INJECT=kernel:overlapped sliced:1"
-run hang_optional "ISPLIB_BENCH_INJECT=hang:pipelined x2:2" ISPLIB_BENCH_T_CANDIDATE=20
-run raise_optional "ISPLIB_BENCH_INJECT=raise:direct x1:3" ISPLIB_BENCH_T_CANDIDATE=20
+run clean ISPLIB_BENCH_T_CANDIDATE=150 ISPLIB_BENCH_DEADLINE=900
+run kernel_fault "ISPLIB_BENCH_INJECT=kernel:overlapped sliced:1" ISPLIB_BENCH_T_CANDIDATE=150 ISPLIB_BENCH_DEADLINE=900
+run hang_optional "ISPLIB_BENCH_INJECT=hang:pipelined x2:2" ISPLIB_BENCH_T_CANDIDATE=40
+run raise_optional "ISPLIB_BENCH_INJECT=raise:overlapped sliced:3" ISPLIB_BENCH_T_CANDIDATE=40
 run hang_before_result "ISPLIB_BENCH_INJECT=hang:north_star:1" ISPLIB_BENCH_T_SAFE=60

@@ -802,6 +802,43 @@ def test_plugin_runs_max_and_min_on_the_stream_schedule(gpu, oracle_mod, monkeyp
     assert all(adj.storage._streams[k] is None for k in adj.storage._streams if k[-1] == "minmax")
 
 
+@pytest.mark.parametrize("k", (41, 47, 33))
+def test_operator_layer_copies_33_to_47_columns_to_a_192_byte_pitch(gpu, oracle_mod, monkeypatch, k):
+    """Round 4: on a stream plan the operator layer gathers a 33..47-column operand from a copy at a 192-byte row pitch (whole
+    cache lines: the GCN's K=41 aggregation, 1.365 -> 1.285 ms on the Reddit shape) -- graphs of at least 65,536 columns;
+    the output and the gradients stay packed.  Forward and backward of sum / mean / max through the plug-in on such a graph
+    (forced onto stream plans), against the oracle; the same call on a strided `other` must see through the stride."""
+    import isplib_amd
+    monkeypatch.setenv("ISPLIB_STREAM_GEOM", "4:6:300")
+    monkeypatch.setenv("ISPLIB_STREAM_MINMAX_GEOM", "4:4:300")
+    n = 66000
+    rowptr, col = cases.random_csr(n, n, 9.0, seed=k, empty_rows=(0, n - 1), hub=(17, 4000))
+    val = cases.weights(col.size, 4)
+    x, g = cases.dense(n, k, 3), cases.dense(n, k, 5)
+    adj = isplib_amd.SparseTensor.from_csr(_t(rowptr, gpu), _t(col, gpu), _t(val, gpu), (n, n))
+    wide = torch.zeros((n, 64), device=gpu)
+    wide[:, :k] = _t(x, gpu)
+    for red in ("sum", "mean", "max"):
+        ref, ref_arg = oracle_mod.spmm_fw(rowptr, col, val, x, red)
+        for other in (_t(x, gpu), wide[:, :k]):
+            xs = other.detach().requires_grad_(True)
+            out = isplib_amd.matmul(adj, xs, red)
+            assert out.is_contiguous() and out.shape == (n, k)
+            out.backward(_t(g, gpu))
+            got = out.detach().cpu().numpy()
+            if red == "max":
+                assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+                _, gm = oracle_mod.spmm_minmax_bw(col, val, x, ref_arg, g)
+                _close(xs.grad, gm, rtol=1e-5, atol=1e-5)
+            else:
+                deg = np.maximum(np.diff(rowptr), 1)[:, None] if red == "mean" else 1
+                assert np.all(np.abs(got - ref) <= cases.sum_tolerance(oracle_mod, rowptr, col, val, x) / deg + 1e-12), red
+                bw = oracle_mod.spmm_mean_bw if red == "mean" else oracle_mod.spmm_sum_bw
+                dmag = oracle_mod.spmm_sum_bw(rowptr, col, np.abs(val), n, np.abs(g))
+                assert np.all(np.abs(xs.grad.cpu().numpy() - bw(rowptr, col, val, n, g)) <= 1e-5 * dmag + 1e-30), red
+    assert any(p is not None for p in adj.storage._streams.values()), "the stream plans were not used"
+
+
 @pytest.mark.parametrize("geom", ("4:3:64", "8:2:100000", "2:5:300"))
 def test_plugin_runs_sum_and_mean_on_the_stream_schedule(gpu, oracle_mod, monkeypatch, geom):
     """The plug-in's default for sum / mean on large graphs, forced onto a small one (ISPLIB_STREAM_GEOM): forward through
