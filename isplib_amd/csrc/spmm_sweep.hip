@@ -499,13 +499,21 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, NVMAX, WGS>())) void s
 #ifdef ISPLIB_EXP_WAVE_TIMES
    const unsigned long long t_loop_end = __builtin_amdgcn_s_memtime();
 #endif
-   // write-out: slot q owns the local rows [q * PER, (q + 1) * PER); its LPR lanes hold one row of the panel
-#pragma unroll 1
+   // write-out: slot q owns the local rows [q * PER, (q + 1) * PER); its LPR lanes hold one row of the panel.  The rows' ids
+   // (two dependent global loads per row) are fetched for the whole slot first and the rows then go out four at a time: a
+   // row-at-a-time loop pays every row's memory latencies one after the other (2 % of a dispatch, scripts/exp_wave_times.py)
+   int row_[PER], part_[PER];
+#pragma unroll
+   for (int jj = 0; jj < PER; jj++) {
+      row_[jj] = cok ? a.wave_row[(size_t)w * NVMAX + g * PER + jj] : -1;
+      part_[jj] = a.wave_part[(size_t)w * NVMAX + g * PER + jj];
+   }
+#pragma unroll 4
    for (int jj = 0; jj < PER; jj++) {
       const int lrow = g * PER + jj;
-      const int row = a.wave_row[(size_t)w * NVMAX + lrow];
-      if (row < 0 || !cok) continue;
-      const int part = a.wave_part[(size_t)w * NVMAX + lrow];
+      const int row = row_[jj];
+      if (row < 0) continue;
+      const int part = part_[jj];
       const float4 t4 = *reinterpret_cast<const float4 *>(lane_base + lrow * PANEL);
       float v[4] = {t4.x, t4.y, t4.z, t4.w};
       int bi[4] = {INT_MAX, INT_MAX, INT_MAX, INT_MAX};
@@ -1090,31 +1098,41 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, 2 * (NVMAX + 1), WGS>(
    }
    *reinterpret_cast<float4 *>(lane_base + cur) = make_float4(acc[0], acc[1], acc[2], acc[3]);
    *reinterpret_cast<int4 *>(lane_idx + cur) = make_int4(bi[0], bi[1], bi[2], bi[3]);
-   // write-out: the winners' word indices become CSR positions through the plan's permutation
+   // write-out, ALL rows of the slot at once: the winners' word indices become CSR positions through the plan's permutation --
+   // four dependent loads per row and lane, which a row-at-a-time loop waits for PER times over (the gather registers are free
+   // by now: every load of the slot's PER rows is in flight before the first one is needed)
    const int32_t *ids = a.ids + s0 * G;
-#pragma unroll 1
+   int row_[PER], part_[PER], best_[PER][4];
+   float val_[PER][4];
+#pragma unroll
    for (int jj = 0; jj < PER; jj++) {
       const int lrow = g * PER + jj;
-      const int row = a.wave_row[(size_t)w * NVMAX + lrow];
-      if (row < 0 || !cok) continue;
-      const int part = a.wave_part[(size_t)w * NVMAX + lrow];
+      row_[jj] = cok ? a.wave_row[(size_t)w * NVMAX + lrow] : -1;
+      part_[jj] = a.wave_part[(size_t)w * NVMAX + lrow];
       const float4 t4 = *reinterpret_cast<const float4 *>(lane_base + lrow * PANEL);
-      float v[4] = {t4.x, t4.y, t4.z, t4.w};
       const int4 i4 = *reinterpret_cast<const int4 *>(lane_idx + lrow * PANEL);
-      int best[4] = {i4.x, i4.y, i4.z, i4.w};
+      val_[jj][0] = t4.x; val_[jj][1] = t4.y; val_[jj][2] = t4.z; val_[jj][3] = t4.w;
+      best_[jj][0] = i4.x; best_[jj][1] = i4.y; best_[jj][2] = i4.z; best_[jj][3] = i4.w;
+   }
 #pragma unroll
-      for (int i = 0; i < 4; i++) best[i] = best[i] == INT_MAX ? INT_MAX : ids[best[i]];
+   for (int jj = 0; jj < PER; jj++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) best_[jj][i] = (row_[jj] >= 0 && best_[jj][i] != INT_MAX) ? ids[best_[jj][i]] : INT_MAX;
+#pragma unroll
+   for (int jj = 0; jj < PER; jj++) {
+      const int row = row_[jj];
+      if (row < 0) continue;
       const int c = ccol;
-      if (part >= 0) {
-         const size_t po = (size_t)part * (size_t)a.k + c;
-         store_tail<4>(a.part_val + po, v, vfirst);
+      if (part_[jj] >= 0) {
+         const size_t po = (size_t)part_[jj] * (size_t)a.k + c;
+         store_tail<4>(a.part_val + po, val_[jj], vfirst);
 #pragma unroll
-         for (int i = 0; i < 4; i++) if (i >= vfirst) a.part_idx[po + i] = best[i];
+         for (int i = 0; i < 4; i++) if (i >= vfirst) a.part_idx[po + i] = best_[jj][i];
          continue;
       }
       int64_t arg[4];
-      finish_row<OP>(a, row, c, v, best, arg);
-      store_tail<4>(a.z + (size_t)row * (size_t)a.ldz + c, v, vfirst);
+      finish_row<OP>(a, row, c, val_[jj], best_[jj], arg);
+      store_tail<4>(a.z + (size_t)row * (size_t)a.ldz + c, val_[jj], vfirst);
       if (a.z_arg) {
          int64_t *ar = a.z_arg + (size_t)row * (size_t)a.ldz + c;
 #pragma unroll
