@@ -881,9 +881,9 @@ def main():
     guard = None
     if world > 1 or os.environ.get("ISPLIB_BENCH_FORCE_DIST") == "1":
         guard = Guard(rank, world)
-        guard.arm("start-up, graph, plans and the north_star form (one all-gather + local SpMM)", _env_seconds("ISPLIB_BENCH_T_SAFE", 300))
+        guard.arm("start-up, graph, plans and the north_star form (one all-gather + local SpMM)", _env_seconds("ISPLIB_BENCH_T_SAFE", 360))
     t_candidate = _env_seconds("ISPLIB_BENCH_T_CANDIDATE", 60)      # one optional exchange schedule: validation + timing
-    t_total = _env_seconds("ISPLIB_BENCH_DEADLINE", 420)            # everything, seconds since this rank started
+    t_total = _env_seconds("ISPLIB_BENCH_DEADLINE", 480)            # everything, seconds since this rank started
 
     verbose = os.environ.get("ISPLIB_BENCH_VERBOSE") == "1"          # progress notes from every rank, not just rank 0
 

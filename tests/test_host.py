@@ -901,3 +901,25 @@ def test_bench_launcher_has_a_time_limit_and_ends_the_process_group(tmp_path, mo
     monkeypatch.setattr(bench, "launcher_command", lambda gpus, argv, port: [sys.executable, str(quick), str(marker)])
     assert bench.self_launch(types.SimpleNamespace(gpus=2), ["--gpus", "2"]) == 7
     assert marker.read_text().split() == ["1", "0"]       # first the full run, then once more restricted to the north_star form
+
+
+def test_exchange_schedules_park_local_kernel_errors_until_their_collectives_are_done():
+    """isplib_amd.dist.RowPartition._kernel / _raise_parked: the first local kernel failure of an exchange is parked (later
+    kernels of the same exchange are skipped, its communication is not), raised once the exchange is complete and marked
+    `collectives_complete` -- what lets bench.py drop a schedule on every rank instead of leaving peers in a collective."""
+    from isplib_amd.dist import RowPartition
+    rowptr = torch.tensor([0, 2, 3, 5], dtype=torch.int64)
+    col = torch.tensor([0, 2, 1, 0, 1], dtype=torch.int64)
+    part = RowPartition(rowptr, col, None, 3, 0, 1)
+    ran = []
+    part._kernel(ran.append, "a")
+    part.fail_next_kernel = RuntimeError("boom")
+    part._kernel(ran.append, "b")                    # fails (injected): parked, not raised
+    part._kernel(ran.append, "c")                    # skipped: the exchange's result is void anyway
+    assert ran == ["a"] and part.fail_next_kernel is None
+    with pytest.raises(RuntimeError, match="boom") as info:
+        part._raise_parked()
+    assert info.value.collectives_complete is True
+    part._raise_parked()                             # nothing parked any more
+    part._kernel(ran.append, "d")
+    assert ran == ["a", "d"]
