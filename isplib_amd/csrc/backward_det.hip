@@ -17,7 +17,7 @@
 #include "../../include/isplib_hip.h"
 #include "common.h"
 
-#include <rocprim/rocprim.hpp>
+#include "prims.h"
 
 namespace isplib {
 
@@ -144,8 +144,7 @@ static inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static hipError_t pair_sort_temp(int64_t total, unsigned bits, size_t *bytes) {
    *bytes = 0;
-   return rocprim::radix_sort_pairs<rocprim::default_config, const uint32_t *, uint32_t *, const float *, float *>(
-       nullptr, *bytes, nullptr, nullptr, nullptr, nullptr, (size_t)total, 0u, bits, (hipStream_t)0, false);
+   return sort_pairs_u32_f32(nullptr, *bytes, nullptr, nullptr, nullptr, nullptr, (size_t)total, 0u, bits, (hipStream_t)0);
 }
 
 }  // namespace isplib
@@ -202,8 +201,7 @@ extern "C" int isplib_spmm_minmax_bw_det_hip(int64_t m, int64_t n, int64_t k, in
                       keys_in, vals_in);
    int rc = check_launch("minmax_pairs_kernel");
    if (rc) return rc;
-   ISPLIB_HIP_TRY((rocprim::radix_sort_pairs<rocprim::default_config, const uint32_t *, uint32_t *, const float *, float *>(
-       temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)total, 0u, bits, st, false)));
+   ISPLIB_HIP_TRY(sort_pairs_u32_f32(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)total, 0u, bits, st));
    const size_t nchunks = ((size_t)total + RUN_CHUNK - 1) / RUN_CHUNK;
    float *open_sum = (float *)((char *)temp + up256(temp_bytes));
    float *cont_sum = (float *)((char *)open_sum + up256(nchunks * 4));

@@ -13,7 +13,7 @@
 #include <stdint.h>
 #include <cstring>
 
-#include <rocprim/rocprim.hpp>
+#include "prims.h"
 
 #include "../../include/isplib_hip.h"
 #include "common.h"
@@ -198,11 +198,9 @@ __global__ __launch_bounds__(256) void plan_fill_kernel(int64_t m, int slices, i
 
 static hipError_t plan_scan_temp_bytes(int64_t items, size_t *bytes) {
    size_t a = 0, b = 0;
-   hipError_t e = rocprim::exclusive_scan(nullptr, a, (const int *)nullptr, (int *)nullptr, 0, (size_t)items,
-                                          rocprim::plus<int>(), (hipStream_t)0, false);
+   hipError_t e = scan_exclusive_i32(nullptr, a, nullptr, nullptr, (size_t)items, (hipStream_t)0);
    if (e != hipSuccess) return e;
-   e = rocprim::exclusive_scan(nullptr, b, (const int64_t *)nullptr, (int64_t *)nullptr, (int64_t)0, (size_t)items,
-                               rocprim::plus<int64_t>(), (hipStream_t)0, false);
+   e = scan_exclusive_i64(nullptr, b, nullptr, nullptr, (size_t)items, (hipStream_t)0);
    *bytes = a > b ? a : b;
    return e;
 }
@@ -224,8 +222,7 @@ static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static hipError_t sort_temp_bytes(int64_t n, int64_t nnz, size_t *bytes) {
    *bytes = 0;
-   return rocprim::radix_sort_pairs<rocprim::default_config, const uint32_t *, uint32_t *, const uint32_t *, uint32_t *>(
-       nullptr, *bytes, nullptr, nullptr, nullptr, nullptr, (size_t)nnz, 0u, key_bits(n), (hipStream_t)0, false);
+   return sort_pairs_u32(nullptr, *bytes, nullptr, nullptr, nullptr, nullptr, (size_t)nnz, 0u, key_bits(n), (hipStream_t)0);
 }
 
 }  // namespace isplib
@@ -277,8 +274,7 @@ extern "C" int isplib_csr2csc_hip(int64_t m, int64_t n, int64_t nnz, const int64
    hipLaunchKernelGGL(make_keys_kernel, dim3(grid_for(nnz)), dim3(256), 0, st, nnz, col, keys_in, pos_in);
    int rc = check_launch("make_keys_kernel");
    if (rc) return rc;
-   ISPLIB_HIP_TRY((rocprim::radix_sort_pairs<rocprim::default_config, const uint32_t *, uint32_t *, const uint32_t *, uint32_t *>(
-       tmp, temp, keys_in, keys_out, pos_in, pos_out, (size_t)nnz, 0u, key_bits(n), st, false)));
+   ISPLIB_HIP_TRY(sort_pairs_u32(tmp, temp, keys_in, keys_out, pos_in, pos_out, (size_t)nnz, 0u, key_bits(n), st));
    hipLaunchKernelGGL(colptr_kernel, dim3(grid_for(n + 1)), dim3(256), 0, st, n, nnz, keys_out, colptr);
    rc = check_launch("colptr_kernel");
    if (rc) return rc;
@@ -359,10 +355,8 @@ extern "C" int isplib_spmm_tasks_count_hip(int64_t m, const int64_t *pntrb, cons
                       pntre, sliceptr, cnt, ecnt);
    int rc = check_launch("plan_count_kernel");
    if (rc) return rc;
-   ISPLIB_HIP_TRY(rocprim::exclusive_scan(tmp, temp, (const int *)cnt, (int *)seg_off, 0, (size_t)items,
-                                          rocprim::plus<int>(), st, false));
-   ISPLIB_HIP_TRY(rocprim::exclusive_scan(tmp, temp, (const int64_t *)ecnt, eoff, (int64_t)0, (size_t)items,
-                                          rocprim::plus<int64_t>(), st, false));
+   ISPLIB_HIP_TRY(scan_exclusive_i32(tmp, temp, (const int *)cnt, (int *)seg_off, (size_t)items, st));
+   ISPLIB_HIP_TRY(scan_exclusive_i64(tmp, temp, (const int64_t *)ecnt, eoff, (size_t)items, st));
    hipLaunchKernelGGL(plan_lanes_kernel, dim3(1), dim3(64), 0, st, items, eoff, seg_off, lanes);
    rc = check_launch("plan_lanes_kernel");
    if (rc) return rc;

@@ -9,7 +9,7 @@
 #include <stdint.h>
 #include <cstring>
 
-#include <rocprim/rocprim.hpp>
+#include "prims.h"
 
 #include "../../include/isplib_hip.h"
 #include "common.h"
@@ -103,10 +103,8 @@ static size_t ro_align(size_t v) { return (v + 255) & ~(size_t)255; }
 struct RoTemp { size_t keys, pairs; };
 static RoTemp ro_temp(int64_t m, int64_t nnz) {
    RoTemp t = {0, 0};
-   (void)rocprim::radix_sort_keys(nullptr, t.keys, (const uint64_t *)nullptr, (uint64_t *)nullptr, (size_t)(nnz > 0 ? nnz : 1), 0, 64,
-                                  (hipStream_t)0, false);
-   (void)rocprim::radix_sort_pairs(nullptr, t.pairs, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr,
-                                   (uint32_t *)nullptr, (size_t)(m > 0 ? m : 1), 0, 32, (hipStream_t)0, false);
+   (void)sort_keys_u64(nullptr, t.keys, nullptr, nullptr, (size_t)(nnz > 0 ? nnz : 1), 0, 64, (hipStream_t)0);
+   (void)sort_pairs_u32(nullptr, t.pairs, nullptr, nullptr, nullptr, nullptr, (size_t)(m > 0 ? m : 1), 0, 32, (hipStream_t)0);
    return t;
 }
 
@@ -155,7 +153,7 @@ extern "C" int isplib_community_order_hip(int64_t m, int64_t nnz, const int64_t 
       hipLaunchKernelGGL(ro_keys_kernel, dim3(ro_grid(nnz)), dim3(256), 0, st, m, nnz, rowptr, col, lab_a, keys_a);
       if ((rc = check_launch("ro_keys_kernel")) != 0) return rc;
       size_t tb = t.keys;
-      ISPLIB_HIP_TRY(rocprim::radix_sort_keys(temp, tb, (const uint64_t *)keys_a, keys_b, (size_t)nnz, 0, end_bit < 64 ? end_bit : 64, st, false));
+      ISPLIB_HIP_TRY(sort_keys_u64(temp, tb, (const uint64_t *)keys_a, keys_b, (size_t)nnz, 0, end_bit < 64 ? end_bit : 64, st));
       const int64_t salt = (int64_t)(seed + round) * 40503 + 12345;
       hipLaunchKernelGGL(ro_mode_kernel, dim3(ro_grid(m)), dim3(256), 0, st, m, rowptr, keys_b, lab_a, lab_b, salt, changed);
       if ((rc = check_launch("ro_mode_kernel")) != 0) return rc;
@@ -170,8 +168,8 @@ extern "C" int isplib_community_order_hip(int64_t m, int64_t nnz, const int64_t 
    if (labels_out) ISPLIB_HIP_TRY(hipMemcpyAsync(labels_out, lab_a, r * 4, hipMemcpyDeviceToDevice, st));
    // rows grouped by label, in index order inside a group: a stable sort of (label, row id)
    size_t tb = t.pairs;
-   ISPLIB_HIP_TRY(rocprim::radix_sort_pairs(temp, tb, (const uint32_t *)lab_a, lab_sorted, (const uint32_t *)ids, (uint32_t *)order, (size_t)m, 0,
-                                            ro_bits(m) < 32 ? ro_bits(m) : 32, st, false));
+   ISPLIB_HIP_TRY(sort_pairs_u32(temp, tb, (const uint32_t *)lab_a, lab_sorted, (const uint32_t *)ids, (uint32_t *)order, (size_t)m, 0,
+                                 ro_bits(m) < 32 ? ro_bits(m) : 32, st));
    return ISPLIB_SUCCESS;
 }
 

@@ -18,7 +18,7 @@
 #include "../../include/isplib_hip.h"
 #include "common.h"
 
-#include <rocprim/rocprim.hpp>
+#include "prims.h"
 
 namespace isplib {
 
@@ -204,8 +204,7 @@ template <class T> static bool sp_alloc_out(T **out, size_t count) {
 
 static hipError_t sp_sort(void *temp, size_t &temp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
                           size_t n, unsigned bits, hipStream_t st) {
-   return rocprim::radix_sort_pairs<rocprim::default_config, const uint32_t *, uint32_t *, const uint32_t *, uint32_t *>(
-       temp, temp_bytes, kin, kout, vin, vout, n, 0u, bits, st, false);
+   return sort_pairs_u32(temp, temp_bytes, kin, kout, vin, vout, n, 0u, bits, st);
 }
 
 }  // namespace isplib
@@ -263,7 +262,7 @@ static int stream_plan_build(int64_t m, int64_t n, int64_t nnz, const int64_t *r
    int rc = check_launch("sp_row_chunks_kernel");
    if (rc) return rc;
    size_t scan_bytes = 0;
-   ISPLIB_HIP_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, (const int *)nullptr, (int *)nullptr, 0, (size_t)m, rocprim::plus<int>(), st, false));
+   ISPLIB_HIP_TRY(scan_exclusive_i32(nullptr, scan_bytes, nullptr, nullptr, (size_t)m, st));
    void *scan_tmp;
    {
       char *p;
@@ -271,9 +270,9 @@ static int stream_plan_build(int64_t m, int64_t n, int64_t nnz, const int64_t *r
       scan_tmp = p;
    }
    size_t sb = scan_bytes;
-   ISPLIB_HIP_TRY(rocprim::exclusive_scan(scan_tmp, sb, (const int *)nchunk, first, 0, (size_t)m, rocprim::plus<int>(), st, false));
+   ISPLIB_HIP_TRY(scan_exclusive_i32(scan_tmp, sb, (const int *)nchunk, first, (size_t)m, st));
    sb = scan_bytes;
-   ISPLIB_HIP_TRY(rocprim::exclusive_scan(scan_tmp, sb, (const int *)hub_flag, hub_idx, 0, (size_t)m, rocprim::plus<int>(), st, false));
+   ISPLIB_HIP_TRY(scan_exclusive_i32(scan_tmp, sb, (const int *)hub_flag, hub_idx, (size_t)m, st));
    int last[4];                                             // first[m-1], nchunk[m-1], hub_idx[m-1], hub_flag[m-1]
    ISPLIB_HIP_TRY(hipMemcpyAsync(&last[0], first + (m - 1), sizeof(int), hipMemcpyDeviceToHost, st));
    ISPLIB_HIP_TRY(hipMemcpyAsync(&last[1], nchunk + (m - 1), sizeof(int), hipMemcpyDeviceToHost, st));
@@ -307,10 +306,10 @@ static int stream_plan_build(int64_t m, int64_t n, int64_t nnz, const int64_t *r
                       vhub, hub_row);
    SP_LAUNCHED("sp_vrows_kernel");
    size_t sbv = 0;
-   SP_TRY(rocprim::exclusive_scan(nullptr, sbv, (const int *)nullptr, (int *)nullptr, 0, (size_t)nv, rocprim::plus<int>(), st, false));
+   SP_TRY(scan_exclusive_i32(nullptr, sbv, nullptr, nullptr, (size_t)nv, st));
    char *scan_tmp2;
    if (!T.alloc(&scan_tmp2, sbv + 256)) SP_FAIL(ISPLIB_NOT_ENOUGH_MEM, "isplib_stream_plan_build_hip: device allocation failed");
-   SP_TRY(rocprim::exclusive_scan(scan_tmp2, sbv, (const int *)vhub, part_of, 0, (size_t)nv, rocprim::plus<int>(), st, false));
+   SP_TRY(scan_exclusive_i32(scan_tmp2, sbv, (const int *)vhub, part_of, (size_t)nv, st));
    int part_last[2];
    SP_TRY(hipMemcpyAsync(&part_last[0], part_of + (nv - 1), sizeof(int), hipMemcpyDeviceToHost, st));
    SP_TRY(hipMemcpyAsync(&part_last[1], vhub + (nv - 1), sizeof(int), hipMemcpyDeviceToHost, st));
@@ -342,13 +341,13 @@ static int stream_plan_build(int64_t m, int64_t n, int64_t nnz, const int64_t *r
    hipLaunchKernelGGL(sp_wave_steps_kernel, dim3(sp_grid(nw)), dim3(256), 0, st, nw, streams, loads, steps, loads64);
    SP_LAUNCHED("sp_wave_steps_kernel");
    size_t s64 = 0;
-   SP_TRY(rocprim::exclusive_scan(nullptr, s64, (const int64_t *)nullptr, (int64_t *)nullptr, (int64_t)0, (size_t)ns, rocprim::plus<int64_t>(), st, false));
+   SP_TRY(scan_exclusive_i64(nullptr, s64, nullptr, nullptr, (size_t)ns, st));
    char *scan_tmp3;
    if (!T.alloc(&scan_tmp3, s64 + 256)) SP_FAIL(ISPLIB_NOT_ENOUGH_MEM, "isplib_stream_plan_build_hip: device allocation failed");
    size_t s64b = s64;
-   SP_TRY(rocprim::exclusive_scan(scan_tmp3, s64b, (const int64_t *)loads64, stream_start, (int64_t)0, (size_t)ns, rocprim::plus<int64_t>(), st, false));
+   SP_TRY(scan_exclusive_i64(scan_tmp3, s64b, (const int64_t *)loads64, stream_start, (size_t)ns, st));
    s64b = s64;
-   SP_TRY(rocprim::exclusive_scan(scan_tmp3, s64b, (const int64_t *)steps, wave_step_off, (int64_t)0, (size_t)nw, rocprim::plus<int64_t>(), st, false));
+   SP_TRY(scan_exclusive_i64(scan_tmp3, s64b, (const int64_t *)steps, wave_step_off, (size_t)nw, st));
    int64_t tail[2];
    SP_TRY(hipMemcpyAsync(&tail[0], wave_step_off + (nw - 1), sizeof(int64_t), hipMemcpyDeviceToHost, st));
    SP_TRY(hipMemcpyAsync(&tail[1], steps + (nw - 1), sizeof(int64_t), hipMemcpyDeviceToHost, st));

@@ -333,6 +333,12 @@ def stream_plan_arrays(rowptr: torch.Tensor, col: torch.Tensor, ncols: int, slic
         # the 32 streams of a CU then sweep a slice's columns together and popular rows of y are gathered by several of them
         # within a few steps of each other (L1 reuse?); the price is a change of accumulator row at nearly every step
         key = (sid[ev] * slices + col // width) * width + col % width
+    elif os.environ.get("ISPLIB_EXP_SNAKE") == "1":
+        # experiment (round 4): a stream walks its rows forwards in even slices and backwards in odd ones, so the last row of
+        # slice s is the first row of slice s + 1 and that change of row disappears (1 of `per` per slice); every row's own
+        # word order is unchanged, so results are bit-identical
+        sl = col // width
+        key = (sid[ev] * slices + sl) * per + torch.where(sl % 2 == 1, per - 1 - rnd[ev], rnd[ev])
     else:
         key = (sid[ev] * slices + col // width) * per + rnd[ev]
     perm = torch.sort(key, stable=True).indices
