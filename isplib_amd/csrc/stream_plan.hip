@@ -111,7 +111,12 @@ __device__ __forceinline__ int64_t sp_row_of(int64_t e, int64_t m, const int64_t
    return lo;
 }
 
-__global__ __launch_bounds__(256) void sp_edge_keys_kernel(int64_t m, int64_t nnz, int64_t width, int slices, int per,
+// snake != 0 (max / min plans): a stream walks its rows forwards in even slices and backwards in odd ones, so the last row of
+// slice s is the first row of slice s + 1 and that change of row -- an LDS swap in the max / min kernel -- disappears (one of
+// `per` per slice: K=64 1.794 -> 1.786 ms, K=32 0.858 -> 0.845; every row's own word order is unchanged, the results are
+// bit-identical).  Sum / mean plans keep the plain order: there a row that continues across a slice boundary without a flush
+// changes the association of its sum, and the launch got 0.5 % slower.
+__global__ __launch_bounds__(256) void sp_edge_keys_kernel(int64_t m, int64_t nnz, int64_t width, int slices, int per, int snake,
                                                            const int64_t *__restrict__ rowptr, const int64_t *__restrict__ col,
                                                            const int *__restrict__ nchunk, const int *__restrict__ first,
                                                            const int *__restrict__ sid, const int *__restrict__ rnd,
@@ -120,7 +125,8 @@ __global__ __launch_bounds__(256) void sp_edge_keys_kernel(int64_t m, int64_t nn
    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += stride) {
       const int64_t row = sp_row_of(e, m, rowptr);
       const int v = first[row] + (int)((e - rowptr[row]) % nchunk[row]);
-      keys[e] = (uint32_t)(((int64_t)sid[v] * slices + col[e] / width) * per + rnd[v]);
+      const int64_t sl = col[e] / width;
+      keys[e] = (uint32_t)(((int64_t)sid[v] * slices + sl) * per + ((snake && (sl & 1)) ? per - 1 - rnd[v] : rnd[v]));
       vals[e] = (uint32_t)e;
    }
 }
@@ -384,8 +390,8 @@ static int stream_plan_build(int64_t m, int64_t n, int64_t nnz, const int64_t *r
    }
    if (nnz > 0) {
       const int64_t width = (n + slices - 1) / slices;
-      hipLaunchKernelGGL(sp_edge_keys_kernel, dim3(sp_grid(nnz)), dim3(256), 0, st, m, nnz, width, slices, per, rowptr, col, nchunk, first, sid, rnd,
-                         k_in, v_in);
+      hipLaunchKernelGGL(sp_edge_keys_kernel, dim3(sp_grid(nnz)), dim3(256), 0, st, m, nnz, width, slices, per, pad_row >= 0 ? 1 : 0, rowptr, col, nchunk, first,
+                         sid, rnd, k_in, v_in);
       SP_LAUNCHED("sp_edge_keys_kernel");
       tb = sort_bytes;
       SP_TRY(sp_sort(sort_tmp, tb, k_in, k_out, v_in, v_out, (size_t)nnz, sp_bits((uint64_t)ns * slices * per + 1), st));

@@ -333,10 +333,12 @@ def stream_plan_arrays(rowptr: torch.Tensor, col: torch.Tensor, ncols: int, slic
         # the 32 streams of a CU then sweep a slice's columns together and popular rows of y are gathered by several of them
         # within a few steps of each other (L1 reuse?); the price is a change of accumulator row at nearly every step
         key = (sid[ev] * slices + col // width) * width + col % width
-    elif os.environ.get("ISPLIB_EXP_SNAKE") == "1":
-        # experiment (round 4): a stream walks its rows forwards in even slices and backwards in odd ones, so the last row of
-        # slice s is the first row of slice s + 1 and that change of row disappears (1 of `per` per slice); every row's own
-        # word order is unchanged, so results are bit-identical
+    elif pad_row is not None or os.environ.get("ISPLIB_EXP_SNAKE") == "1":
+        # max / min plans (round 4; ISPLIB_EXP_SNAKE=1 forces it for an experiment on sum plans, scripts/exp_snake.py): a stream
+        # walks its rows forwards in even slices and backwards in odd ones, so the last row of slice s is the first row of
+        # slice s + 1 and that change of row -- an LDS swap in the max / min kernel -- disappears (one of `per` per slice);
+        # every row's own word order is unchanged, so max / min results are bit-identical (K=64 1.794 -> 1.786 ms, K=32
+        # 0.858 -> 0.845).  Sum / mean plans keep the plain order (0.5 % slower there, and the sums re-associate).
         sl = col // width
         key = (sid[ev] * slices + sl) * per + torch.where(sl % 2 == 1, per - 1 - rnd[ev], rnd[ev])
     else:

@@ -1,6 +1,8 @@
 """Experiment (round 4): the stream plan's rows in snake order (ISPLIB_EXP_SNAKE=1, torch builder): forwards in even slices,
 backwards in odd ones -- one change of row per slice and stream disappears.  Sum K=128 (16 rows per stream) and max K=64
-(8 rows per stream), each against the plain order, bit-identical results checked.  usage: exp_snake.py"""
+(8 rows per stream), each against the plain order, bit-identical results checked.  The measurement behind the rule that max /
+min plans are snake-ordered and sum / mean plans are not (profiles/r04_experiments.txt); since that rule is in the builders,
+the "plain order" column of the max rows now shows the snake order too.  usage: exp_snake.py"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
