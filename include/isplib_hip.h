@@ -390,7 +390,9 @@ int    isplib_suggest_stream_weighted(int64_t m, int64_t n, int64_t nnz, int64_t
  * position) pairs into their fold.  Slots of 64 columns (streams = 4) or, for k <= 32, of 32 columns (streams = 8), with
  * half the rows per wave of the sum kernel, so max / min plans are built for isplib_spmm_stream_minmax_geometry -- isplib_stream_plan_build_minmax_hip
  * does that and returns ISPLIB_FAIL for a graph with an unsorted row (use the task list) -- and are not interchangeable
- * with sum plans.  nnz < 2^31.  z_arg (may be NULL): [m][ldz] int64 CSR positions, nnz = empty row. */
+ * with sum plans.  nnz < 2^31.  z_arg (may be NULL): [m][ldz] int64 CSR positions, nnz = empty row.  With z_arg = NULL the
+ * launch is a values-only one: no position is tracked at all (a quarter of the loop's vector instructions), same plan,
+ * same values bit for bit. */
 int    isplib_spmm_stream_minmax_geometry(int streams /* 4 | 8 */, int *rows_per_wave /*out*/, int *waves_resident /*out*/);
 int    isplib_suggest_stream_minmax(int64_t m, int64_t n, int64_t nnz, int64_t k, int *streams, int *slices, int *chunk);
 int    isplib_stream_plan_build_minmax_hip(int64_t m, int64_t n, int64_t nnz, const int64_t *rowptr, const int64_t *col,

@@ -965,7 +965,11 @@ __global__ __launch_bounds__(512, 2) void spmm_hybrid_kernel(const SweepArgs a) 
 // unpacks and moves a per-row word count as well, which costs what the saved dispatch gave.)
 typedef float v2f_t __attribute__((ext_vector_type(2)));
 
-template <int OP, int LPR, bool HAS_VAL, int NVMAX, int NBW, int WGS>
+// ARG = false (z_arg == NULL: values only, e.g. the aggregation of an inference pass, where no backward will ask which edge
+// won): the index registers, their selects -- four of the 16-18 vector instructions of a step, in a loop that is bound by
+// them (profiles/r04_experiments.txt) --, the index plane and the permutation lookups at write-out all drop out; same plan,
+// same values bit for bit.  K=64 on the Reddit shape: 1.80 -> 1.6 ms with U(0,1) weights, 1.61 -> 1.4 with unit weights.
+template <int OP, int LPR, bool HAS_VAL, int NVMAX, int NBW, int WGS, bool ARG>
 __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, 2 * (NVMAX + 1), WGS>())) void spmm_stream_minmax_kernel(const SweepArgs a) {
    constexpr int WAVES = 4, G = 64 / LPR, PANEL = LPR * 4, U = 64 * NBW / G;
    constexpr int PER = NVMAX / G;
@@ -984,8 +988,9 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, 2 * (NVMAX + 1), WGS>(
    float *my = s_all + wave * WAVE_DWORDS;
    for (int i = lane * 4; i < ROWS * PANEL; i += 256)
       *reinterpret_cast<float4 *>(my + i) = make_float4(identity<OP>(), identity<OP>(), identity<OP>(), identity<OP>());
-   for (int i = lane * 4; i < ROWS * PANEL; i += 256)
-      *reinterpret_cast<int4 *>(my + IDX0 + i) = make_int4(INT_MAX, INT_MAX, INT_MAX, INT_MAX);
+   if (ARG)
+      for (int i = lane * 4; i < ROWS * PANEL; i += 256)
+         *reinterpret_cast<int4 *>(my + IDX0 + i) = make_int4(INT_MAX, INT_MAX, INT_MAX, INT_MAX);
    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.y), 0, (int)a.ybytes, 0x00020000);
    const bool cok = lc * 4 < a.k;
    int ccol = lc * 4, vfirst = 0;
@@ -1052,10 +1057,14 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, 2 * (NVMAX + 1), WGS>(
    auto swap_to = [&](unsigned nxt) {
       asm volatile("" : "+v"(nxt));                      // keeps the LDS address arithmetic inside the branch (one vector instruction per step otherwise)
       const float4 o = *reinterpret_cast<const float4 *>(lane_base + nxt);
-      const int4 oi = *reinterpret_cast<const int4 *>(lane_idx + nxt);
-      *reinterpret_cast<float4 *>(lane_base + cur) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-      *reinterpret_cast<int4 *>(lane_idx + cur) = make_int4(bi[0], bi[1], bi[2], bi[3]);
-      bi[0] = oi.x; bi[1] = oi.y; bi[2] = oi.z; bi[3] = oi.w;
+      if constexpr (ARG) {
+         const int4 oi = *reinterpret_cast<const int4 *>(lane_idx + nxt);
+         *reinterpret_cast<float4 *>(lane_base + cur) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+         *reinterpret_cast<int4 *>(lane_idx + cur) = make_int4(bi[0], bi[1], bi[2], bi[3]);
+         bi[0] = oi.x; bi[1] = oi.y; bi[2] = oi.z; bi[3] = oi.w;
+      } else {
+         *reinterpret_cast<float4 *>(lane_base + cur) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      }
       acc[0] = o.x; acc[1] = o.y; acc[2] = o.z; acc[3] = o.w;
       cur = nxt;
    };
@@ -1087,7 +1096,7 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, 2 * (NVMAX + 1), WGS>(
          for (int v = 0; v < 4; v++) {
             const bool win = OP == OP_MAX ? tt[v] > acc[v] : tt[v] < acc[v];      // NaN never wins, as in the oracle
             acc[v] = win ? tt[v] : acc[v];
-            bi[v] = win ? mark : bi[v];
+            if (ARG) bi[v] = win ? mark : bi[v];
          }
          issue(u, wcur);
       }
@@ -1097,7 +1106,7 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, 2 * (NVMAX + 1), WGS>(
       load_vals((b + 2) * 64 * NBW, v1);
    }
    *reinterpret_cast<float4 *>(lane_base + cur) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-   *reinterpret_cast<int4 *>(lane_idx + cur) = make_int4(bi[0], bi[1], bi[2], bi[3]);
+   if (ARG) *reinterpret_cast<int4 *>(lane_idx + cur) = make_int4(bi[0], bi[1], bi[2], bi[3]);
    // write-out, ALL rows of the slot at once: the winners' word indices become CSR positions through the plan's permutation --
    // four dependent loads per row and lane, which a row-at-a-time loop waits for PER times over (the gather registers are free
    // by now: every load of the slot's PER rows is in flight before the first one is needed)
@@ -1110,14 +1119,20 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, 2 * (NVMAX + 1), WGS>(
       row_[jj] = cok ? a.wave_row[(size_t)w * NVMAX + lrow] : -1;
       part_[jj] = a.wave_part[(size_t)w * NVMAX + lrow];
       const float4 t4 = *reinterpret_cast<const float4 *>(lane_base + lrow * PANEL);
-      const int4 i4 = *reinterpret_cast<const int4 *>(lane_idx + lrow * PANEL);
       val_[jj][0] = t4.x; val_[jj][1] = t4.y; val_[jj][2] = t4.z; val_[jj][3] = t4.w;
-      best_[jj][0] = i4.x; best_[jj][1] = i4.y; best_[jj][2] = i4.z; best_[jj][3] = i4.w;
+      if constexpr (ARG) {
+         const int4 i4 = *reinterpret_cast<const int4 *>(lane_idx + lrow * PANEL);
+         best_[jj][0] = i4.x; best_[jj][1] = i4.y; best_[jj][2] = i4.z; best_[jj][3] = i4.w;
+      } else {
+         best_[jj][0] = best_[jj][1] = best_[jj][2] = best_[jj][3] = INT_MAX;
+      }
    }
+   if constexpr (ARG) {
 #pragma unroll
-   for (int jj = 0; jj < PER; jj++)
+      for (int jj = 0; jj < PER; jj++)
 #pragma unroll
-      for (int i = 0; i < 4; i++) best_[jj][i] = (row_[jj] >= 0 && best_[jj][i] != INT_MAX) ? ids[best_[jj][i]] : INT_MAX;
+         for (int i = 0; i < 4; i++) best_[jj][i] = (row_[jj] >= 0 && best_[jj][i] != INT_MAX) ? ids[best_[jj][i]] : INT_MAX;
+   }
 #pragma unroll
    for (int jj = 0; jj < PER; jj++) {
       const int row = row_[jj];
@@ -1126,8 +1141,10 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, 2 * (NVMAX + 1), WGS>(
       if (part_[jj] >= 0) {
          const size_t po = (size_t)part_[jj] * (size_t)a.k + c;
          store_tail<4>(a.part_val + po, val_[jj], vfirst);
+         if constexpr (ARG) {
 #pragma unroll
-         for (int i = 0; i < 4; i++) if (i >= vfirst) a.part_idx[po + i] = best_[jj][i];
+            for (int i = 0; i < 4; i++) if (i >= vfirst) a.part_idx[po + i] = best_[jj][i];
+         }
          continue;
       }
       int64_t arg[4];
@@ -1212,8 +1229,13 @@ template <int OP, bool HAS_VAL>
 static int launch_stream_minmax(const SweepArgs &a, hipStream_t st, int streams) {
    const unsigned blocks = (unsigned)((a.wave_count + 3) / 4);
    if (blocks == 0) return ISPLIB_SUCCESS;
-   if (streams == 8) hipLaunchKernelGGL((spmm_stream_minmax_kernel<OP, 8, HAS_VAL, ISPLIB_STREAM_MM8_NV, ISPLIB_STREAM_MM8_NBW, ISPLIB_STREAM_MM8_WGS>), dim3(blocks), dim3(256), 0, st, a);
-   else hipLaunchKernelGGL((spmm_stream_minmax_kernel<OP, 16, HAS_VAL, ISPLIB_STREAM_MM_NV, ISPLIB_STREAM_MM_NBW, ISPLIB_STREAM_MM_WGS>), dim3(blocks), dim3(256), 0, st, a);
+   if (a.z_arg) {
+      if (streams == 8) hipLaunchKernelGGL((spmm_stream_minmax_kernel<OP, 8, HAS_VAL, ISPLIB_STREAM_MM8_NV, ISPLIB_STREAM_MM8_NBW, ISPLIB_STREAM_MM8_WGS, true>), dim3(blocks), dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((spmm_stream_minmax_kernel<OP, 16, HAS_VAL, ISPLIB_STREAM_MM_NV, ISPLIB_STREAM_MM_NBW, ISPLIB_STREAM_MM_WGS, true>), dim3(blocks), dim3(256), 0, st, a);
+   } else {                                               // values only
+      if (streams == 8) hipLaunchKernelGGL((spmm_stream_minmax_kernel<OP, 8, HAS_VAL, ISPLIB_STREAM_MM8_NV, ISPLIB_STREAM_MM8_NBW, ISPLIB_STREAM_MM8_WGS, false>), dim3(blocks), dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((spmm_stream_minmax_kernel<OP, 16, HAS_VAL, ISPLIB_STREAM_MM_NV, ISPLIB_STREAM_MM_NBW, ISPLIB_STREAM_MM_WGS, false>), dim3(blocks), dim3(256), 0, st, a);
+   }
    return check_launch("spmm_stream_minmax_kernel");
 }
 

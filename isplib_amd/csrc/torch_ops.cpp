@@ -248,8 +248,11 @@ bool spmm_through_handle(int32_t msg, const Tensor &rowptr, const Tensor &col, c
    return true;
 }
 
+// want_arg = false (max / min through the *_values operators: nobody will ask which edge won): on a stream plan the
+// launch then leaves the positions out altogether (isplib_hip.h: fusedMM_csr_stream_minmax_hip with z_arg = NULL) and the
+// second tensor of the result is undefined; every other schedule computes them as always
 std::tuple<Tensor, Tensor> spmm_fw(const Tensor &rowptr_, const Tensor &col_, const optional<Tensor> &value_,
-                                   const Tensor &mat_, int reduction, const Plan &plan = Plan()) {
+                                   const Tensor &mat_, int reduction, const Plan &plan = Plan(), bool want_arg = true) {
    check_index(rowptr_, "rowptr");
    check_index(col_, "col");
    check_float(mat_, "mat");
@@ -271,14 +274,15 @@ std::tuple<Tensor, Tensor> spmm_fw(const Tensor &rowptr_, const Tensor &col_, co
    if (reduction == R_MAX) msg = ISPLIB_MSG_SPMM_MAX;
    if (reduction == R_MIN) msg = ISPLIB_MSG_SPMM_MIN;
    if (reduction == R_MEAN) msg = ISPLIB_MSG_SPMM_MEAN;
-   if (reduction == R_MAX || reduction == R_MIN) arg = at::empty({M, K}, rowptr.options());
    const int64_t *rp = rowptr.data_ptr<int64_t>();
    const bool tasks_fit = K >= 4 && (double)N * (double)K * 4.0 <= 3.5 * 1073741824.0;
    // (a stream plan for a shape outside the stream entry's domain -- dense operand over 3.5 GiB, k < 4 -- is not an error:
    // the graph is served by the kernels below, which read `col` / `value`)
    const bool minmax_op = reduction == R_MAX || reduction == R_MIN;      // (the max / min stream entry serves dense operands under 2 GiB)
-   if (is_stream_plan(plan) && M > 0 && K >= 4 && (double)N * (double)K * 4.0 <= 3.5 * 1073741824.0 &&
-       !(minmax_op && (double)N * (double)K * 4.0 >= 2.0 * 1073741824.0)) {
+   const bool on_stream = is_stream_plan(plan) && M > 0 && K >= 4 && (double)N * (double)K * 4.0 <= 3.5 * 1073741824.0 &&
+                          !(minmax_op && (double)N * (double)K * 4.0 >= 2.0 * 1073741824.0);
+   if (minmax_op && (want_arg || !on_stream)) arg = at::empty({M, K}, rowptr.options());
+   if (on_stream) {
       // the plan carries the edges (and the weights) in its own order: `col` / `value` are not read
       const isplib_stream_plan sp = stream_plan_of(plan);
       // A line-friendly pitch for 33..47 columns (the GCN's 41 classes): what the address pipeline charges for is the
@@ -299,7 +303,7 @@ std::tuple<Tensor, Tensor> spmm_fw(const Tensor &rowptr_, const Tensor &col_, co
          const size_t ws = isplib_spmm_stream_minmax_workspace_bytes(&sp);
          Tensor work = at::empty({(int64_t)ws}, mat.options().dtype(at::kByte));
          const int st = fusedMM_csr_stream_minmax_hip(msg, M, N, K, nnz, rp, rp + 1, &sp, y, ldy, out.data_ptr<float>(), K,
-                                                      arg.data_ptr<int64_t>(), work.data_ptr(), ws, current_stream(mat));
+                                                      arg.defined() ? arg.data_ptr<int64_t>() : nullptr, work.data_ptr(), ws, current_stream(mat));
          check_status(st, "fusedMM_csr_stream_minmax_hip");
          return std::make_tuple(out, arg);
       }
@@ -773,6 +777,18 @@ std::tuple<Tensor, Tensor> fusedmm_spmm_min_planned(Tensor rowptr, Tensor col, o
    return std::make_tuple(r[0], r[1]);
 }
 
+// values only, no autograd node: what the plug-in calls for max / min when no gradient can be asked for (the patched matmul
+// returns the tensor alone, isplib/__init__.py:143,145 + SURVEY 8a P1, so the positions would be computed and dropped)
+Tensor fusedmm_spmm_max_values(Tensor rowptr, Tensor col, optional<Tensor> opt_value, Tensor mat, Plan plan) {
+   OpTimer timer("FUSEDMM_SPMM_MAX_VALUES", mat);
+   return std::get<0>(spmm_fw(rowptr, col, opt_value, mat, R_MAX, plan, /* want_arg = */ false));
+}
+
+Tensor fusedmm_spmm_min_values(Tensor rowptr, Tensor col, optional<Tensor> opt_value, Tensor mat, Plan plan) {
+   OpTimer timer("FUSEDMM_SPMM_MIN_VALUES", mat);
+   return std::get<0>(spmm_fw(rowptr, col, opt_value, mat, R_MIN, plan, /* want_arg = */ false));
+}
+
 std::tuple<Tensor, Tensor> fusedmm_spmm_min(Tensor rowptr, Tensor col, optional<Tensor> opt_value, Tensor mat) {
    auto r = SpmmMinMax<R_MIN>::apply(rowptr, col, opt_value, mat, auto_plan());
    return std::make_tuple(r[0], r[1]);
@@ -821,6 +837,8 @@ TORCH_LIBRARY(isplib, m) {
          &fusedmm_spmm_max_planned);
    m.def("fusedmm_spmm_min_planned(Tensor rowptr, Tensor col, Tensor? value, Tensor mat, Tensor[] plan) -> (Tensor, Tensor)",
          &fusedmm_spmm_min_planned);
+   m.def("fusedmm_spmm_max_values(Tensor rowptr, Tensor col, Tensor? value, Tensor mat, Tensor[] plan) -> Tensor", &fusedmm_spmm_max_values);
+   m.def("fusedmm_spmm_min_values(Tensor rowptr, Tensor col, Tensor? value, Tensor mat, Tensor[] plan) -> Tensor", &fusedmm_spmm_min_values);
    m.def("gcn_norm_spmm(Tensor rowptr, Tensor col, Tensor mat, Tensor dinv, Tensor? colptr, Tensor? row_t, Tensor[] plan, "
          "Tensor[] plan_t, Tensor? bias, bool relu) -> Tensor",
          &gcn_norm_spmm);

@@ -64,6 +64,26 @@ if "mm" in what:
         del x, z, arg, want, want_arg
     del col32
 
+if "mmv" in what:       # max / min with and without the winners' positions (z_arg = NULL: the values-only launch), the rule's plan
+    for k, weighted in [(int(v.split(":")[0]), v.endswith("w")) for v in os.environ.get("MM_CASES", "64:w,64:u,128:w,32:u").split(",")]:
+        val = w if weighted else None
+        x = synth.features(n, k, device=dev, integer=False)
+        z = torch.empty((n, k), device=dev)
+        z2 = torch.empty((n, k), device=dev)
+        arg = torch.empty((n, k), dtype=torch.int64, device=dev)
+        streams, r_slices, r_chunk = cabi.suggest_stream_minmax(n, n, nnz, k)
+        plan = build_stream_plan(rowptr, col, val, n, r_slices, None, None, streams, r_chunk, minmax=True)
+        ws = plan.workspace(minmax=True)
+        for red in ("max", "min"):
+            msg = cabi.MESSAGE[red]
+            cabi.fusedMM_csr_stream_minmax_hip(msg, rowptr, nnz, plan, x, z, arg, ws)
+            cabi.fusedMM_csr_stream_minmax_hip(msg, rowptr, nnz, plan, x, z2, None, ws)
+            same = torch.equal(z.view(torch.int32), z2.view(torch.int32))
+            t_arg = timeit(lambda: cabi.fusedMM_csr_stream_minmax_hip(msg, rowptr, nnz, plan, x, z, arg, ws))
+            t_val = timeit(lambda: cabi.fusedMM_csr_stream_minmax_hip(msg, rowptr, nnz, plan, x, z2, None, ws))
+            print(f"[mmv] K={k} {'w' if weighted else 'u'} {red} rule {streams}:{r_slices}:{r_chunk}: with arg {t_arg:.3f} ms, values only {t_val:.3f} ms  {'same values' if same else 'VALUES DIFFER'}", flush=True)
+        del plan, ws, x, z, z2, arg
+
 if "sddmm" in what:
     L = cabi.lib()
     for k in (128, 64, 256):

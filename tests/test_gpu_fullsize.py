@@ -325,6 +325,8 @@ def test_config3_reddit_minmax_on_the_stream_schedule(gpu, reddit, oracle_mod, r
     out2, arg2 = cabi.spmm_stream_minmax(rowptr, col.numel(), nat, x, red)
     nat.close()
     assert torch.equal(out, out2) and torch.equal(arg, arg2), "the two plan builders must agree"
+    only, none = cabi.spmm_stream_minmax(rowptr, col.numel(), plan, x, red, want_arg=False)
+    assert none is None and torch.equal(only.view(torch.int32), out.view(torch.int32)), "the values-only launch must give the same values"
     rp, cl, ww, xx = _host(rowptr, col, w, x)
     ref, ref_arg = oracle_mod.spmm_fw(rp, cl, ww, xx, red)
     assert np.array_equal(out.cpu().numpy().view(np.uint32), ref.view(np.uint32)), "values must be bit-exact"

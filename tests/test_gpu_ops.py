@@ -790,6 +790,9 @@ def test_plugin_runs_max_and_min_on_the_stream_schedule(gpu, oracle_mod, monkeyp
                 assert np.array_equal(out.detach().cpu().numpy().view(np.uint32), ref.view(np.uint32)), (red, weighted)
                 _, gm = oracle_mod.spmm_minmax_bw(col, cur, x, ref_arg, g)
                 _close(xs.grad, gm, rtol=1e-5, atol=1e-5)
+                # nothing to differentiate: the values-only launch (torch.ops.isplib.fusedmm_spmm_{max,min}_values), same bits
+                plain = isplib_amd.matmul(adj, _t(x, gpu), red)
+                assert not plain.requires_grad and torch.equal(plain.view(torch.int32), out.detach().view(torch.int32)), (red, weighted)
             if weighted:
                 value.copy_(_t(val1, gpu))
         assert any(k[-1] == "minmax" and adj.storage._streams[k] is not None for k in adj.storage._streams), "the max / min stream plan was not used"
