@@ -152,10 +152,18 @@ def extra_configs(dev, rowptr, col, n, with_cpu_epoch=True):
         geom = cabi.suggest_stream(n, n, nnz, k, val is not None) if red in ("sum", "mean") else None
         geom_mm = cabi.suggest_stream_minmax(n, n, nnz, k) if red in ("max", "min") else None
         mplan = None if geom_mm is None else build_stream_plan(rowptr, col, val, n, geom_mm[1], None, None, geom_mm[0], geom_mm[2], minmax=True)
+        more = {}
         if mplan is not None:
             ws = mplan.workspace(minmax=True)
             ms = _time_launches(lambda: cabi.fusedMM_csr_stream_minmax_hip(msg, rowptr, nnz, mplan, x, z, arg, ws))
             sched = f"stream (max / min kernel), {mplan.slices} slices, {mplan.gens} generation(s)"
+            # the same launch without the winners' positions (z_arg = NULL: what the plug-in runs when no gradient can be
+            # asked for); same plan; its values are compared with the launch above, bit for bit, outside the timing
+            z2 = torch.empty_like(z)
+            cabi.fusedMM_csr_stream_minmax_hip(msg, rowptr, nnz, mplan, x, z2, None, ws)
+            more = {"values_only_ms": _time_launches(lambda: cabi.fusedMM_csr_stream_minmax_hip(msg, rowptr, nnz, mplan, x, z2, None, ws)),
+                    "values_only_same_bits": bool(torch.equal(z.view(torch.int32), z2.view(torch.int32)))}
+            del z2
         elif geom is not None:
             plan = build_stream_plan(rowptr, col, val, n, geom[1], None, None, geom[0], geom[2])
             ws = plan.workspace()
@@ -167,7 +175,7 @@ def extra_configs(dev, rowptr, col, n, with_cpu_epoch=True):
             ws = plan.workspace(red, k)
             ms = _time_launches(lambda: cabi.fusedMM_csr_tasks_hip(msg, rowptr, col, val, plan, x, z, arg, ws))
             sched = f"task list, {sl} slices"
-        entry(name, ms, n, n, nnz, k, arg is not None, sched, key=key or f"reddit-{red}-k{k}-weighted")
+        entry(name, ms, n, n, nnz, k, arg is not None, sched, key=key or f"reddit-{red}-k{k}-weighted", **more)
 
     only = os.environ.get("ISPLIB_BENCH_ONLY", "")          # profiling: one configuration (its traffic.json key) instead of all
     for red in ("mean", "max", "min"):
