@@ -539,3 +539,53 @@ def test_hybrid_epilogue_and_status_codes(gpu, oracle_mod):
     odd = plan.struct()
     odd.cold.waves_per_gen = 12
     assert call(cabi.MSG_SPMM_SUM, ctypes.byref(odd)) == 1
+
+
+def test_stream_entries_can_be_captured_in_a_hip_graph(gpu, oracle_mod):
+    """The planned entries do nothing on the hot path but launch kernels on the caller's stream (no allocation, no
+    synchronisation, no host read-back: the workspace and the plan are the caller's), so a training loop can capture them in a
+    HIP graph (torch.cuda.CUDAGraph is one on ROCm) and replay it: sum on the stream schedule (two generations, a hub fold),
+    max with positions, and the values-only max, replayed on NEW operand values written into the captured buffers, against
+    the eager calls bit for bit and against the oracle."""
+    from isplib_amd import cabi
+    from isplib_amd.plan import build_stream_plan
+    rowptr, col = cases.random_csr(700, 600, 25.0, seed=21, empty_rows=(0, 350), hub=(11, 5000))
+    val = cases.weights(col.size, 4)
+    d_rowptr, d_col, d_val = _t(rowptr, gpu), _t(col, gpu), _t(val, gpu)
+    k = 72
+    xs = [cases.dense(600, k, 3), cases.dense(600, k, 8)]
+    x = _t(xs[0], gpu)
+    plan = build_stream_plan(d_rowptr, d_col, d_val, 600, 4, 3, None, 2, 300)
+    mplan = build_stream_plan(d_rowptr, d_col, d_val, 600, 3, 3, None, 4, 300, minmax=True)
+    assert plan.gens > 1 and plan.n_hub > 0
+    ws, mws = plan.workspace(), mplan.workspace(minmax=True)
+    z, zm, zv = (torch.empty((700, k), device=gpu) for _ in range(3))
+    arg = torch.empty((700, k), dtype=torch.int64, device=gpu)
+
+    def step():
+        cabi.fusedMM_csr_stream_hip(cabi.MESSAGE["sum"], d_rowptr, col.size, plan, x, z, ws)
+        cabi.fusedMM_csr_stream_minmax_hip(cabi.MESSAGE["max"], d_rowptr, col.size, mplan, x, zm, arg, mws)
+        cabi.fusedMM_csr_stream_minmax_hip(cabi.MESSAGE["max"], d_rowptr, col.size, mplan, x, zv, None, mws)
+
+    side = torch.cuda.Stream(device=gpu)
+    side.wait_stream(torch.cuda.current_stream(gpu))
+    with torch.cuda.stream(side):
+        step()                                               # warm-up outside the capture (module load, first-call paths)
+    torch.cuda.current_stream(gpu).wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    for host_x in (xs[1], xs[0]):
+        x.copy_(_t(host_x, gpu))
+        z.zero_(); zm.zero_(); zv.zero_(); arg.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        got = (z.clone(), zm.clone(), zv.clone(), arg.clone())
+        step()
+        torch.cuda.synchronize()
+        for a_, b_ in zip(got, (z, zm, zv, arg)):
+            assert torch.equal(a_.view(torch.int32) if a_.dtype == torch.float32 else a_, b_.view(torch.int32) if b_.dtype == torch.float32 else b_)
+        _check(oracle_mod, rowptr, col, val, host_x, "sum", got[0], None)
+        _check(oracle_mod, rowptr, col, val, host_x, "max", got[1], got[3])
+        assert torch.equal(got[1].view(torch.int32), got[2].view(torch.int32))
