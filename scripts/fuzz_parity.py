@@ -105,6 +105,12 @@ def main():
                     cabi.fusedMM_csr_stream_hip(cabi.MESSAGE[red], d_rowptr, col.size, splan, d_x, out, splan.workspace())
                 elif name == "stream" and mplan is not None and red in ("max", "min"):
                     cabi.fusedMM_csr_stream_minmax_hip(cabi.MESSAGE[red], d_rowptr, col.size, mplan, d_x, out, arg, mplan.workspace(minmax=True))
+                    # the values-only launch (z_arg = NULL: the kernel without its index registers): same plan, same bits
+                    only = torch.full((m, ld), 7.0, device=dev)[:, :k]
+                    cabi.fusedMM_csr_stream_minmax_hip(cabi.MESSAGE[red], d_rowptr, col.size, mplan, d_x, only, None, mplan.workspace(minmax=True))
+                    if not torch.equal(only.contiguous().view(torch.int32), out.contiguous().view(torch.int32)):
+                        bad += 1
+                        print(f"MISMATCH case {case}: stream/{red} values-only differs from the launch with positions, m={m} n={n} k={k}", flush=True)
                 elif name == "sweep" and wplan is not None:
                     cabi.fusedMM_csr_sweep_hip(cabi.MESSAGE[red], d_rowptr, d_col, d_val, wplan, d_x, out, arg, wplan.workspace(red, k))
                 elif name == "ordered":
