@@ -80,6 +80,9 @@ def test_torch_ops_have_reference_names_and_schemas():
         s = str(getattr(ops, name).default._schema)
         assert "Tensor rowptr, Tensor col, Tensor? value, Tensor mat" in s and "-> (Tensor, Tensor)" in s
     assert "int flag" in str(ops.performDummySpMM.default._schema)
+    for name in ("fusedmm_spmm_max_values", "fusedmm_spmm_min_values"):      # not the reference's: the plug-in's no-gradient path
+        s = str(getattr(ops, name).default._schema)
+        assert "Tensor rowptr, Tensor col, Tensor? value, Tensor mat, Tensor[] plan" in s and s.endswith("-> Tensor")
 
 
 def test_cpu_tensors_are_refused_not_silently_served():
@@ -90,6 +93,8 @@ def test_cpu_tensors_are_refused_not_silently_served():
         torch.ops.isplib.fusedmm_spmm(None, rowptr, col, None, None, None, x, None, None)
     with pytest.raises(RuntimeError, match="no CPU path"):
         torch.ops.isplib.fusedmm_spmm_max(rowptr, col, None, x)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        torch.ops.isplib.fusedmm_spmm_max_values(rowptr, col, None, x, [])
     adj = isplib_amd.SparseTensor.from_csr(rowptr, col, None, (2, 2))
     with pytest.raises(RuntimeError, match="no CPU path"):
         isplib_amd.matmul(adj, x)
