@@ -1033,9 +1033,11 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, 2 * (NVMAX + 1), WGS>(
    auto fetch = [&](int u, const unsigned (&word_l)[NBW]) {
       return (unsigned)__builtin_amdgcn_ds_bpermute(g4 + (int)(((u * G) % 64) * 4), (int)word_l[(u * G) / 64]);
    };
+   // la[u] keeps the WORD of step u as it is: its top byte, the local row, is compared byte against byte when the gather is
+   // consumed (one SDWA compare) and only becomes an LDS offset inside the rare change of row -- no shift per step
    auto issue = [&](int u, unsigned word) {
       const unsigned o = __umul24(word, ldyb) + cbyte;
-      la[u] = (word >> 24) * (unsigned)PANEL;
+      la[u] = word;
       t[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)o, 0, 0);
    };
    load_words(0, w1);
@@ -1045,7 +1047,8 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, 2 * (NVMAX + 1), WGS>(
    load_words(64 * NBW, w1);
    load_vals(64 * NBW, v1);
    load_words(128 * NBW, w2);
-   unsigned cur = (unsigned)(g * PER * PANEL);
+   unsigned cur = (unsigned)(g * PER * PANEL);            // LDS offset of the row the registers hold ...
+   unsigned curw = (unsigned)(g * PER) << 24;             // ... and that row as the top byte of a word
    float acc[4];
    int bi[4];
 #pragma unroll
@@ -1054,8 +1057,10 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, 2 * (NVMAX + 1), WGS>(
    // disjoint rows (the spare row is written by all and read back by nobody who cares) and a wave's LDS operations execute
    // in order, so a later visit of a row reads what the last one stored.
    // (reads first: the wave then waits for the loads only -- the stores just have to be issued)
-   auto swap_to = [&](unsigned nxt) {
-      asm volatile("" : "+v"(nxt));                      // keeps the LDS address arithmetic inside the branch (one vector instruction per step otherwise)
+   auto swap_to = [&](unsigned nxt_word) {
+      asm volatile("" : "+v"(nxt_word));                 // keeps the LDS address arithmetic inside the branch (one vector instruction per step otherwise)
+      const unsigned nxt = (nxt_word >> 24) * (unsigned)PANEL;
+      curw = nxt_word;
       const float4 o = *reinterpret_cast<const float4 *>(lane_base + nxt);
       if constexpr (ARG) {
          const int4 oi = *reinterpret_cast<const int4 *>(lane_idx + nxt);
@@ -1082,7 +1087,12 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, 2 * (NVMAX + 1), WGS>(
          if (HAS_VAL && u + 1 < U)
             vnext = __int_as_float(__builtin_amdgcn_ds_bpermute(g4 + (int)((((u + 1) * G) % 64) * 4), __float_as_int(v0[((u + 1) * G) / 64])));
          if (u + 1 < U) wnext = fetch(u + 1, w1);
-         if (la[u] != cur) swap_to(la[u]);              // per lane: the slots of a wave change rows at different steps
+         // per lane: the slots of a wave change rows at different steps.  ONE vector instruction: the top bytes of the two words
+         // compared in place (SDWA), the lane mask handed to the branch as it is -- written in C++ the test becomes xor + compare,
+         // and with the row offset kept per step, shift + compare (round 4, second session: 18 -> 17 instructions per step)
+         unsigned long long row_changes;
+         asm("v_cmp_ne_u32_sdwa %0, %1, %2 src0_sel:BYTE_3 src1_sel:BYTE_3" : "=s"(row_changes) : "v"(la[u]), "v"(curw));
+         if (__builtin_amdgcn_inverse_ballot_w64(row_changes)) swap_to(la[u]);
          const int mark = widx0 + u * G;                 // what a winner of this step is remembered by: its word index
          v2f_t x01 = {__int_as_float(t[u][0]), __int_as_float(t[u][1])};
          v2f_t x23 = {__int_as_float(t[u][2]), __int_as_float(t[u][3])};
