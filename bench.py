@@ -832,6 +832,7 @@ def self_launch(a, argv) -> int:
     limit = float(os.environ.get("ISPLIB_BENCH_LAUNCH_TIMEOUT", "540"))
     t_start = time.monotonic()
     last_rc = 3
+    history = []                 # one record per attempt that ended WITHOUT a line: what the relayed line's "launch" field tells
     for attempt, extra_env in enumerate(({}, {"ISPLIB_OVERLAP": "0", "ISPLIB_BENCH_NO_DIST_EXTRA": "1"})):
         left = limit - (time.monotonic() - t_start)
         if attempt and (left < 90 or os.environ.get("ISPLIB_BENCH_NO_RETRY") == "1"):
@@ -843,6 +844,7 @@ def self_launch(a, argv) -> int:
         print("[bench] launching" + (" again, north_star form only" if attempt else "") + ": " + " ".join(cmd), file=sys.stderr, flush=True)
         proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, start_new_session=True, env=dict(os.environ, **extra_env))
         timed_out = False
+        stdout = ""                                               # per attempt: never the previous attempt's output
         try:
             stdout, _ = proc.communicate(timeout=max(left, 1.0))
         except subprocess.TimeoutExpired:
@@ -851,10 +853,16 @@ def self_launch(a, argv) -> int:
                 try:
                     os.killpg(proc.pid, sig)                          # the launcher AND every rank it started
                 except ProcessLookupError:
-                    break
+                    pass                                              # the group is gone already: collect what it wrote
                 try:
                     stdout, _ = proc.communicate(timeout=wait)
                     break
+                except subprocess.TimeoutExpired:
+                    stdout = ""
+            else:
+                proc.kill()                                           # still there after SIGKILL to the group: the child itself
+                try:
+                    stdout, _ = proc.communicate(timeout=5)
                 except subprocess.TimeoutExpired:
                     stdout = ""
         line = None
@@ -870,9 +878,17 @@ def self_launch(a, argv) -> int:
             if timed_out or proc.returncode != 0:
                 print(f"bench.py: the {a.gpus}-rank run ended abnormally (exit {proc.returncode}{', time limit' if timed_out else ''}) "
                       "after its result was measured", file=sys.stderr)
-            print(line, flush=True)
+            # the relayed line says how it came about: a clean first attempt and a line from the retry (fresh children,
+            # north_star form only, after a first attempt that failed) must not look the same to whoever parses it
+            rec = json.loads(line)
+            rec["launch"] = {"attempts": attempt + 1, "restricted_to_north_star_form": bool(attempt),
+                             "this_attempt": {"rc": proc.returncode, "timed_out": timed_out}}
+            if history:
+                rec["launch"]["first_attempt"] = history[0]
+            print(json.dumps(rec), flush=True)
             return 0
         last_rc = 124 if timed_out else (proc.returncode or 3)
+        history.append({"rc": last_rc, "timed_out": timed_out, "seconds": round(time.monotonic() - t_start, 1)})
         print(f"bench.py: the {a.gpus}-rank run failed (exit {last_rc}{', time limit' if timed_out else ''}, no JSON line)", file=sys.stderr, flush=True)
     return last_rc
 

@@ -203,15 +203,20 @@ static int check_row_order(int64_t rows, const int32_t *order) {
       (void)hipGetLastError();
       return fail(ISPLIB_NOT_ENOUGH_MEM, "isplib_graph_set_row_order: device allocation failed");
    }
-   bool ok = hipMemset(seen, 0, ((size_t)rows + 1) * sizeof(int)) == hipSuccess;
-   if (ok) {
+   // The order arrays carry no stream: whatever produced them (a kernel on a non-blocking side stream, say) must be complete
+   // before they are read here, and the null stream does not wait for such streams -- so the device is drained first.  This
+   // is a once-per-graph call that already allocates and copies back; one more synchronisation costs it nothing.
+   hipError_t err = hipDeviceSynchronize();
+   if (err == hipSuccess) err = hipMemset(seen, 0, ((size_t)rows + 1) * sizeof(int));
+   if (err == hipSuccess) {
       int64_t blocks = (rows + 255) / 256;
       if (blocks > 4096) blocks = 4096;
       hipLaunchKernelGGL(order_check_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, rows, order, seen, seen + rows);
-      ok = hipGetLastError() == hipSuccess && hipMemcpy(&host, seen + rows, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+      err = hipGetLastError();                               // read ONCE: a second call would report success
+      if (err == hipSuccess) err = hipMemcpy(&host, seen + rows, sizeof(int), hipMemcpyDeviceToHost);
    }
    (void)hipFree(seen);
-   if (!ok) return hip_fail(hipGetLastError(), "isplib_graph_set_row_order: checking the order");
+   if (err != hipSuccess) return hip_fail(err, "isplib_graph_set_row_order: checking the order");
    if (host) return fail(ISPLIB_FAIL, host & 1 ? "isplib_graph_set_row_order: an entry of the order is outside [0, rows)"
                                                : "isplib_graph_set_row_order: the order is not a permutation (a row appears twice)");
    return ISPLIB_SUCCESS;
@@ -481,7 +486,10 @@ static int run_side(isplib_graph *g, Side &s, const float *val, int32_t imessage
    }
    // max / min on such graphs: the stream schedule's own kernel and plan geometry, for column-sorted rows
    int mm_streams = 0, mm_slices = 0, mm_chunk = 0;
-   if (minmax && g->forced_slices < 0 && !s.minmax_stream_refused && ldy < (1LL << 22) && y_in_one_descriptor &&
+   // (the max / min entry admits dense operands under 2 GiB WITH THE CALLER'S ldy -- lanes past column k carry 2^31 in their
+   // column term -- while the rule only sees k: a padded leading dimension that crosses it stays on the task list)
+   const bool y_under_2gib = (double)s.n * (double)ldy * 4.0 < 2147483648.0;
+   if (minmax && g->forced_slices < 0 && !s.minmax_stream_refused && ldy < (1LL << 22) && y_in_one_descriptor && y_under_2gib &&
        isplib_suggest_stream_minmax(s.m, s.n, s.nnz, k, &mm_streams, &mm_slices, &mm_chunk)) {
       mm_slices = skew_adjusted(s, mm_slices, st, 512);
       const uint64_t key = (1ULL << 63) | ((uint64_t)mm_streams << 48) | ((uint64_t)mm_slices << 32) | (uint64_t)(uint32_t)mm_chunk;

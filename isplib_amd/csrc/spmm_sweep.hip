@@ -329,7 +329,9 @@ __global__ __launch_bounds__(256) void sweep_hub_fold_kernel(const SweepArgs a) 
             if (OP == OP_ADD) {
                v[q] += t[q];
             } else {
-               const int oi = a.part_idx[po + q];
+               // a values-only launch (z_arg == NULL) never wrote part_idx: the chunk's ordinal stands in for its position --
+               // chunks are in CSR order, so among equal values the earliest chunk stays, exactly as with real positions
+               const int oi = a.z_arg ? a.part_idx[po + q] : p;
                const bool take = better<OP>(t[q], oi, v[q], bi[q]);
                v[q] = take ? t[q] : v[q];
                bi[q] = take ? oi : bi[q];
@@ -1141,7 +1143,8 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, 2 * (NVMAX + 1), WGS>(
 #pragma unroll
       for (int jj = 0; jj < PER; jj++)
 #pragma unroll
-         for (int i = 0; i < 4; i++) best_[jj][i] = (row_[jj] >= 0 && best_[jj][i] != INT_MAX) ? ids[best_[jj][i]] : INT_MAX;
+         for (int i = 0; i < 4; i++)   // (a word index outside the wave's stream -- INT_MAX = no winner -- never reaches the subscript)
+            best_[jj][i] = (row_[jj] >= 0 && (unsigned)best_[jj][i] < (unsigned)nwords) ? ids[best_[jj][i]] : INT_MAX;
    }
 #pragma unroll
    for (int jj = 0; jj < PER; jj++) {

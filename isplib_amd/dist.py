@@ -169,6 +169,7 @@ class RowPartition:
         the fold follow once it has landed.  Same slices and fold order as the non-overlapped sliced
         call, so the result is bitwise identical to it."""
         from . import cabi
+        self._parked = None          # an error an EARLIER exchange left behind (its waits raised before _raise_parked) is not this one's
         s, table, work = plan
         k = x_shard.size(1)
         msg = cabi.MESSAGE[reduce]
@@ -232,6 +233,7 @@ class RowPartition:
         order as `fusedMM_csr_sliced_hip` over the gathered buffer: bitwise equal to it for every reduction.
         `plan` = self.plan(k, reduce) (slice count a multiple of world).  batches = P-1 gives per-peer completion."""
         from . import cabi
+        self._parked = None          # an error an EARLIER exchange left behind (its waits raised before _raise_parked) is not this one's
         s, table, work = plan
         k = x_shard.size(1)
         msg = cabi.MESSAGE[reduce]
@@ -321,6 +323,7 @@ class RowPartition:
         panel width).  A K = 128 aggregation costs the same as two K = 64 ones on this hardware (DESIGN.md
         section 5), so the panels are free on the compute side and hide all but the first panel's transfer."""
         from . import cabi
+        self._parked = None          # an error an EARLIER exchange left behind (its waits raised before _raise_parked) is not this one's
         bounds, send, recv, tplan, work = state
         msg = cabi.MESSAGE[reduce]
         handles = []

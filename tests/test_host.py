@@ -908,6 +908,36 @@ def test_bench_launcher_has_a_time_limit_and_ends_the_process_group(tmp_path, mo
     assert marker.read_text().split() == ["1", "0"]       # first the full run, then once more restricted to the north_star form
 
 
+def test_bench_launcher_stamps_a_retry_into_the_line_it_relays(tmp_path, monkeypatch, capsys):
+    """A first attempt that fails without a JSON line and a clean retry must not look like a clean run: the relayed line
+    carries `launch` = attempts, the first attempt's exit code / time-limit flag, and that the retry was restricted to the
+    north_star form.  A clean first attempt says attempts = 1 and has no `first_attempt`."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    child = tmp_path / "child.py"
+    # first attempt (ISPLIB_OVERLAP unset): dies with exit 9 and no line; the retry (ISPLIB_OVERLAP=0) prints a result
+    child.write_text("import json, os, sys\n"
+                     "if os.environ.get('ISPLIB_OVERLAP', '1') != '0' and os.environ.get('CLEAN') != '1':\n"
+                     "    print('rank 1 aborted'); sys.exit(9)\n"
+                     "print(json.dumps({'metric': 'edges_aggregated_per_sec', 'value': 1.0, 'n_gpus': 2}))\n")
+    monkeypatch.setattr(bench, "launcher_command", lambda gpus, argv, port: [sys.executable, str(child)])
+    monkeypatch.setattr(bench, "visible_gpu_count", lambda *a_, **k_: 8)
+    monkeypatch.setenv("ISPLIB_BENCH_LAUNCH_TIMEOUT", "200")
+    assert bench.self_launch(types.SimpleNamespace(gpus=2), ["--gpus", "2"]) == 0
+    lines = _json_lines(capsys.readouterr().out)
+    assert len(lines) == 1
+    launch = lines[0]["launch"]
+    assert launch["attempts"] == 2 and launch["restricted_to_north_star_form"] is True
+    assert launch["first_attempt"]["rc"] == 9 and launch["first_attempt"]["timed_out"] is False
+    assert launch["this_attempt"] == {"rc": 0, "timed_out": False}
+    monkeypatch.setenv("CLEAN", "1")
+    assert bench.self_launch(types.SimpleNamespace(gpus=2), ["--gpus", "2"]) == 0
+    lines = _json_lines(capsys.readouterr().out)
+    assert lines[0]["launch"] == {"attempts": 1, "restricted_to_north_star_form": False, "this_attempt": {"rc": 0, "timed_out": False}}
+
+
 def test_exchange_schedules_park_local_kernel_errors_until_their_collectives_are_done():
     """isplib_amd.dist.RowPartition._kernel / _raise_parked: the first local kernel failure of an exchange is parked (later
     kernels of the same exchange are skipped, its communication is not), raised once the exchange is complete and marked
