@@ -112,6 +112,64 @@ def _time_launches(fn, reps=5, warm=2):
     return s.elapsed_time(e) / reps
 
 
+XGMI_LINK_GBPS = 153.0    # one xGMI link of the MI355X full mesh (7 per GPU), the figure SURVEY.md 8(e) / BASELINE.md use
+
+
+def scaling_emulated(dev, rowptr, col, n, k, label, one_gpu_ms=None, ranks=(2, 4, 8)):
+    """The COMPUTE half of the 1 -> 8 GPU curve, under this run's clock, on ONE GPU -- no RCCL call is made and nothing
+    here is a multi-GPU measurement.  For P in `ranks`, every rank's RowPartition (1-D rows, nnz-balanced: exactly what
+    `bench.py --gpus P` builds on rank p) is built on this device, the padded gather buffer is filled locally with what
+    all_gather_into_tensor would leave in it, and the rank's local SpMM runs on the schedule `RowPartition.local_ops`
+    picks for the shard (the single-GPU rules: what `spmm_auto` runs after its one all-gather).  Reported per P: max /
+    mean over ranks of the local SpMM (HIP events, 5 launches each), per-rank nnz balance, the all-gather's bytes per
+    rank, and the exchange MODELLED two ways over xGMI at 153 GB/s per link -- every peer's shard on its own link
+    (direct: one shard time) and a ring (P - 1 shard times) -- with the step that follows if exchange and compute do
+    not overlap at all (sum) or overlap perfectly (max)."""
+    from isplib_amd import synth
+    from isplib_amd.dist import RowPartition
+    nnz = col.numel()
+    x = synth.features(n, k, device=dev)
+    rec = {"what": "EMULATED ON ONE GPU, NO RCCL: per-rank local SpMM of the 1-D row partition timed rank by rank on this device; "
+                   "the exchange is a model (xGMI 153 GB/s per link), not a measurement",
+           "workload": label, "k": k, "one_gpu_ms": one_gpu_ms, "points": []}
+    for world in ranks:
+        buf, per_rank = None, []
+        for rank in range(world):
+            part = RowPartition(rowptr, col, None, n, rank, world)
+            if buf is None:
+                buf = part.gather_buffer(k, dev)
+                buf.zero_()
+                for p_ in range(world):
+                    r0, r1 = part.x_cuts[p_], part.x_cuts[p_ + 1]
+                    buf[p_ * part.max_rows: p_ * part.max_rows + (r1 - r0)] = x[r0:r1]
+                shard_bytes = part.max_rows * k * 4
+            ops = part.local_ops(k, "sum")
+            out = torch.empty((part.rows, k), dtype=torch.float32, device=dev)
+            ms = _time_launches(lambda: part.local_spmm(ops, buf, out, "sum"))
+            sched = ops[0] if ops[0] != "stream" else f"stream ({ops[1].streams} streams, {ops[1].slices} slices, {ops[1].gens} generation(s))"
+            per_rank.append({"rank": rank, "rows": part.rows, "nnz": part.nnz, "schedule": sched, "ms": round(ms, 4)})
+            del part, ops, out
+        del buf
+        torch.cuda.empty_cache()
+        t = [r["ms"] for r in per_rank]
+        e = [r["nnz"] for r in per_rank]
+        direct_ms = shard_bytes / (XGMI_LINK_GBPS * 1e9) * 1e3
+        ring_ms = (world - 1) * direct_ms
+        compute_ms = max(t)
+        rec["points"].append({
+            "ranks": world, "local_spmm_ms_max": compute_ms, "local_spmm_ms_mean": sum(t) / world,
+            "nnz_balance_max_over_mean": max(e) / (sum(e) / world), "schedules": sorted({r["schedule"] for r in per_rank}),
+            "all_gather_bytes_sent_per_rank": shard_bytes, "all_gather_bytes_received_per_rank": (world - 1) * shard_bytes,
+            "exchange_model_ms": {"direct_one_link_per_peer": direct_ms, "ring": ring_ms},
+            "step_model_ms": {"direct, no overlap": compute_ms + direct_ms, "direct, full overlap": max(compute_ms, direct_ms),
+                              "ring, no overlap": compute_ms + ring_ms},
+            "edges_per_s_model": {"compute only": nnz / (compute_ms * 1e-3), "direct, no overlap": nnz / ((compute_ms + direct_ms) * 1e-3)},
+            "compute_speedup_over_one_gpu": None if not one_gpu_ms else one_gpu_ms / compute_ms,
+            "per_rank": per_rank})
+    del x
+    return rec
+
+
 def extra_configs(dev, rowptr, col, n, with_cpu_epoch=True):
     """The other configurations of BASELINE.json under the same clock as the headline (N = 1, outside its timed region):
     config 3 (Reddit-shaped mean / max / min, K=64, weighted), config 2 with weights, config 4's shape on one GPU
@@ -198,9 +256,24 @@ def extra_configs(dev, rowptr, col, n, with_cpu_epoch=True):
         h.close()
         del xs, gs
     del w, col32
-    if only and not only.startswith("products") and only != "gcn-epoch":
+    if only and not only.startswith("products") and only not in ("gcn-epoch", "scaling-emulated-reddit"):
         return out
 
+    if not only or only == "scaling-emulated-reddit":
+        # the headline's own workload on P = 2 / 4 / 8 emulated ranks (compute half of the north_star metric's curve)
+        one = None
+        if not only:
+            g1 = cabi.suggest_stream(n, n, nnz, 128, False)
+            if g1 is not None:
+                from isplib_amd.plan import build_stream_plan_native
+                p1 = build_stream_plan_native(rowptr, col, n, skew_adjusted(rowptr, g1[1], cap=512), g1[0], g1[2])
+                x1, z1, w1 = synth.features(n, 128, device=dev), torch.empty((n, 128), dtype=torch.float32, device=dev), p1.workspace()
+                one = _time_launches(lambda: cabi.fusedMM_csr_stream_hip(cabi.MSG_SPMM_SUM, rowptr, nnz, p1, x1, z1, w1))
+                del p1, x1, z1, w1
+        out.append({"config": "scaling_emulated, config 2: reddit-like SpMM-sum K=128, unit weights, 1-D row partition over 2 / 4 / 8 emulated ranks",
+                    "scaling_emulated": scaling_emulated(dev, rowptr, col, n, 128, f"reddit-like (N={n}, nnz={nnz})", one)})
+        if only:
+            return out
     if not only or only == "gcn-epoch":
         out.append(gcn_epoch_config(dev, rowptr, col, n, with_cpu_epoch and not only))
         if only:
@@ -251,6 +324,29 @@ def gcn_epoch_config(dev, rowptr, col, n, with_cpu_epoch):
     gpu_epoch_ms = statistics.mean(times) * 1e3
     rec = {"config": "config 5: 2-layer GCN 602-32-41 epoch on the reddit-like graph through iSpLibPlugin.patch_pyg (6 SpMM + dense + Adam)",
            "ms": gpu_epoch_ms, "epoch_ms_std": statistics.pstdev(times) * 1e3, "epochs_timed": len(times)}
+    # the same epoch with GCNConv(normalize=True) (tests/dist/gcn/pyg-sparse.py:61-62) on the library's fused layer
+    # (isplib_amd.gcn_norm_matmul: D^-1/2 (A + I) D^-1/2, bias and ReLU inside the aggregation's write-back; backward prologue --
+    # ReLU mask, D^-1/2, bias gradient -- one HIP pass): beside the unchanged-PyG epoch above, not instead of it
+    model_n = ge.Net(feats, hidden, classes, normalize=True).to(dev)
+    opt_n = torch.optim.Adam(model_n.parameters(), lr=0.01, weight_decay=5e-4)
+    times_n = []
+    for epoch in range(6):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model_n.train()
+        opt_n.zero_grad()
+        o = model_n(x, adj, isplib_amd.matmul)
+        loss = F.nll_loss(o[mask], y[mask], reduction="sum") / n_train
+        loss.backward()
+        opt_n.step()
+        model_n(x, adj, isplib_amd.matmul).argmax(1)
+        torch.cuda.synchronize()
+        if epoch:
+            times_n.append(time.perf_counter() - t0)
+    rec["normalize_true_fused"] = {"ms": statistics.mean(times_n) * 1e3, "epoch_ms_std": statistics.pstdev(times_n) * 1e3, "epochs_timed": len(times_n),
+                                   "what": "GCNConv(normalize=True) epoch: every aggregation is torch.ops.isplib.gcn_norm_spmm (self loop, "
+                                           "D^-1/2 on both sides, bias, ReLU fused; backward prologue one HIP pass)"}
+    del model_n, opt_n
     if with_cpu_epoch:
         # the same epoch on the host cores with the oracle doing every aggregation (the reference's CPU mode `isplib`,
         # tests/cpu/gcn-sparse.py:29-36,83-92): A is symmetric with unit weights here, so A^T dY is the same call
@@ -308,7 +404,7 @@ def products_configs(dev, only=""):
     out = []
     k = 256
     for tag, make in (("chunglu", lambda: synth.dataset_like("products", device=dev)), ("sbm", lambda: synth.sbm_like("products", device=dev))):
-        if only and not only.startswith(f"products-{tag}"):
+        if only and not only.startswith(f"products-{tag}") and not (tag == "chunglu" and only == "scaling-emulated-products"):
             continue
         torch.cuda.empty_cache()
         p_rowptr, p_col, pn = make()
@@ -356,6 +452,13 @@ def products_configs(dev, only=""):
                         **({} if identical is None else {"bit_identical_to_index_order": identical, "checked": f"torch.equal over all {pn} x {k} outputs, this run"}),
                         "order_search": ("a community order was kept" if order is not None else
                                          f"looked for a community order ({search_ms:.0f} ms, once): none worth keeping, index order")})
+        if tag == "chunglu" and (not only or only == "scaling-emulated-products"):
+            plain_ms = next((o_["ms"] for o_ in out if "index order" in o_.get("schedule", "") and "Chung-Lu" in o_["config"]), None)
+            del px, pz
+            torch.cuda.empty_cache()
+            out.append({"config": "scaling_emulated, config 4: products-like SpMM-sum K=256, unit weights, 1-D row partition over 2 / 4 / 8 emulated ranks",
+                        "scaling_emulated": scaling_emulated(dev, p_rowptr, p_col, pn, k, f"products-like Chung-Lu (N={pn}, nnz={e})", plain_ms)})
+            px = pz = None
         del p_rowptr, p_col, px, pz, order, plain_result
     return out
 
@@ -936,7 +1039,7 @@ def main():
         os.environ["ISPLIB_BENCH_ONLY"] = a.only
         for kv in filter(None, a.tune.split(",")):
             _cabi.lib().isplib_hip_tune(int(kv.split("=")[0]), int(kv.split("=")[1]))
-        if a.only.startswith("products"):
+        if a.only.startswith("products") or a.only == "scaling-emulated-products":
             extra = products_configs(dev, a.only)
         else:
             g_rowptr, g_col, g_n = _synth.dataset_like("reddit", device=dev)

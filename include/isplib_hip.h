@@ -74,6 +74,21 @@ int         isplib_hip_abi_version(void);
 const char *isplib_hip_last_error(void);   /* thread-local, "" if none */
 
 /*
+ * The one convention of this path that nothing in the reference tree pins: what an EMPTY row of a max / min SpMM holds.
+ * The reference launcher pre-fills the output with lowest() / max() and the positions with nnz (csrc/fusedmm.cpp:147-150,
+ * 171,177) and hands them to fusedMM_csr, whose body is not in the tree (configure:2-7).
+ *   0 "zero" (default)  the row is 0 -- torch_sparse's CPU kernel, the one the iSpLib authors compared against
+ *                       (isplib/__init__.py:120-128), and what oracle/ restates
+ *   1 "init"            the row keeps the launcher's pre-fill, -FLT_MAX (max) / +FLT_MAX (min) -- what a body returns
+ *                       that only visits stored entries
+ * The positions are nnz either way; sum / mean are 0 either way.  Process-wide, every schedule; read once from the
+ * environment (ISPLIB_EMPTY_ROW=init|zero) unless set here first.  A maintainer who holds the real fusedmm_cpu.a picks
+ * whichever it does.
+ */
+int isplib_hip_set_empty_row(int init);
+int isplib_hip_get_empty_row(void);
+
+/*
  * SpMM with the reference's 20-argument FusedMM signature, device pointers.
  *
  *   z[i,:] = REDUCE_{j in [pntrb[i], pntre[i])}  val[j] * y[indx[j], :]
@@ -88,7 +103,7 @@ const char *isplib_hip_last_error(void);   /* thread-local, "" if none */
  *   - val may be NULL = unit weights (what isplib/__init__.py:51-57
  *     materialises as a ones vector); the stream is then never read.
  *   - MAX/MIN: strict compare in CSR order (lowest CSR position wins ties, NaN
- *     never wins); empty row -> value 0, z_arg = nnz.  z_arg (int64, same
+ *     never wins); empty row -> value 0 (or the launcher's init value: isplib_hip_set_empty_row), z_arg = nnz.  z_arg (int64, same
  *     leading dimension as z) holds ABSOLUTE CSR positions; may be NULL.
  *   - x/ldx/alpha/rows/cols are accepted and ignored, as in the reference.
  * Requirements: n < 2^31, every row's degree < 2^31, ldy >= k, ldz >= k.
@@ -284,6 +299,26 @@ int    fusedMM_csr_tasks_epilogue_hip(int32_t imessage, int64_t m, int64_t n, in
                                       const float *y, int64_t ldy, float *z, int64_t ldz,
                                       void *workspace, size_t workspace_bytes,
                                       const isplib_epilogue *epilogue /*host, may be NULL*/,
+                                      void *stream);
+
+/*
+ * The dense passes either side of the fused GCN aggregation (epilogue above with self = y, row_scale = D^-1/2), one launch each,
+ * no atomics (the column sums are per-block partials folded in block order: bitwise reproducible):
+ *   isplib_row_scale_hip            y[i,c] = scale[i] * x[i,c], c < k; columns k..ldy-1 of y are written 0 -- y = D^-1/2 X at
+ *                                   whatever pitch the gather wants (a 33..47-column operand at 48 floats touches 2 lines
+ *                                   per row instead of 2.25)
+ *   isplib_masked_scale_colsum_hip  the backward's prologue, reading dz (and out) once:
+ *                                   g[i,c] = out ? (out[i,c] > 0 ? dz[i,c] : 0) : dz[i,c]      (ReLU mask; out may be NULL)
+ *                                   gy[i,c] = g[i,c] * (scale ? scale[i] : 1)                  (gy may be NULL; pitch as above)
+ *                                   grad_bias[c] = sum_i g[i,c]                                (may be NULL; else workspace of
+ *                                   isplib_masked_scale_colsum_workspace_bytes(n, k) bytes, 256-byte aligned)
+ */
+int    isplib_row_scale_hip(int64_t n, int64_t k, const float *x /*[dev] n x ldx*/, int64_t ldx, const float *scale /*[dev] n*/,
+                            float *y /*[dev] n x ldy*/, int64_t ldy, void *stream);
+size_t isplib_masked_scale_colsum_workspace_bytes(int64_t n, int64_t k);
+int    isplib_masked_scale_colsum_hip(int64_t n, int64_t k, const float *dz, int64_t lddz, const float *out /*NULL: no mask*/,
+                                      int64_t ldo, const float *scale /*[dev] n | NULL*/, float *gy /*[dev] n x ldgy | NULL*/,
+                                      int64_t ldgy, float *grad_bias /*[dev] k | NULL*/, void *workspace, size_t workspace_bytes,
                                       void *stream);
 
 /*
@@ -529,6 +564,19 @@ int isplib_spmm_minmax_bw_det_hip(int64_t m, int64_t n, int64_t k, int64_t nnz,
                                   const float *mat, const int64_t *arg,
                                   const float *grad_out, float *grad_mat,
                                   float *grad_val, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * The local half of the max / min backward under the 1-D row partition (isplib_amd/dist.py; no reference counterpart: the
+ * reference has no distributed path).  After the exchange every rank holds, in global row order, the winners' columns
+ * dest[i,c] (int32 global row of the dense operand, < 0 = no winner) and the weighted gradients gval[i,c] = val[arg] *
+ * grad_out[i,c] of ALL rows; it keeps the destinations that are its own rows [lo, lo + n):
+ *     grad_mat[d - lo, c] = sum over i, ascending, of gval[i,c] where dest[i,c] == d
+ * Same stable sort + ordered run sums as isplib_spmm_minmax_bw_det_hip (no atomics, bitwise reproducible), same
+ * workspace: isplib_spmm_minmax_bw_workspace_bytes(m, n, k).  grad_mat (n x k, contiguous) is zero-filled first.
+ */
+int isplib_scatter_rows_det_hip(int64_t m, int64_t n, int64_t k, int64_t lo,
+                                const int32_t *dest /*[dev] m x k*/, const float *gval /*[dev] m x k*/,
+                                float *grad_mat /*[dev] n x k*/, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * SDDMM-style value gradient of SpMM-sum / SpMM-mean:

@@ -41,7 +41,7 @@ PATTERNS = {
 }
 
 EXPORTS = (
-    "isplib_hip_abi_version", "isplib_hip_last_error", "fusedMM_csr_hip", "performDummySpMM_hip",
+    "isplib_hip_abi_version", "isplib_hip_last_error", "isplib_hip_set_empty_row", "isplib_hip_get_empty_row", "fusedMM_csr_hip", "performDummySpMM_hip",
     "isplib_spmm_minmax_bw_hip", "isplib_sddmm_csr_hip", "isplib_csr_row_ids_hip",
     "isplib_csr2csc_workspace_bytes", "isplib_csr2csc_hip",
     "isplib_spmm_slices_bytes", "isplib_spmm_slices_build_hip", "isplib_spmm_sliced_workspace_bytes",
@@ -52,7 +52,8 @@ EXPORTS = (
     "isplib_suggest_slices", "isplib_graph_create", "isplib_graph_set_slices", "isplib_graph_set_values", "isplib_graph_spmm", "isplib_graph_spmm_backward",
     "isplib_graph_destroy", "isplib_suggest_slices_whole_rows", "isplib_graph_sddmm",
     "fusedMM_csr_sweep_hip", "isplib_spmm_sweep_workspace_bytes", "isplib_spmm_sweep_resident_waves",
-    "fusedMM_csr_stream_hip", "isplib_spmm_stream_workspace_bytes", "isplib_spmm_stream_geometry", "isplib_suggest_stream", "isplib_suggest_stream_weighted", "isplib_stream_plan_build_hip", "isplib_stream_plan_build_minmax_hip", "fusedMM_csr_stream_minmax_hip", "isplib_spmm_stream_minmax_geometry", "isplib_suggest_stream_minmax", "isplib_spmm_stream_minmax_workspace_bytes", "isplib_stream_plan_set_values_hip", "isplib_stream_plan_free", "isplib_spmm_minmax_bw_det_hip", "isplib_spmm_minmax_bw_workspace_bytes",
+    "fusedMM_csr_stream_hip", "isplib_spmm_stream_workspace_bytes", "isplib_spmm_stream_geometry", "isplib_suggest_stream", "isplib_suggest_stream_weighted", "isplib_stream_plan_build_hip", "isplib_stream_plan_build_minmax_hip", "fusedMM_csr_stream_minmax_hip", "isplib_spmm_stream_minmax_geometry", "isplib_suggest_stream_minmax", "isplib_spmm_stream_minmax_workspace_bytes", "isplib_stream_plan_set_values_hip", "isplib_stream_plan_free", "isplib_spmm_minmax_bw_det_hip", "isplib_spmm_minmax_bw_workspace_bytes", "isplib_scatter_rows_det_hip",
+    "isplib_row_scale_hip", "isplib_masked_scale_colsum_hip", "isplib_masked_scale_colsum_workspace_bytes",
     "fusedMM_csr_hybrid_hip", "isplib_spmm_hybrid_geometry", "isplib_spmm_hybrid_workspace_bytes", "isplib_sddmm_stream_hip",
     "fusedMM_csr_ordered_hip", "isplib_community_order_hip", "isplib_community_order_workspace_bytes", "isplib_order_locality_hip",
     "isplib_graph_set_row_order",
@@ -184,6 +185,14 @@ def lib() -> ctypes.CDLL:
         L.isplib_spmm_minmax_bw_workspace_bytes.argtypes = [_i64, _i64, _i64]
         L.isplib_spmm_minmax_bw_det_hip.restype = ctypes.c_int
         L.isplib_spmm_minmax_bw_det_hip.argtypes = [_i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]
+        L.isplib_row_scale_hip.restype = ctypes.c_int
+        L.isplib_row_scale_hip.argtypes = [_i64, _i64, _vp, _i64, _vp, _vp, _i64, _vp]
+        L.isplib_masked_scale_colsum_workspace_bytes.restype = ctypes.c_size_t
+        L.isplib_masked_scale_colsum_workspace_bytes.argtypes = [_i64, _i64]
+        L.isplib_masked_scale_colsum_hip.restype = ctypes.c_int
+        L.isplib_masked_scale_colsum_hip.argtypes = [_i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, ctypes.c_size_t, _vp]
+        L.isplib_scatter_rows_det_hip.restype = ctypes.c_int
+        L.isplib_scatter_rows_det_hip.argtypes = [_i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]
         L.isplib_stream_plan_build_hip.restype = ctypes.c_int
         L.isplib_stream_plan_build_hip.argtypes = [_i64, _i64, _i64, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                    ctypes.POINTER(StreamPlanStruct), _vp]
@@ -438,6 +447,65 @@ def spmm_minmax_bw(col, val, mat, arg, grad_out, need_mat=True, need_val=True, d
                                              _ptr(grad_mat), _ptr(grad_val), _stream(mat.device))
     _check(st, "isplib_spmm_minmax_bw_hip")
     return grad_val, grad_mat
+
+
+def row_scale(x: torch.Tensor, scale: torch.Tensor, pitch: Optional[int] = None) -> torch.Tensor:
+    """y = scale[:, None] * x through isplib_row_scale_hip; `pitch` > k: a [n, k] view of an [n, pitch] buffer (padding 0)."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    scale = _dev(scale, "scale", torch.float32)
+    n, k = x.shape
+    ld = k if pitch is None else int(pitch)
+    buf = torch.empty((n, ld), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().isplib_row_scale_hip(n, k, _ptr(x), x.stride(0) if n > 1 else max(k, x.stride(0)), _ptr(scale), _ptr(buf), ld,
+                                          _stream(x.device)), "isplib_row_scale_hip")
+    return buf[:, :k]
+
+
+def masked_scale_colsum(dz: torch.Tensor, out: Optional[torch.Tensor], scale: Optional[torch.Tensor], want_gy: bool = True,
+                        want_bias: bool = True, pitch: Optional[int] = None):
+    """(gy, grad_bias) of isplib_masked_scale_colsum_hip: g = dz * (out > 0), gy = g * scale[:, None], grad_bias = g.sum(0)."""
+    dz = _dev(dz, "dz", torch.float32)
+    out = None if out is None else _dev(out, "out", torch.float32)
+    scale = None if scale is None else _dev(scale, "scale", torch.float32)
+    n, k = dz.shape
+    ld = k if pitch is None else int(pitch)
+    gy = torch.empty((n, ld), dtype=torch.float32, device=dz.device) if want_gy else None
+    gb = torch.empty(k, dtype=torch.float32, device=dz.device) if want_bias else None
+    with torch.cuda.device(dz.device):
+        ws = lib().isplib_masked_scale_colsum_workspace_bytes(n, k)
+        work = torch.empty(max(ws, 256), dtype=torch.uint8, device=dz.device)
+        _check(lib().isplib_masked_scale_colsum_hip(n, k, _ptr(dz), k, _ptr(out), k, _ptr(scale), _ptr(gy), ld, _ptr(gb), _ptr(work),
+                                                    work.numel(), _stream(dz.device)), "isplib_masked_scale_colsum_hip")
+    return (None if gy is None else gy[:, :k]), gb
+
+
+def set_empty_row(mode: str = "zero") -> None:
+    """What an EMPTY row of max / min holds from now on, every schedule: "zero" (default) or "init" (-FLT_MAX / +FLT_MAX, the
+    reference launcher's pre-fill left untouched; include/isplib_hip.h: isplib_hip_set_empty_row).  Positions stay nnz."""
+    if mode not in ("zero", "init"):
+        raise ValueError("empty-row mode: 'zero' or 'init'")
+    _check(lib().isplib_hip_set_empty_row(1 if mode == "init" else 0), "isplib_hip_set_empty_row")
+
+
+def get_empty_row() -> str:
+    return "init" if lib().isplib_hip_get_empty_row() else "zero"
+
+
+def scatter_rows_det(dest: torch.Tensor, gval: torch.Tensor, lo: int, n: int) -> torch.Tensor:
+    """grad[d - lo, c] = sum over i (ascending) of gval[i, c] where dest[i, c] == d, for d in [lo, lo + n)
+    (isplib_scatter_rows_det_hip: the local half of the row-partitioned max / min backward)."""
+    dest = _dev(dest, "dest", torch.int32)
+    gval = _dev(gval, "gval", torch.float32)
+    assert dest.shape == gval.shape and dest.dim() == 2
+    m, k = dest.shape
+    out = torch.empty((n, k), dtype=torch.float32, device=gval.device)
+    with torch.cuda.device(gval.device):
+        ws = lib().isplib_spmm_minmax_bw_workspace_bytes(m, n, k)
+        work = torch.empty(max(ws, 256), dtype=torch.uint8, device=gval.device)
+        _check(lib().isplib_scatter_rows_det_hip(m, n, k, int(lo), _ptr(dest), _ptr(gval), _ptr(out), _ptr(work), work.numel(),
+                                                 _stream(gval.device)), "isplib_scatter_rows_det_hip")
+    return out
 
 
 def sddmm(rowptr, col, y, g, mean: bool = False):
@@ -958,12 +1026,15 @@ class GraphHandle:
         _check(lib().isplib_graph_set_values(self._h, _ptr(self.val)), "isplib_graph_set_values")
 
     def spmm(self, y: torch.Tensor, reduce: str = "sum"):
-        y = _dev(y, "y", torch.float32)
+        """y: [n, k] with unit column stride; a row stride > k (a column block of a wider matrix) is passed on as ldy."""
+        if not (y.is_cuda and y.dtype == torch.float32 and y.dim() == 2 and y.stride(1) == 1 and y.stride(0) >= y.size(1)):
+            y = _dev(y, "y", torch.float32)
         k = y.size(1)
+        ldy = y.stride(0) if y.size(0) > 1 else max(k, y.stride(0))
         out = torch.empty((self.m, k), dtype=torch.float32, device=y.device)
         arg = torch.empty((self.m, k), dtype=torch.int64, device=y.device) if reduce in ("max", "min") else None
         with torch.cuda.device(y.device):
-            _check(lib().isplib_graph_spmm(self._h, MESSAGE[reduce], k, _ptr(y), k, _ptr(out), k, _ptr(arg), _stream(y.device)),
+            _check(lib().isplib_graph_spmm(self._h, MESSAGE[reduce], k, _ptr(y), ldy, _ptr(out), k, _ptr(arg), _stream(y.device)),
                    "isplib_graph_spmm")
         return out, arg
 

@@ -39,6 +39,21 @@ __global__ __launch_bounds__(256) void minmax_pairs_kernel(int64_t total, int64_
    }
 }
 
+// The same pairs from (destination row, value) arrays instead of (arg, indx, val, grad_out): what a rank of the 1-D row partition
+// holds after the exchange of the max / min backward (isplib_amd/dist.py) -- every rank's winners' columns and weighted gradients,
+// all-gathered in rank (= global row) order; only the destinations inside this rank's own rows [lo, lo + n) are kept.
+__global__ __launch_bounds__(256) void dest_pairs_kernel(int64_t total, int64_t k, int64_t n, int64_t lo, uint32_t limit,
+                                                         const int32_t *__restrict__ dest, const float *__restrict__ gval,
+                                                         uint32_t *__restrict__ keys, float *__restrict__ vals) {
+   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+      const int64_t d = (int64_t)dest[t] - lo;
+      const bool mine = dest[t] >= 0 && d >= 0 && d < n;
+      keys[t] = mine ? (uint32_t)(d * k + t % k) : limit;
+      vals[t] = mine ? gval[t] : 0.0f;
+   }
+}
+
 // Run sums in two levels, so that a destination with thousands of contributions (a hub column wins in many rows) does
 // not leave one thread adding them up alone.  Level 1: every thread walks its own RUN_CHUNK consecutive sorted pairs;
 // runs that begin and end inside the chunk are finished there; of a run that crosses chunk borders the thread keeps
@@ -178,6 +193,8 @@ static hipError_t pair_sort_temp(int64_t total, unsigned bits, size_t *bytes) {
 
 using namespace isplib;
 
+static int sorted_run_sums(int64_t total, uint32_t limit, void *workspace, float *grad_mat, hipStream_t st);
+
 extern "C" size_t isplib_spmm_minmax_bw_workspace_bytes(int64_t m, int64_t n, int64_t k) {
    if (m <= 0 || n <= 0 || k <= 0) return 256;
    const double dest = (double)n * (double)k;
@@ -215,19 +232,30 @@ extern "C" int isplib_spmm_minmax_bw_det_hip(int64_t m, int64_t n, int64_t k, in
    if (((uintptr_t)workspace & 255) != 0) return fail(ISPLIB_FAIL, "isplib_spmm_minmax_bw_det_hip: workspace must be 256-byte aligned");
    const size_t plane = up256((size_t)total * 4);
    char *w = (char *)workspace;
-   uint32_t *keys_in = (uint32_t *)w, *keys_out = (uint32_t *)(w + plane);
-   float *vals_in = (float *)(w + 2 * plane), *vals_out = (float *)(w + 3 * plane);
-   void *temp = w + 4 * plane;
+   uint32_t *keys_in = (uint32_t *)w;
+   float *vals_in = (float *)(w + 2 * plane);
    const uint32_t limit = (uint32_t)(n * k);
-   const unsigned bits = bits_for((uint64_t)limit + 1);
-   size_t temp_bytes = 0;
-   ISPLIB_HIP_TRY(pair_sort_temp(total, bits, &temp_bytes));
    int64_t blocks = (total + 255) / 256;
    if (blocks > 256 * 32) blocks = 256 * 32;
    hipLaunchKernelGGL(minmax_pairs_kernel, dim3((unsigned)blocks), dim3(256), 0, st, total, k, nnz, limit, indx, val, arg, grad_out,
                       keys_in, vals_in);
-   int rc = check_launch("minmax_pairs_kernel");
+   const int rc = check_launch("minmax_pairs_kernel");
    if (rc) return rc;
+   return sorted_run_sums(total, limit, workspace, grad_mat, st);
+}
+
+// the second half of both entries: the (key, value) pairs in the first and third plane of the workspace are sorted by key
+// (stable) and every run of equal keys < limit is added up in order into grad_mat[key]
+static int sorted_run_sums(int64_t total, uint32_t limit, void *workspace, float *grad_mat, hipStream_t st) {
+   const size_t plane = up256((size_t)total * 4);
+   char *w = (char *)workspace;
+   uint32_t *keys_in = (uint32_t *)w, *keys_out = (uint32_t *)(w + plane);
+   float *vals_in = (float *)(w + 2 * plane), *vals_out = (float *)(w + 3 * plane);
+   void *temp = w + 4 * plane;
+   const unsigned bits = bits_for((uint64_t)limit + 1);
+   size_t temp_bytes = 0;
+   ISPLIB_HIP_TRY(pair_sort_temp(total, bits, &temp_bytes));
+   int rc;
    ISPLIB_HIP_TRY(sort_pairs_u32_f32(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)total, 0u, bits, st));
    const size_t nchunks = ((size_t)total + RUN_CHUNK - 1) / RUN_CHUNK;
    float *open_sum = (float *)((char *)temp + up256(temp_bytes));
@@ -241,4 +269,33 @@ extern "C" int isplib_spmm_minmax_bw_det_hip(int64_t m, int64_t n, int64_t k, in
    if (rc) return rc;
    hipLaunchKernelGGL(minmax_open_runs_kernel, dim3((unsigned)cblocks), dim3(256), 0, st, total, keys_out, open_sum, cont_sum, state, grad_mat);
    return check_launch("minmax_open_runs_kernel");
+}
+
+// grad_mat[d - lo, c] = sum, in ascending i, of gval[i, c] over the (i, c) with dest[i, c] = d in [lo, lo + n): the local half of the
+// max / min backward under the 1-D row partition (isplib_amd/dist.py: every rank all-gathers its winners' columns and weighted
+// gradients and keeps the destinations that are its own rows).  Same sort and run sums as isplib_spmm_minmax_bw_det_hip, same
+// workspace (isplib_spmm_minmax_bw_workspace_bytes(m, n, k)); dest < 0 = no winner.  No atomics: bitwise reproducible.
+extern "C" int isplib_scatter_rows_det_hip(int64_t m, int64_t n, int64_t k, int64_t lo, const int32_t *dest, const float *gval,
+                                           float *grad_mat, void *workspace, size_t workspace_bytes, void *stream) {
+   clear_error();
+   if (m < 0 || n < 0 || k < 0) return fail(ISPLIB_FAIL, "isplib_scatter_rows_det_hip: negative dimension");
+   hipStream_t st = (hipStream_t)stream;
+   if (!grad_mat && n * k > 0) return fail(ISPLIB_FAIL, "isplib_scatter_rows_det_hip: null operand");
+   if (n * k > 0) ISPLIB_HIP_TRY(hipMemsetAsync(grad_mat, 0, (size_t)n * (size_t)k * sizeof(float), st));
+   const int64_t total = m * k;
+   if (total == 0 || n == 0) return ISPLIB_SUCCESS;
+   if (!dest || !gval) return fail(ISPLIB_FAIL, "isplib_scatter_rows_det_hip: null operand");
+   const size_t need = isplib_spmm_minmax_bw_workspace_bytes(m, n, k);
+   if (need == 0) return fail(ISPLIB_NO_OPT_IMPL, "isplib_scatter_rows_det_hip: n*k or m*k beyond 32-bit keys");
+   if (!workspace || workspace_bytes < need) return fail(ISPLIB_NOT_ENOUGH_MEM, "isplib_scatter_rows_det_hip: workspace too small");
+   if (((uintptr_t)workspace & 255) != 0) return fail(ISPLIB_FAIL, "isplib_scatter_rows_det_hip: workspace must be 256-byte aligned");
+   const size_t plane = up256((size_t)total * 4);
+   const uint32_t limit = (uint32_t)(n * k);
+   int64_t blocks = (total + 255) / 256;
+   if (blocks > 256 * 32) blocks = 256 * 32;
+   hipLaunchKernelGGL(dest_pairs_kernel, dim3((unsigned)blocks), dim3(256), 0, st, total, k, n, lo, limit, dest, gval,
+                      (uint32_t *)workspace, (float *)((char *)workspace + 2 * plane));
+   const int rc = check_launch("dest_pairs_kernel");
+   if (rc) return rc;
+   return sorted_run_sums(total, limit, workspace, grad_mat, st);
 }

@@ -9,6 +9,7 @@
 namespace isplib {
 
 char *error_buffer();   // thread-local, 512 bytes (defined in runtime.hip)
+int empty_row_init();   // 1: an empty row of max / min keeps the reference launcher's pre-fill (isplib_hip_set_empty_row; runtime.hip)
 
 inline void clear_error() { error_buffer()[0] = '\0'; }
 

@@ -35,6 +35,7 @@ struct GenArgs {
    int vop, rop, sop, vsc, aop;   // stage codes, already shifted down to 0..15
    int sop_udef;
    float sop_param;
+   int empty_init;                // max / min: an empty row holds the launcher's init value (-+FLT_MAX) instead of 0
    unsigned ybytes;
    // task form (fusedMM_csr_udef_tasks_hip): the plan of the SpMM task list; partial rows instead of z
    const int32_t *indx32;
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(WAVES * 64) void fusedmm_general_kernel(const GenAr
          float out = acc[j][v];
          if (op.vsc == G_VSC_MEAN) out = out / scale;
          if (op.aop != G_AOP_ADD) {
-            if (re <= rb) out = 0.0f;                             // empty row: 0 / arg = nnz
+            if (re <= rb) out = !a.empty_init ? 0.0f : (op.aop == G_AOP_MAX ? -FLT_MAX : FLT_MAX);   // empty row: 0 (or the launcher's init) / arg = nnz
             if (a.z_arg) a.z_arg[off] = bi[j][v] == INT_MAX ? a.nnz : rb + bi[j][v];
          }
          a.z[off] = out;
@@ -315,6 +316,7 @@ static int general_entry(int32_t imessage, int64_t m, int64_t n, int64_t k, int6
                          float sop_param, const GenPlan &plan, void *stream) {
    clear_error();
    GenArgs a = {};
+   a.empty_init = empty_row_init();
    a.vop = imessage & 0xF; a.rop = (imessage >> 4) & 0xF; a.sop = (imessage >> 8) & 0xF;
    a.vsc = (imessage >> 12) & 0xF; a.aop = (imessage >> 16) & 0xF;
    if ((imessage >> 20) != 0) return fail(ISPLIB_NO_OPT_IMPL, "fusedMM_csr_udef_hip: unknown bits above the AOP nibble");

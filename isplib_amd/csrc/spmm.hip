@@ -42,6 +42,7 @@ struct SpmmArgs {
    int64_t ldz;
    int64_t *z_arg;         // may be null
    int mean;               // OP_ADD only: divide by max(deg,1)
+   int empty_init;         // max / min: an empty row holds the launcher's init value (-+FLT_MAX) instead of 0
    int long_row;           // rows with more edges are split across the workgroup
    unsigned nblk;          // number of row blocks
    unsigned ybytes;        // n*ldy*4 when it fits the buffer-descriptor path, else 0
@@ -76,7 +77,7 @@ __device__ __forceinline__ void write_row(const SpmmArgs &a, int64_t row, int64_
 #pragma unroll
       for (int j = 0; j < NCH; j++)
 #pragma unroll
-         for (int v = 0; v < VEC; v++) acc[j][v] = 0.0f;
+         for (int v = 0; v < VEC; v++) acc[j][v] = a.empty_init ? identity<OP>() : 0.0f;
    }
 #pragma unroll
    for (int j = 0; j < NCH; j++) {
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(256) void combine_slices_kernel(const SpmmArgs a) {
          }
       } else if (deg <= 0) {
 #pragma unroll
-         for (int v = 0; v < VEC; v++) acc[v] = 0.0f;
+         for (int v = 0; v < VEC; v++) acc[v] = a.empty_init ? identity<OP>() : 0.0f;
       }
       store_vec<VEC>(a.z + (size_t)row * (size_t)a.ldz + c, acc);
       if (OP != OP_ADD && a.z_arg) {
@@ -435,6 +436,7 @@ static int spmm_entry(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t
    a.val = val; a.indx = indx; a.indx32 = nullptr; a.pntrb = pntrb; a.pntre = pntre;
    a.y = y; a.ldy = ldy; a.z = z; a.ldz = ldz; a.z_arg = z_arg;
    a.mean = (vsc == ISPLIB_VSC_MEAN) ? 1 : 0;
+   a.empty_init = empty_row_init();
    a.long_row = 2048;
    a.nblk = 0;
    {

@@ -112,6 +112,7 @@ struct SweepArgs {
    int64_t ldz;
    int64_t *z_arg;
    int mean;
+   int empty_init;                 // max / min: an empty row holds the launcher's init value (-+FLT_MAX) instead of 0
    const int32_t *wave_row;        // [waves][NVMAX] row of the slot, -1 = unused slot
    const int32_t *wave_part;       // [waves][NVMAX] -1: the slot is a whole row (written to z); else index of its partial row
    const int64_t *wave_task_off;   // [waves + 1]
@@ -178,7 +179,7 @@ __device__ __forceinline__ void finish_row(const SweepArgs &a, int row, int c, f
    } else {
 #pragma unroll
       for (int i = 0; i < 4; i++) {
-         if (deg <= 0) v[i] = 0.0f;
+         if (deg <= 0) v[i] = a.empty_init ? identity<OP>() : 0.0f;
          arg[i] = bi[i] == INT_MAX ? a.nnz : (a.abs_ids ? (int64_t)bi[i] : rb + (int64_t)bi[i]);
       }
    }
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(256) void sweep_hub_fold_kernel(const SweepArgs a) 
             if (a.ep_bias) v[0] += a.ep_bias[c];
             if (a.ep_relu) v[0] = v[0] > 0.0f ? v[0] : 0.0f;
          } else {
-            if (deg <= 0) v[0] = 0.0f;
+            if (deg <= 0) v[0] = a.empty_init ? identity<OP>() : 0.0f;
             arg[0] = bi[0] == INT_MAX ? a.nnz : (a.abs_ids ? (int64_t)bi[0] : rb + (int64_t)bi[0]);
          }
          a.z[(size_t)row * (size_t)a.ldz + c] = v[0];
@@ -1318,6 +1319,7 @@ extern "C" int fusedMM_csr_sweep_hip(int32_t imessage, int64_t m, int64_t n, int
       if (((uintptr_t)workspace & 255) != 0) return fail(ISPLIB_FAIL, "fusedMM_csr_sweep_hip: workspace must be 256-byte aligned");
    }
    SweepArgs a = {};
+   a.empty_init = empty_row_init();
    a.k = k; a.nnz = nnz; a.val = val; a.indx = indx; a.indx32 = indx32; a.pntrb = pntrb; a.pntre = pntre;
    a.y = y; a.ldy = ldy; a.ybytes = (unsigned)yb; a.z = z; a.ldz = ldz; a.z_arg = z_arg;
    a.mean = (vsc == ISPLIB_VSC_MEAN) ? 1 : 0;
@@ -1524,6 +1526,7 @@ static int stream_run(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t
       if (((uintptr_t)workspace & 255) != 0) return fail(ISPLIB_FAIL, "fusedMM_csr_stream_hip: workspace must be 256-byte aligned");
    }
    SweepArgs a = {};
+   a.empty_init = empty_row_init();
    a.k = k; a.nnz = nnz; a.pntrb = pntrb; a.pntre = pntre;
    a.y = y; a.ldy = ldy; a.ybytes = (unsigned)yb; a.z = z; a.ldz = ldz; a.z_arg = z_arg;
    a.mean = imessage == ISPLIB_MSG_SPMM_MEAN ? 1 : 0;
@@ -1639,6 +1642,7 @@ extern "C" int isplib_sddmm_stream_hip(int64_t m, int64_t n, int64_t k, int64_t 
    if (!pntrb || !pntre || !y || !g || !dval || !plan->wave_row || !plan->wave_step_off || (plan->n_steps > 0 && !plan->words))
       return fail(ISPLIB_FAIL, "isplib_sddmm_stream_hip: null operand");
    SweepArgs a = {};
+   a.empty_init = empty_row_init();
    a.k = k; a.nnz = nnz; a.pntrb = pntrb; a.pntre = pntre;
    a.y = y; a.ldy = ldy; a.ybytes = (unsigned)yb;
    a.mean = mean ? 1 : 0;
@@ -1728,6 +1732,7 @@ extern "C" int fusedMM_csr_hybrid_hip(int32_t imessage, int64_t m, int64_t n, in
       if (((uintptr_t)workspace & 255) != 0) return fail(ISPLIB_FAIL, "fusedMM_csr_hybrid_hip: workspace must be 256-byte aligned");
    }
    SweepArgs a = {};
+   a.empty_init = empty_row_init();
    a.k = k; a.nnz = nnz; a.pntrb = pntrb; a.pntre = pntre;
    a.y = y; a.ldy = ldy; a.ybytes = (unsigned)yb; a.z = z; a.ldz = ldz;
    a.mean = imessage == ISPLIB_MSG_SPMM_MEAN ? 1 : 0;

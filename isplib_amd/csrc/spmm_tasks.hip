@@ -34,6 +34,7 @@ struct TaskArgs {
    int64_t ldz;
    int64_t *z_arg;
    int mean, slices;
+   int empty_init;           // max / min: an empty row holds the launcher's init value (-+FLT_MAX) instead of 0
    const int *task_row;      // [n_tasks]
    const int64_t *task_b;    // [n_tasks] first CSR position
    const int *task_len;      // [n_tasks] edges (<= T)
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(256) void combine_tasks_kernel(const TaskArgs a) {
          }
       } else if (deg <= 0) {
 #pragma unroll
-         for (int v = 0; v < VEC; v++) acc[v] = 0.0f;
+         for (int v = 0; v < VEC; v++) acc[v] = a.empty_init ? identity<OP>() : 0.0f;
       }
       store_vec<VEC>(a.z + (size_t)row * (size_t)a.ldz + c, acc);
       if (OP != OP_ADD && a.z_arg) {
@@ -256,6 +257,7 @@ int combine_task_partials(int aop, int64_t m, int64_t k, int64_t nnz, const int6
    TaskArgs a = {};
    a.m = m; a.k = k; a.nnz = nnz; a.pntrb = pntrb; a.pntre = pntre; a.seg_off = seg_off; a.slices = slices; a.mean = mean;
    a.part_val = part_val; a.part_idx = part_idx; a.z = z; a.ldz = ldz; a.z_arg = z_arg;
+   a.empty_init = empty_row_init();
    const bool v4 = k % 4 == 0 && ldz % 4 == 0 && ((uintptr_t)z & 15) == 0;
    int64_t blocks = (m * (v4 ? k / 4 : k) + 255) / 256;
    if (blocks > 8192) blocks = 8192;
@@ -307,6 +309,7 @@ static int tasks_entry(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_
    a.m = m; a.k = k; a.nnz = nnz; a.val = val; a.indx = indx; a.indx32 = indx32; a.pntrb = pntrb; a.pntre = pntre;
    a.y = y; a.ldy = ldy; a.ybytes = (unsigned)yb; a.z = z; a.ldz = ldz; a.z_arg = z_arg;
    a.mean = (vsc == ISPLIB_VSC_MEAN) ? 1 : 0; a.slices = slices;
+   a.empty_init = empty_row_init();
    a.task_row = task_row; a.task_b = task_b; a.task_len = task_len; a.seg_off = seg_off;
    for (int x = 0; x < 9; x++) a.lane_off[x] = lane_off_host[x];
    if (a.lane_off[0] != 0 || a.lane_off[8] != n_tasks) return fail(ISPLIB_FAIL, "fusedMM_csr_tasks_hip: lane_off must run from 0 to n_tasks");

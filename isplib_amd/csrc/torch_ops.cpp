@@ -436,15 +436,20 @@ Tensor sddmm(const Tensor &rowptr, const Tensor &col, const Tensor &mat, const T
 
 // sum-SpMM with unit weights and the fused epilogue out = act(row_scale * (A y + self) + bias); the fold kernel
 // applies it when a task plan is given (isplib_epilogue), otherwise it is composed from ATen ops.
+// a [N, K] matrix whose rows may sit at a wider pitch (a view of an [N, pitch] buffer): usable as it is by the stream entry
+static bool row_strided(const Tensor &t) { return t.dim() == 2 && t.stride(1) == 1 && (t.size(0) <= 1 || t.stride(0) >= t.size(1)); }
+
 Tensor epilogue_spmm(const Tensor &rowptr, const Tensor &col, const Plan &plan, const Tensor &y_, const Tensor &self_,
                      const Tensor &row_scale, const Tensor &bias, bool relu) {
-   const Tensor y = y_.contiguous();
-   const int64_t M = rowptr.numel() - 1, N = y.size(0), K = y.size(1), nnz = col.numel();
+   const int64_t M = rowptr.numel() - 1, N = y_.size(0), K = y_.size(1), nnz = col.numel();
    const bool tasks_fit = is_task_plan(plan) && K >= 4 && M > 0 && (double)N * (double)K * 4.0 <= 3.5 * 1073741824.0;
    if (is_stream_plan(plan) && M > 0 && K >= 4) {
       // the stream kernel applies the same epilogue when it writes a finished row (hub rows: in their fold)
-      c10::DeviceGuard guard(y.device());
-      const Tensor self = self_.defined() ? self_.contiguous() : Tensor();
+      c10::DeviceGuard guard(y_.device());
+      const Tensor y = row_strided(y_) ? y_ : y_.contiguous();          // the gather's own pitch is kept (GcnNormSpmm)
+      const int64_t ldy = N > 1 ? y.stride(0) : K;
+      TORCH_CHECK((double)N * (double)ldy * 4.0 <= 3.5 * 1073741824.0, "isplib: dense operand beyond one buffer descriptor");
+      const Tensor self = self_.defined() ? (row_strided(self_) ? self_ : self_.contiguous()) : Tensor();
       const Tensor rs = row_scale.defined() ? row_scale.contiguous() : Tensor();
       const Tensor bs = bias.defined() ? bias.contiguous() : Tensor();
       if (self.defined()) TORCH_CHECK(self.size(0) == M && self.size(1) == K, "isplib: `self` must be [M, K]");
@@ -459,15 +464,16 @@ Tensor epilogue_spmm(const Tensor &rowptr, const Tensor &col, const Plan &plan, 
       isplib_epilogue ep;
       ep.row_scale = rs.defined() ? rs.data_ptr<float>() : nullptr;
       ep.self = self.defined() ? self.data_ptr<float>() : nullptr;
-      ep.ld_self = K;
+      ep.ld_self = self.defined() && M > 1 ? self.stride(0) : K;
       ep.bias = bs.defined() ? bs.data_ptr<float>() : nullptr;
       ep.relu = relu ? 1 : 0;
       const int64_t *rp = rp_c.data_ptr<int64_t>();
-      const int st = fusedMM_csr_stream_hip(ISPLIB_MSG_SPMM_SUM, M, N, K, nnz, rp, rp + 1, &sp, y.data_ptr<float>(), K, out.data_ptr<float>(), K,
+      const int st = fusedMM_csr_stream_hip(ISPLIB_MSG_SPMM_SUM, M, N, K, nnz, rp, rp + 1, &sp, y.data_ptr<float>(), ldy, out.data_ptr<float>(), K,
                                             work.data_ptr(), ws, &ep, current_stream(y));
       check_status(st, "fusedMM_csr_stream_hip");
       return out;
    }
+   const Tensor y = y_.contiguous();
    if (!tasks_fit) {
       Tensor out = std::get<0>(spmm_fw(rowptr, col, c10::nullopt, y, R_SUM, plan));
       if (self_.defined()) out = out + self_;
@@ -681,6 +687,28 @@ class SpmmMinMax : public torch::autograd::Function<SpmmMinMax<RED>> {
    }
 };
 
+// The pitch (floats per row) a gathered [N, K] operand of the stream schedule should be written at: 48 for 33..47 columns
+// on large graphs (a 164-byte row at its packed pitch straddles 2.25 cache lines on average, at 192 bytes exactly 2: spmm_fw
+// above copies for the same reason); K otherwise.
+static int64_t gather_pitch(int64_t N, int64_t K, bool stream) {
+   return (stream && K > 32 && K < 48 && N >= (1 << 16) && (double)N * 48.0 * 4.0 < 2.0 * 1073741824.0) ? 48 : K;
+}
+
+// y = D^-1/2 X in one pass (isplib_row_scale_hip), written at the gather's pitch: a [N, K] view
+static Tensor gcn_row_scale(const Tensor &mat_, const Tensor &dinv_, bool stream) {
+   c10::DeviceGuard guard(mat_.device());
+   const Tensor mat = row_strided(mat_) ? mat_ : mat_.contiguous();
+   const Tensor dinv = dinv_.contiguous();
+   const int64_t N = mat.size(0), K = mat.size(1);
+   TORCH_CHECK(dinv.numel() == N, "isplib: `dinv` must have one entry per row of `mat`");
+   const int64_t ld = gather_pitch(N, K, stream);
+   Tensor buf = at::empty({N, ld}, mat.options());
+   const int st = isplib_row_scale_hip(N, K, mat.data_ptr<float>(), N > 1 ? mat.stride(0) : K, dinv.data_ptr<float>(), buf.data_ptr<float>(),
+                                       ld, current_stream(mat));
+   check_status(st, "isplib_row_scale_hip");
+   return buf.narrow(1, 0, K);
+}
+
 // ---- GCN's normalised aggregation, fused: relu(D^-1/2 (A + I) D^-1/2 X + b) with unit-weight A ----------
 // (the `normalize=True` callers, tests/dist/gcn/pyg-sparse.py:61-62; not an operator of the reference)
 class GcnNormSpmm : public torch::autograd::Function<GcnNormSpmm> {
@@ -691,7 +719,7 @@ class GcnNormSpmm : public torch::autograd::Function<GcnNormSpmm> {
       check_index(rowptr, "rowptr"); check_index(col, "col"); check_float(mat, "mat"); check_float(dinv, "dinv");
       TORCH_CHECK(mat.dim() == 2 && rowptr.numel() - 1 == mat.size(0), "isplib: gcn_norm_spmm needs a square graph and [N, K] features");
       const Tensor bias = or_undef(opt_bias);
-      const Tensor y = mat * dinv.unsqueeze(1);
+      const Tensor y = gcn_row_scale(mat, dinv, is_stream_plan(plan));      // D^-1/2 X, one pass, at the gather's pitch
       Tensor out = epilogue_spmm(rowptr, col, plan, y, y, dinv, bias, relu);
       ctx->saved_data["relu"] = relu;
       ctx->saved_data["plan_t"] = plan_t;
@@ -704,18 +732,38 @@ class GcnNormSpmm : public torch::autograd::Function<GcnNormSpmm> {
    static variable_list backward(AutogradContext *ctx, variable_list grad_outs) {
       auto saved = ctx->get_saved_variables();
       auto rowptr = saved[0], col = saved[1], dinv = saved[2], colptr = saved[3], row_t = saved[4], out = saved[5];
-      Tensor g = grad_outs[0];
-      if (ctx->saved_data["relu"].toBool()) g = g * (out > 0).to(g.scalar_type());
+      const Tensor dz = grad_outs[0].contiguous();
+      check_float(dz, "grad_out");
       auto grad_bias = Variable(), grad_mat = Variable();
-      if (ctx->saved_data["has_bias"].toBool() && ctx->needs_input_grad(ctx->saved_data["bias_edge"].toInt())) grad_bias = g.sum(0);
-      if (ctx->needs_input_grad(2)) {
+      const bool need_bias = ctx->saved_data["has_bias"].toBool() && ctx->needs_input_grad(ctx->saved_data["bias_edge"].toInt());
+      const bool need_mat = ctx->needs_input_grad(2);
+      if (need_bias || need_mat) {
+         // ONE pass over dZ (and the saved output, for the ReLU mask): gY = (dZ . [out > 0]) D^-1/2 written at the pitch the
+         // backward's gather wants, and the bias gradient as a tall-skinny column sum (per-block partials + one fold,
+         // deterministic) -- the four ATen passes this replaces included a 1.2 ms reduce_kernel on a 38 MB matrix
+         c10::DeviceGuard guard(dz.device());
          Plan plan_t = ctx->saved_data["plan_t"].toTensorVector();
-         if (!colptr.defined() || !row_t.defined()) {
+         if (need_mat && (!colptr.defined() || !row_t.defined())) {
             auto t = build_transpose(rowptr, col, Tensor(), rowptr.numel() - 1, false);
             colptr = t.colptr; row_t = t.row_t; plan_t.clear();
          }
-         const Tensor gy = g * dinv.unsqueeze(1);
-         grad_mat = epilogue_spmm(colptr, row_t, plan_t, gy, gy, dinv, Tensor(), false) ;   // D (A^T + I) D dZ
+         const int64_t N = dz.size(0), K = dz.size(1);
+         const int64_t ld = need_mat ? gather_pitch(N, K, is_stream_plan(plan_t)) : K;
+         Tensor gy_buf = need_mat ? at::empty({N, ld}, dz.options()) : Tensor();
+         if (need_bias) grad_bias = at::empty({K}, dz.options());
+         const Tensor mask = ctx->saved_data["relu"].toBool() ? out.contiguous() : Tensor();
+         const Tensor scale = dinv.contiguous();
+         const size_t ws = isplib_masked_scale_colsum_workspace_bytes(N, K);
+         Tensor work = at::empty({(int64_t)ws}, dz.options().dtype(at::kByte));
+         const int st = isplib_masked_scale_colsum_hip(N, K, dz.data_ptr<float>(), K, mask.defined() ? mask.data_ptr<float>() : nullptr, K,
+                                                       scale.data_ptr<float>(), need_mat ? gy_buf.data_ptr<float>() : nullptr, ld,
+                                                       need_bias ? grad_bias.data_ptr<float>() : nullptr, work.data_ptr(), ws,
+                                                       current_stream(dz));
+         check_status(st, "isplib_masked_scale_colsum_hip");
+         if (need_mat) {
+            const Tensor gy = gy_buf.narrow(1, 0, K);
+            grad_mat = epilogue_spmm(colptr, row_t, plan_t, gy, gy, dinv, Tensor(), false);   // D (A^T + I) D dZ
+         }
       }
       return {Variable(), Variable(), grad_mat, Variable(), Variable(), Variable(), Variable(), Variable(), grad_bias, Variable()};
    }

@@ -140,7 +140,7 @@ class RowPartition:
         arg = torch.empty((self.rows, k), dtype=torch.int64, device=x_shard.device) if reduce in ("max", "min") else None
         cabi.fusedMM_csr_hip(cabi.MESSAGE[reduce], self.rowptr, self.col_padded, self.val, buf, out, arg)
         if arg is not None:
-            arg = torch.where(arg == self.nnz, arg.new_full((), self.total_nnz), arg + self.edge0)
+            arg = self.global_arg(arg)
         return out, arg
 
     # ---- overlapped form: local column slices run while the all-gather is in flight ----------------
@@ -263,12 +263,13 @@ class RowPartition:
             self._col32 = cabi.pack_indices(self.col_padded)
         return build_task_plan(self.rowptr, self.col_padded, self.ncols_padded, slices, chunk, short_row, col32=self._col32)
 
-    def _stream_plan(self, geom):
+    def _stream_plan(self, geom, minmax: bool = False):
         """Stream plan of this rank's rows over the padded gather layout, geom = (streams, slices, chunk): the library's own
         builder (rocPRIM sorts, ~10 ms at Reddit size; no torch kernel has to be loaded for it), weights gathered through
-        the plan's permutation.  None where the builder declines."""
+        the plan's permutation.  minmax: a plan of the max / min kernel's geometry (column-sorted rows; the padded column ids
+        are monotone in the original ones, so a sorted row stays sorted).  None where the builder declines."""
         from .plan import build_stream_plan_native
-        plan = build_stream_plan_native(self.rowptr, self.col_padded, self.ncols_padded, geom[1], geom[0], geom[2])
+        plan = build_stream_plan_native(self.rowptr, self.col_padded, self.ncols_padded, geom[1], geom[0], geom[2], minmax=minmax)
         if plan is not None and self.val is not None:
             plan.set_values(self.val)
         return plan
@@ -359,11 +360,51 @@ class _DistSpMM(torch.autograd.Function):
         return ctx.graph.bwd.spmm_auto(grad_out.contiguous()), None
 
 
+class _DistSpMMMean(torch.autograd.Function):
+    """mean forward; dX[R_p] = A^T[R_p, :] @ allgather(dY) with the weights value[csr2csc] / max(deg, 1)[row[csr2csc]]
+    (csrc/fusedmm.cpp:357-375).  For an unweighted graph that weight is 1 / deg of the edge's row in A, i.e. a scale of
+    the rows of dY: applied to this rank's rows before the exchange, and A^T stays on the unit-weight path."""
+
+    @staticmethod
+    def forward(ctx, x_local, graph):
+        ctx.graph = graph
+        return graph.fwd.spmm_auto(x_local, "mean")
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        g = ctx.graph
+        if g.fwd.val is None:
+            return g.bwd.spmm_auto((grad_out * g.inv_deg().unsqueeze(1)).contiguous()), None
+        return g.bwd_mean().spmm_auto(grad_out.contiguous()), None
+
+
+class _DistSpMMMinMax(torch.autograd.Function):
+    """max / min forward (values; the winners' GLOBAL CSR positions are kept for the backward).  Backward
+    (csrc/fusedmm.cpp:410-451): dX[col[arg[i,c]], c] += val[arg[i,c]] * dY[i,c] -- the destination row may live on any
+    rank, so the exchange carries, for every (i, c), the destination's global row and the weighted gradient (ONE
+    all-gather of each, in global row order), and every rank adds up what lands in its own rows in ascending i
+    (isplib_scatter_rows_det_hip: sort-based, no atomics)."""
+
+    @staticmethod
+    def forward(ctx, x_local, graph, reduce):
+        out, arg = graph.fwd.spmm_auto(x_local, reduce)
+        ctx.graph = graph
+        ctx.save_for_backward(arg)
+        ctx.mark_non_differentiable(arg)
+        return out, arg
+
+    @staticmethod
+    def backward(ctx, grad_out, _grad_arg):
+        (arg,) = ctx.saved_tensors
+        return ctx.graph.fwd.minmax_backward(arg, grad_out.contiguous()), None, None
+
+
 class DistGraph:
     """This rank's rows of A and of A^T (same row boundaries) for full-batch GNN training on one node:
-    `matmul(x_local)` is the sum-aggregation of the 1-D row-partitioned graph with autograd; every call
-    is ONE all-gather + the local SpMM, forward and backward alike.  Dense layer weights are replicated
-    by the caller and their gradients all-reduced (outside the SpMM path)."""
+    `matmul(x_local, reduce)` is the aggregation of the 1-D row-partitioned graph with autograd; every call
+    is ONE all-gather + the local SpMM, forward and backward alike (max / min backward: one all-gather of the
+    destinations and one of the weighted gradients).  Dense layer weights are replicated by the caller and their
+    gradients all-reduced (outside the SpMM path)."""
 
     def __init__(self, rowptr, col, val, n, rank, world, group=None):
         from . import cabi
@@ -371,77 +412,205 @@ class DistGraph:
         colptr, _, row_t, val_t = cabi.csr2csc(rowptr, col, val, n, want_perm=False, want_val=val is not None)
         self.bwd = RowPartition(colptr, row_t, val_t, n, rank, world, cuts=self.fwd.row_cuts, group=group)
         self.row0, self.rows = self.fwd.row0, self.fwd.rows
+        self._bwd_mean = None
+        self._inv_deg = None
+        self._graph = (rowptr, col, val, n, rank, world, group) if val is not None else None     # for the mean backward's weights
 
-    def matmul(self, x_local: torch.Tensor) -> torch.Tensor:
-        return _DistSpMM.apply(x_local, self)
+    def inv_deg(self) -> torch.Tensor:
+        """1 / max(deg, 1) of this rank's rows of A."""
+        if self._inv_deg is None:
+            rp = self.fwd.rowptr
+            self._inv_deg = 1.0 / (rp[1:] - rp[:-1]).clamp(min=1).to(torch.float32)
+        return self._inv_deg
+
+    def bwd_mean(self) -> "RowPartition":
+        """A^T with the mean backward's weights (weighted graphs only; built on first use)."""
+        if self._bwd_mean is None:
+            from . import cabi
+            rowptr, col, val, n, rank, world, group = self._graph
+            colptr, _, row_t, val_t = cabi.csr2csc(rowptr, col, val, n, mean_scale=True, want_perm=False)
+            self._bwd_mean = RowPartition(colptr, row_t, val_t, n, rank, world, cuts=self.fwd.row_cuts, group=group)
+        return self._bwd_mean
+
+    def matmul(self, x_local: torch.Tensor, reduce: str = "sum") -> torch.Tensor:
+        if reduce in ("sum", "add"):
+            return _DistSpMM.apply(x_local, self)
+        if reduce == "mean":
+            return _DistSpMMMean.apply(x_local, self)
+        if reduce in ("max", "min"):
+            return _DistSpMMMinMax.apply(x_local, self, reduce)[0]
+        raise ValueError(f"isplib: unknown reduce '{reduce}' (expected sum|add|mean|max|min)")
 
 
-def _spmm_auto(self, x_local: torch.Tensor) -> torch.Tensor:
-    """Sum-SpMM of this partition on unpadded local rows [x_rows, K]: pads into the shard pitch, then
-    ISPLIB_DIST_SCHEDULE = tasks (default: one all-gather, then the stream schedule / task list / plain kernel by the
-    single-GPU rules applied to this rank's shard) | overlap (local column slices
-    during the all-gather) | pipelined (two column panels, panel 2 travels while panel 1 is aggregated; on the stream
-    schedule where isplib_suggest_stream accepts the panel, else on the task list) | direct
-    (per-peer send / receive in ISPLIB_DIRECT_BATCHES groups, shards aggregated as they land).
-    Whatever the schedule, a graph for which the slice rule says 0 runs gather + the plain kernel."""
+def _local_ops(self, k: int, reduce: str = "sum"):
+    """The schedule of this rank's local SpMM once the dense operand is complete in the padded gather buffer -- the
+    single-GPU rules applied to the rank's shard: ("stream", plan, workspace) where isplib_suggest_stream (sum / mean) or
+    isplib_suggest_stream_minmax (max / min; column-sorted rows -- the padded column ids keep the order) accepts it, else
+    ("tasks", plan, workspace) where isplib_suggest_slices gives a slice count, else ("plain", None, None).  Cached per
+    (k, reduce).  ISPLIB_STREAM=0 / ISPLIB_SLICES as in the plug-in."""
     import os
     from . import cabi
     from .plugin import suggest_slices
+    kind = "minmax" if reduce in ("max", "min") else "sum"
+    cache = self.__dict__.setdefault("_local", {})
+    key = (k, kind)
+    if key in cache:
+        return cache[key]
+    ops = None
+    stream_off = os.environ.get("ISPLIB_STREAM") == "0" or os.environ.get("ISPLIB_SLICES") is not None
+    if not stream_off and self.rows > 0 and self.nnz > 0:
+        if kind == "minmax":
+            geom = cabi.suggest_stream_minmax(self.rows, self.ncols_padded, self.nnz, k)
+        else:
+            geom = cabi.suggest_stream(self.rows, self.ncols_padded, self.nnz, k, self.val is not None)
+        if geom is not None:
+            plans = self.__dict__.setdefault("_stream_plans", {})
+            pkey = tuple(geom) + ((kind,) if kind == "minmax" else ())
+            if pkey not in plans:
+                plans[pkey] = self._stream_plan(geom, minmax=kind == "minmax")
+            sp = plans[pkey]
+            if sp is not None and not (kind == "minmax" and sp.perm.dtype != torch.int32):
+                ops = ("stream", sp, sp.workspace(minmax=kind == "minmax"))
+    if ops is None:
+        forced = os.environ.get("ISPLIB_SLICES")
+        s = int(forced) if forced is not None else suggest_slices(self.rows, self.ncols_padded, self.nnz, k, kind == "minmax")
+        if s > 0 and k >= 4 and self.nnz > 0:
+            plans = self.__dict__.setdefault("_task_plans", {})
+            if s not in plans:
+                plans[s] = self.task_plan(s)
+            if plans[s] is not None:
+                ops = ("tasks", plans[s], plans[s].workspace("max" if kind == "minmax" else "sum", k))
+    if ops is None:
+        ops = ("plain", None, None)
+    cache[key] = ops
+    return ops
+
+
+def _local_spmm(self, ops, buf: torch.Tensor, out: torch.Tensor, reduce: str = "sum", arg: Optional[torch.Tensor] = None):
+    """out[rows, K] (and arg: LOCAL CSR positions, sentinel = this rank's nnz) from the gathered buffer on schedule `ops`."""
+    from . import cabi
+    msg = cabi.MESSAGE[reduce]
+    kind, plan, work = ops
+    if kind == "stream" and reduce in ("max", "min"):
+        cabi.fusedMM_csr_stream_minmax_hip(msg, self.rowptr, self.nnz, plan, buf, out, arg, work)
+    elif kind == "stream":
+        cabi.fusedMM_csr_stream_hip(msg, self.rowptr, self.nnz, plan, buf, out, work)
+    elif kind == "tasks":
+        cabi.fusedMM_csr_tasks_hip(msg, self.rowptr, self.col_padded, self.val, plan, buf, out, arg, work)
+    else:
+        cabi.fusedMM_csr_hip(msg, self.rowptr, self.col_padded, self.val, buf, out, arg)
+    return out
+
+
+def _global_arg(self, arg: torch.Tensor) -> torch.Tensor:
+    """LOCAL CSR positions -> GLOBAL ones (+ this rank's edge offset; 'no winner' becomes the global nnz)."""
+    return torch.where(arg == self.nnz, arg.new_full((), self.total_nnz), arg + self.edge0)
+
+
+def _spmm_auto(self, x_local: torch.Tensor, reduce: str = "sum"):
+    """SpMM of this partition on unpadded local rows [x_rows, K]: pads into the shard pitch, then
+    ISPLIB_DIST_SCHEDULE = tasks (default: ONE all-gather, then the schedule the single-GPU rules pick for this rank's
+    shard -- `local_ops`: stream schedule / task list / plain kernel, every reduction) | overlap (local column slices
+    during the all-gather) | pipelined (two column panels, panel 2 travels while panel 1 is aggregated; on the stream
+    schedule where isplib_suggest_stream accepts the panel (sum / mean), else on the task list) | direct
+    (per-peer send / receive in ISPLIB_DIRECT_BATCHES groups, shards aggregated as they land).
+    Whatever the schedule, a graph for which the slice rule says 0 runs gather + the plain kernel.
+    Returns out for sum / mean, (out, arg) for max / min with arg = GLOBAL CSR positions (global nnz = no winner)."""
+    import os
+    from .plugin import suggest_slices
+    if reduce == "add":
+        reduce = "sum"
+    if reduce not in ("sum", "mean", "max", "min"):
+        raise ValueError(f"isplib: unknown reduce '{reduce}' (expected sum|add|mean|max|min)")
+    minmax = reduce in ("max", "min")
     k = x_local.size(1)
     mode = os.environ.get("ISPLIB_DIST_SCHEDULE", "tasks")
     if mode not in ("tasks", "overlap", "pipelined", "direct"):
         raise ValueError(f"ISPLIB_DIST_SCHEDULE={mode!r}: expected tasks | overlap | pipelined | direct")
     cache = self.__dict__.setdefault("_auto", {})
-    key = (k, mode)
+    key = (k, mode, reduce)
     if key not in cache:
-        s = suggest_slices(self.rows, self.ncols_padded, self.nnz, k)
         ops = None
-        if s > 0 and mode in ("overlap", "direct"):
-            forced = os.environ.get("ISPLIB_SLICES")        # one-pass sliced kernel: its own (whole-row) slice rule
-            ops = self.plan(k, "sum", slices=int(forced) if forced else None)
+        if mode in ("overlap", "direct"):
+            if suggest_slices(self.rows, self.ncols_padded, self.nnz, k, minmax) > 0:
+                forced = os.environ.get("ISPLIB_SLICES")        # one-pass sliced kernel: its own (whole-row) slice rule
+                ops = self.plan(k, reduce, slices=int(forced) if forced else None)
         elif mode == "pipelined" and k >= 32:
-            ops = self.pipeline_state(k, 2, "sum", stream=True)
-            if ops is None and s > 0:
-                ops = self.pipeline_state(k, 2, "sum")
-        else:
-            # one all-gather, then the single-GPU rule on this rank's shard: stream schedule where isplib_suggest_stream
-            # accepts it, else the task list, else the plain kernel (the collective is the same in all three: ranks
-            # may decide differently)
-            geom = None if os.environ.get("ISPLIB_STREAM") == "0" else cabi.suggest_stream(self.rows, self.ncols_padded, self.nnz, k, self.val is not None)
-            if geom is not None:
-                sp = self._stream_plan(geom)
-                ops = None if sp is None else (sp, sp.workspace())
-            if ops is None and s > 0:
-                plans = self.__dict__.setdefault("_task_plans", {})
-                if s not in plans:
-                    plans[s] = self.task_plan(s)
-                ops = None if plans[s] is None else (plans[s], plans[s].workspace("sum", k))
-        if self.world > 1 and mode in ("pipelined", "direct"):
-            # these two exchange X with other collectives than the one all-gather of the fallback: every rank must take
+            ops = None if minmax else self.pipeline_state(k, 2, reduce, stream=True)
+            if ops is None and suggest_slices(self.rows, self.ncols_padded, self.nnz, k, minmax) > 0:
+                ops = self.pipeline_state(k, 2, reduce)
+        if self.world > 1 and mode != "tasks":
+            # these exchange X with other collectives than the one all-gather of the fallback: every rank must take
             # the same branch, and whether a plan exists is decided from the rank's own shard
             ok = torch.tensor([0 if ops is None else 1], dtype=torch.int32, device=x_local.device)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
             if not int(ok):
                 ops = None
-        cache[key] = (ops, self.gather_buffer(k, x_local.device),
+        if ops is None:
+            # ONE all-gather, then the single-GPU rule on this rank's shard (the collective is the same whatever a rank
+            # decides, so ranks may decide differently)
+            mode_run, ops = "tasks", self.local_ops(k, reduce)
+        else:
+            mode_run = mode
+        cache[key] = (mode_run, ops, self.gather_buffer(k, x_local.device),
                       torch.zeros((self.max_rows, k), dtype=torch.float32, device=x_local.device))
-    ops, buf, shard = cache[key]
+    mode_run, ops, buf, shard = cache[key]
     shard[: self.x_rows].copy_(x_local)
     out = torch.empty((self.rows, k), dtype=torch.float32, device=x_local.device)
-    if ops is not None and mode == "overlap":
-        return self.spmm_overlapped(shard, buf, out, ops, "sum")
-    if ops is not None and mode == "direct":
-        return self.spmm_direct(shard, buf, out, ops, "sum", batches=int(os.environ.get("ISPLIB_DIRECT_BATCHES", "2")))
-    if ops is not None and mode == "pipelined" and k >= 32:
-        return self.spmm_pipelined(shard, out, ops, "sum")
-    self.all_gather(shard, buf)
-    if ops is not None and hasattr(ops[0], "words"):
-        cabi.fusedMM_csr_stream_hip(cabi.MSG_SPMM_SUM, self.rowptr, self.nnz, ops[0], buf, out, ops[1])
-    elif ops is not None:
-        cabi.fusedMM_csr_tasks_hip(cabi.MSG_SPMM_SUM, self.rowptr, self.col_padded, self.val, ops[0], buf, out, None, ops[1])
+    arg = torch.empty((self.rows, k), dtype=torch.int64, device=x_local.device) if minmax else None
+    if mode_run == "overlap":
+        self.spmm_overlapped(shard, buf, out, ops, reduce, arg)
+    elif mode_run == "direct":
+        self.spmm_direct(shard, buf, out, ops, reduce, arg, batches=int(os.environ.get("ISPLIB_DIRECT_BATCHES", "2")))
+    elif mode_run == "pipelined":
+        self.spmm_pipelined(shard, out, ops, reduce, arg)
     else:
-        cabi.fusedMM_csr_hip(cabi.MSG_SPMM_SUM, self.rowptr, self.col_padded, self.val, buf, out)
-    return out
+        self.all_gather(shard, buf)
+        self.local_spmm(ops, buf, out, reduce, arg)
+    return (out, self.global_arg(arg)) if minmax else out
+
+
+def _minmax_backward(self, arg_global: torch.Tensor, grad_out: torch.Tensor) -> torch.Tensor:
+    """dX of this rank's rows of the dense operand for a max / min forward of this partition: arg_global [rows, K] as
+    `spmm_auto` returned it, grad_out [rows, K].  Two all-gathers (int32 destinations, fp32 weighted gradients; padded to
+    the longest shard), then the deterministic scatter into the rank's own rows."""
+    from . import cabi
+    k = grad_out.size(1)
+    ok = arg_global != self.total_nnz
+    a = (arg_global - self.edge0).clamp_(0, max(self.nnz - 1, 0))
+    if self.nnz == 0:
+        dest = torch.full(arg_global.shape, -1, dtype=torch.int32, device=grad_out.device)
+        gval = torch.zeros_like(grad_out)
+    else:
+        dest = torch.where(ok, self.col[a], self.col.new_full((), -1)).to(torch.int32)
+        gval = torch.where(ok, grad_out if self.val is None else self.val[a] * grad_out, grad_out.new_zeros(()))
+    pad = max(self.row_cuts[p + 1] - self.row_cuts[p] for p in range(self.world))
+    if self.world > 1:
+        d_send = torch.full((pad, k), -1, dtype=torch.int32, device=grad_out.device)
+        g_send = torch.zeros((pad, k), dtype=torch.float32, device=grad_out.device)
+        d_send[: self.rows] = dest
+        g_send[: self.rows] = gval
+        d_all = torch.empty((self.world * pad, k), dtype=torch.int32, device=grad_out.device)
+        g_all = torch.empty((self.world * pad, k), dtype=torch.float32, device=grad_out.device)
+        dist.all_gather_into_tensor(d_all, d_send, group=self.group)
+        dist.all_gather_into_tensor(g_all, g_send, group=self.group)
+    else:
+        d_all, g_all = dest.contiguous(), gval.contiguous()
+    return self.scatter_rows(d_all, g_all, self.x_cuts[self.rank], self.x_rows)
 
 
 RowPartition.spmm_auto = _spmm_auto
+RowPartition.local_ops = _local_ops
+RowPartition.local_spmm = _local_spmm
+RowPartition.global_arg = _global_arg
+RowPartition.minmax_backward = _minmax_backward
+
+
+def _scatter_rows(dest: torch.Tensor, gval: torch.Tensor, lo: int, n: int) -> torch.Tensor:
+    """The local kernel of `minmax_backward` (isplib_scatter_rows_det_hip); a hook, so that the CPU / gloo tests of the
+    exchange can put a NumPy statement of it in its place."""
+    from . import cabi
+    return cabi.scatter_rows_det(dest, gval, lo, n)
+
+
+RowPartition.scatter_rows = staticmethod(_scatter_rows)

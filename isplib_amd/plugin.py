@@ -104,9 +104,31 @@ def suggest_slices(m: int, n: int, nnz: int, k: int, minmax: bool = False) -> in
     return int(cabi.lib().isplib_suggest_slices(int(m), int(n), int(nnz), int(k), int(bool(minmax))))   # one rule, in the C ABI
 
 
-# Measured choices that outlive the process: {graph signature: {"rows:k:minmax": slice count}}.  Filled by
+# Measured choices that outlive the process: {graph signature: {"rows:k:minmax": ["stream", streams, slices, chunk] |
+# ["tasks", slices] | ["plain"]}} (tables from before round 5: a bare slice count).  Filled by
 # iSpLibPlugin.autotune, written/merged by save_tuning/load_tuning; ISPLIB_TUNE_FILE names a file read at import.
 _tuning_db: dict = {}
+
+
+def _as_choice(entry):
+    """A tuning-table entry as a schedule choice: ("plain",) | ("tasks", slices) | ("stream", streams, slices, chunk).
+    Tables written before round 5 hold bare slice counts (0 = plain kernel)."""
+    if isinstance(entry, (int, float)):
+        return ("tasks", int(entry)) if int(entry) > 0 else ("plain",)
+    entry = tuple(entry)
+    return (str(entry[0]),) + tuple(int(v) for v in entry[1:])
+
+
+def tuned_choice(storage: SparseStorage, rows: int, k: int, minmax: bool = False):
+    """What `iSpLibPlugin.autotune` measured best for an SpMM of this graph whose dense operand has `rows` rows and k
+    columns (this process, or a loaded tuning table keyed by the graph's signature); None = nothing measured: the rules."""
+    key = (int(rows), int(k), bool(minmax))
+    hit = storage._tuned.get(key)
+    if hit is None and _tuning_db:
+        entry = _tuning_db.get(graph_signature(storage), {}).get(f"{key[0]}:{key[1]}:{int(key[2])}")
+        if entry is not None:
+            hit = storage._tuned[key] = _as_choice(entry)
+    return hit
 
 
 def graph_signature(storage: SparseStorage) -> str:
@@ -155,14 +177,11 @@ def choose_slices(storage: SparseStorage, rows: int, k: int, minmax: bool = Fals
     if env is not None:
         n = int(env)
         return n if 1 <= n <= 4096 else 0
-    tuned = storage._tuned.get((rows, k, minmax))
-    if tuned is not None:
-        return tuned
-    if _tuning_db:
-        tuned = _tuning_db.get(graph_signature(storage), {}).get(f"{rows}:{k}:{int(minmax)}")
-        if tuned is not None:
-            storage._tuned[(rows, k, minmax)] = int(tuned)
-            return int(tuned)
+    tuned = tuned_choice(storage, rows, k, minmax)
+    if tuned is not None and tuned[0] == "tasks":
+        return tuned[1]
+    if tuned is not None and tuned[0] == "plain":
+        return 0
     ruled = storage._tuned.get((rows, k, minmax, transposed))          # the rule's answer for this side, from last time
     if ruled is not None:
         return ruled
@@ -192,6 +211,14 @@ def choose_stream(storage: SparseStorage, m: int, n: int, k: int, weighted: bool
     forced = os.environ.get("ISPLIB_STREAM_GEOM")          # "streams:slices:chunk": tests and experiments
     if forced:
         return tuple(int(v) for v in forced.split(":"))
+    tuned = tuned_choice(storage, n, k, False)             # a measured choice for this graph and width beats the rule
+    if tuned is not None:
+        return tuple(tuned[1:]) if tuned[0] == "stream" else None
+    return stream_rule(storage, m, n, k, weighted)
+
+
+def stream_rule(storage: SparseStorage, m: int, n: int, k: int, weighted: bool = False):
+    """The rule's own answer (isplib_suggest_stream_weighted + the degree-skew adjustment), whatever was tuned."""
     from . import cabi
     geom = cabi.suggest_stream(m, n, storage._col.numel(), k, weighted)
     return None if geom is None else (geom[0], skew_adjusted(storage, geom[1], cap=512), geom[2])
@@ -207,6 +234,14 @@ def choose_stream_minmax(storage: SparseStorage, m: int, n: int, k: int):
     forced = os.environ.get("ISPLIB_STREAM_MINMAX_GEOM")   # "streams:slices:chunk": tests and experiments
     if forced:
         return tuple(int(v) for v in forced.split(":"))
+    tuned = tuned_choice(storage, n, k, True)
+    if tuned is not None:
+        return tuple(tuned[1:]) if tuned[0] == "stream" else None
+    return stream_minmax_rule(storage, m, n, k)
+
+
+def stream_minmax_rule(storage: SparseStorage, m: int, n: int, k: int):
+    """The rule's own answer for max / min (isplib_suggest_stream_minmax + the degree-skew adjustment)."""
     from . import cabi
     geom = cabi.suggest_stream_minmax(m, n, storage._col.numel(), k)
     return None if geom is None else (geom[0], skew_adjusted(storage, geom[1], cap=512), geom[2])
@@ -238,11 +273,14 @@ def spmm_autotuned(src, other: torch.Tensor, reduce: str = "sum") -> torch.Tenso
     else:                                                            # max / min: its own kernel geometry, sorted rows only
         geom = choose_stream_minmax(s, m_rows, mat.size(0), k)
         plan = s.stream_plan(False, geom, "minmax") if geom is not None else None
+    ran = ("stream",) + tuple(int(v) for v in geom) if plan is not None else None
     if plan is None:
         n_sl = choose_slices(s, mat.size(0), k, reduce in ("max", "min"))
         plan = s.plan(n_sl)                                          # per-graph, built once on the device
+        ran = ("tasks", int(n_sl)) if plan else ("plain",)
         if not plan:                                                 # the plain kernel: rows in a community order where that pays
             plan = s.row_order(False, k)
+    s._last_schedule = ran                                           # what this call's forward runs on (autotune checks it)
     if reduce in ("sum", "add", "mean"):
         colptr = val_t = row_t = None
         plan_t = []
@@ -372,22 +410,46 @@ class iSpLibPlugin:
                 _pyg_typing.WITH_PT20 = pt20
 
     @classmethod
-    def autotune(cls, src, k: int, reduce: str = "sum", candidates=(0, 2, 4, 6, 8, 12, 16, 24), reps: int = 3, other_rows=None):
-        """Times the SpMM of `src` at width `k` for each candidate slice count on the actual graph and keeps
-        the fastest for every later call (the heir of the reference's tuning scripts: autotuner/findbestk.py:34-38
-        sweeps K and prints a table, gpu/kernels/codegen.py:30-41 sweeps a launch parameter).  Returns
-        {slices: milliseconds}.  Costs one plan build per candidate; results live on the graph's storage."""
+    def autotune(cls, src, k: int, reduce: str = "sum", candidates=(0, 2, 4, 6, 8, 12, 16, 24), reps: int = 3, other_rows=None,
+                 stream_slices=(0.5, 0.75, 1.0, 1.25, 1.5), stream_chunk=(0.5, 2.0)):
+        """Times the SpMM of `src` at width `k` on every candidate SCHEDULE AND GEOMETRY on the actual graph and keeps the
+        fastest for every later call (the heir of the reference's tuning scripts: autotuner/findbestk.py:34-38 sweeps K and
+        prints a table, gpu/kernels/codegen.py:30-41 sweeps a launch parameter).  Candidates, each actually forced:
+          ("stream", streams, slices, chunk)  the stream schedule where its rule accepts the shape: the rule's column-slice
+                                              count x `stream_slices`, and the rule's hub-row chunk x `stream_chunk`
+          ("tasks", slices)                   the task list at every non-zero slice count of `candidates`
+          ("plain",)                          the row-per-wave kernel (a 0 in `candidates`)
+        A candidate only counts if the call really ran on it (a plan builder that declines falls back to another
+        schedule: that measurement is dropped).  Returns {choice: milliseconds}; the winner lives on the graph's storage
+        and in the table `save_tuning` writes.  Costs one plan build per candidate; the losers' stream plans are freed."""
         rowptr, col, value = src.csr()
         x = torch.zeros((other_rows or src.sparse_sizes()[1], k), dtype=torch.float32, device=col.device)
         s = _storage_of(src, x)
         minmax = reduce in ("max", "min")
         key = (x.size(0), k, minmax)
+        m_rows = rowptr.numel() - 1
+        before = s._tuned.pop(key, None)
+        rule = stream_minmax_rule(s, m_rows, x.size(0), k) if minmax else stream_rule(s, m_rows, x.size(0), k, s._value is not None)
+        stream_off = os.environ.get("ISPLIB_STREAM", "1") == "0" or os.environ.get("ISPLIB_SLICES") is not None
+        cands = []
+        if rule is not None and not stream_off and k >= 4 and x.size(0) < (1 << 24):
+            st, sl, ch = rule
+            for f in stream_slices:
+                cands.append(("stream", st, max(1, min(512, int(sl * f + 0.5))), ch))
+            for f in stream_chunk:
+                cands.append(("stream", st, sl, max(256, int(ch * f))))
+        for c in candidates:
+            cands.append(("tasks", int(c)) if int(c) > 0 else ("plain",))
+        cands = list(dict.fromkeys(cands))                         # the rule's own geometry appears once
         times = {}
         start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for cand in candidates:
+        built = set(s._streams)
+        for cand in cands:
             s._tuned[key] = cand
             try:
                 spmm_autotuned(src, x, reduce)                     # builds the plan, warms up
+                if s._last_schedule != cand:                       # the builder declined: this is another schedule's time
+                    continue
                 start.record()
                 for _ in range(reps):
                     spmm_autotuned(src, x, reduce)
@@ -397,10 +459,18 @@ class iSpLibPlugin:
             except RuntimeError:
                 continue
         if times:
-            s._tuned[key] = min(times, key=times.get)
-            _tuning_db.setdefault(graph_signature(s), {})[f"{key[0]}:{k}:{int(minmax)}"] = s._tuned[key]
+            best = s._tuned[key] = min(times, key=times.get)
+            _tuning_db.setdefault(graph_signature(s), {})[f"{key[0]}:{k}:{int(minmax)}"] = list(best)
+        elif before is not None:
+            s._tuned[key] = before
         else:
             s._tuned.pop(key, None)
+        keep = s._tuned.get(key)
+        for pkey in [p_ for p_ in s._streams if p_ not in built]:      # stream plans of the losing geometries: 4-12 B per edge each
+            if not (keep is not None and keep[0] == "stream" and pkey[1:4] == tuple(keep[1:])):
+                s._streams.pop(pkey, None)
+                for vkey in [v_ for v_ in s._stream_vals if v_[:len(pkey)] == pkey]:
+                    s._stream_vals.pop(vkey, None)
         return times
 
     @classmethod
@@ -421,7 +491,7 @@ class iSpLibPlugin:
         with open(path) as f:
             table = json.load(f)
         for sig, entries in table.items():
-            _tuning_db.setdefault(sig, {}).update({k: int(v) for k, v in entries.items()})
+            _tuning_db.setdefault(sig, {}).update({k: list(_as_choice(v)) for k, v in entries.items()})
         return len(table)
 
     @classmethod

@@ -50,7 +50,10 @@ class SparseStorage:
         # order per (transposed, streams, slices, chunk, kind) with the state of `value` they were gathered from
         self._streams = {}
         self._stream_vals = {}
-        self._tuned = {}          # (dense rows, k, minmax) -> slice count measured by iSpLibPlugin.autotune
+        # (dense rows, k, minmax) -> schedule choice measured by iSpLibPlugin.autotune: ("stream", streams, slices, chunk) |
+        # ("tasks", slices) | ("plain",); (dense rows, k, minmax, transposed) -> the slice rule's answer, remembered
+        self._tuned = {}
+        self._last_schedule = None   # what the last spmm_autotuned call on this graph ran its forward on
 
     def sparse_sizes(self) -> Tuple[int, int]:
         return self._sparse_sizes

@@ -144,6 +144,14 @@ def spmm_fw(rowptr, col, value, mat, reduce="sum"):
     return out, arg
 
 
+def set_empty_row(mode: str = "zero") -> None:
+    """What an EMPTY row of max / min holds: "zero" (default; torch_sparse's CPU semantic) or "init" (the launcher's
+    pre-fill, lowest() / max() of csrc/fusedmm.cpp:147-150, left untouched).  The HIP path has the same switch."""
+    if mode not in ("zero", "init"):
+        raise ValueError("empty-row mode: 'zero' or 'init'")
+    lib().oracle_set_empty_row(1 if mode == "init" else 0)
+
+
 def spmm_sum_timed(rowptr, col, value, mat, reps=5):
     """bench.py's CPU baseline: SpMM-sum with NUMA-aware placement and a static nnz-balanced row partition
     (fusedmm_oracle.c: oracle_spmm_sum_timed).  Returns (seconds per pass [reps], out)."""

@@ -44,7 +44,8 @@
  *     authors compared against (isplib/__init__.py:120-128).
  *   - z_arg holds the ABSOLUTE CSR position j (the backward indexes col/value
  *     with it, csrc/fusedmm.cpp:422,434-436,442).
- *   - Empty row under MAX/MIN: value 0, z_arg left at the caller's sentinel
+ *   - Empty row under MAX/MIN: value 0 (oracle_set_empty_row(1): left at the
+ *     caller's init, lowest() / max()), z_arg left at the caller's sentinel
  *     (nnz, csrc/fusedmm.cpp:171,177).  A non-empty row in which nothing
  *     wins (all NaN / all -inf) keeps the caller's init (+-FLT_MAX) and nnz.
  *   - MEAN: sum in CSR order, one IEEE division by max(deg,1) per element.
@@ -134,6 +135,9 @@ static void row_min(const VALUETYPE *val, const INDEXTYPE *indx,
 #include <float.h>
 #include <stdlib.h>
 
+static int g_empty_row_init = 0;
+void oracle_set_empty_row(int init) { g_empty_row_init = init ? 1 : 0; }
+
 static VALUETYPE sop_menu(int kind, VALUETYPE s, VALUETYPE p)
 {
    switch (kind) {
@@ -217,13 +221,19 @@ int oracle_fusedMM_csr_udef(const int32_t imessage, const INDEXTYPE m, const IND
             const VALUETYPE d = (VALUETYPE)((e - b) > 1 ? (e - b) : 1);
             for (INDEXTYPE c = 0; c < k; c++) zi[c] = zi[c] / d;
          }
-         if (aop != 1 && e <= b)
+         if (aop != 1 && e <= b && !g_empty_row_init)
             for (INDEXTYPE c = 0; c < k; c++) zi[c] = 0.0f;
       }
       free(t);
    }
    return ORC_SUCCESS;
 }
+
+/* The one convention nothing in the reference tree pins: an EMPTY row under MAX/MIN.  0 (default): the row is written 0, as
+ * torch_sparse's CPU kernel does.  1 ("init"): the row is left as the caller pre-filled it -- lowest() / max(), csrc/fusedmm.cpp:
+ * 147-150 -- which is what a body that only visits stored entries returns.  z_arg stays the caller's sentinel either way.
+ * The HIP path has the same switch (isplib_hip_set_empty_row / ISPLIB_EMPTY_ROW); the tests run both.
+ * (oracle_set_empty_row, defined above the generic pipeline, which follows the same switch.) */
 
 /* Same 20-argument C ABI as csrc/fusedMM.h:77-99. Host pointers. */
 int fusedMM_csr(const int32_t imessage, const INDEXTYPE m, const INDEXTYPE n,
@@ -261,7 +271,8 @@ int fusedMM_csr(const int32_t imessage, const INDEXTYPE m, const INDEXTYPE n,
          }
       } else {
          if (e <= b) {
-            for (INDEXTYPE kk = 0; kk < k; kk++) zi[kk] = (VALUETYPE)0;
+            if (!g_empty_row_init)
+               for (INDEXTYPE kk = 0; kk < k; kk++) zi[kk] = (VALUETYPE)0;
          } else if (aop == ORC_AOP_MAX) {
             row_max(val, indx, b, e, k, y, ldy, zi, ai);
          } else {

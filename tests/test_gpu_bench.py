@@ -1,0 +1,41 @@
+"""bench.py's one-GPU pieces that are not the timed region itself."""
+import importlib.util
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+def test_scaling_emulated_block_has_every_rank_and_the_exchange_model(gpu):
+    """`extra[*].scaling_emulated`: every rank's shard of the 1-D row partition timed on this GPU with
+    the schedule spmm_auto would run on it, nnz balance, all-gather bytes, exchange modelled over xGMI -- labelled as an
+    emulation.  Small graph: the point is the bookkeeping (ranks cover every edge once, bytes follow the shard pitch)."""
+    from isplib_amd import synth
+    bench = _bench()
+    rowptr, col, n = synth.dataset_like("reddit", device=gpu, scale=0.02)
+    rec = bench.scaling_emulated(gpu, rowptr, col, n, 32, "scaled reddit-like", one_gpu_ms=1.0, ranks=(2, 3))
+    assert "EMULATED" in rec["what"] and "NO RCCL" in rec["what"]
+    assert [p["ranks"] for p in rec["points"]] == [2, 3]
+    for p in rec["points"]:
+        assert len(p["per_rank"]) == p["ranks"]
+        assert sum(r["nnz"] for r in p["per_rank"]) == col.numel()
+        assert sum(r["rows"] for r in p["per_rank"]) == n
+        assert p["local_spmm_ms_max"] >= p["local_spmm_ms_mean"] > 0
+        assert 1.0 <= p["nnz_balance_max_over_mean"] < 1.5
+        shard = p["all_gather_bytes_sent_per_rank"]
+        assert shard % (192 * 32 * 4) == 0 and shard * p["ranks"] >= n * 32 * 4
+        assert p["all_gather_bytes_received_per_rank"] == (p["ranks"] - 1) * shard
+        direct = p["exchange_model_ms"]["direct_one_link_per_peer"]
+        assert abs(direct - shard / 153e9 * 1e3) < 1e-9 and abs(p["exchange_model_ms"]["ring"] - (p["ranks"] - 1) * direct) < 1e-9
+        assert abs(p["step_model_ms"]["direct, no overlap"] - (p["local_spmm_ms_max"] + direct)) < 1e-9
+        assert abs(p["compute_speedup_over_one_gpu"] - 1.0 / p["local_spmm_ms_max"]) < 1e-9

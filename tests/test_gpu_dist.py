@@ -49,6 +49,49 @@ for slices, mode in (("0", "tasks"), ("8", "tasks"), ("8", "overlap"), ("6", "pi
     dmag = oracle.spmm_sum_bw(rowptr, col, np.abs(val), n, np.abs(g))
     assert np.all(np.abs(xs.grad.cpu().numpy() - dref[r0:r1]) <= 1e-5 * dmag[r0:r1] + 1e-30), (slices, mode)
 os.environ.pop("ISPLIB_SLICES", None)
+# every reduction with autograd under the partition (DistGraph.matmul(x, reduce)): default exchange (one all-gather + the
+# schedule the single-GPU rules pick for the shard; forced onto this small graph: stream plans, then the task list) and the
+# overlapped / direct exchanges.  Forward rows bit for bit the single-device rows for max / min (values AND global
+# positions), within the bound for sum / mean; gradients against the oracle's backward formulas.
+os.environ["ISPLIB_DIST_SCHEDULE"] = "tasks"
+import isplib_amd.cabi as cabi_mod
+rule, rule_mm = cabi_mod.suggest_stream, cabi_mod.suggest_stream_minmax
+for forced in ("stream", "tasks", "plain", "overlap", "direct"):
+    cabi_mod.suggest_stream = (lambda m_, n_, e_, k_, w_=False: (4, 3, 200)) if forced == "stream" else (lambda *a_, **kw_: None)
+    cabi_mod.suggest_stream_minmax = (lambda m_, n_, e_, k_: (4, 3, 200)) if forced == "stream" else (lambda *a_, **kw_: None)
+    plugin.suggest_slices = (lambda *a_, **kw_: 0 if forced == "plain" else 6)
+    os.environ["ISPLIB_DIST_SCHEDULE"] = forced if forced in ("overlap", "direct") else "tasks"
+    for weighted in (True, False):
+        vv = val if weighted else None
+        ones = np.ones(col.size, np.float32)
+        graph = DistGraph(t(rowptr), t(col), None if vv is None else t(vv), n, rank, world)
+        r0, r1 = graph.row0, graph.row0 + graph.rows
+        for red in ("sum", "mean", "max", "min"):
+            kind, _, _ = graph.fwd.local_ops(k, red)
+            if forced in ("stream", "tasks", "plain"):
+                assert kind == forced, (forced, red, kind)
+            xs = t(x[r0:r1].copy()).requires_grad_(True)
+            out = graph.matmul(xs, red)
+            out.backward(t(g[r0:r1].copy()))
+            torch.cuda.synchronize()
+            w_ = vv if weighted else ones
+            ref, ref_arg = oracle.spmm_fw(rowptr, col, w_, x, red)
+            mag, _ = oracle.spmm_fw(rowptr, col, np.abs(w_), np.abs(x), "sum")
+            if red in ("max", "min"):
+                assert np.array_equal(out.detach().cpu().numpy(), ref[r0:r1]), (forced, weighted, red)
+                _, garg = graph.fwd.spmm_auto(t(x[r0:r1].copy()), red)
+                assert np.array_equal(garg.cpu().numpy(), ref_arg[r0:r1]), (forced, weighted, red)
+                dref = oracle.spmm_minmax_bw(col, w_, x, ref_arg, g)[1]
+                dmag = oracle.spmm_minmax_bw(col, np.abs(w_), x, ref_arg, np.abs(g))[1]
+            else:
+                if red == "mean":
+                    mag = mag / np.maximum(np.diff(rowptr), 1)[:, None]
+                assert np.all(np.abs(out.detach().cpu().numpy() - ref[r0:r1]) <= 1e-5 * mag[r0:r1] + 1e-30), (forced, weighted, red)
+                bw = oracle.spmm_sum_bw if red == "sum" else oracle.spmm_mean_bw
+                dref, dmag = bw(rowptr, col, w_, n, g), bw(rowptr, col, np.abs(w_), n, np.abs(g))
+            assert np.all(np.abs(xs.grad.cpu().numpy() - dref[r0:r1]) <= 1e-5 * dmag[r0:r1] + 1e-30), (forced, weighted, red)
+cabi_mod.suggest_stream, cabi_mod.suggest_stream_minmax = rule, rule_mm
+os.environ["ISPLIB_DIST_SCHEDULE"] = "tasks"
 # pipelined K-panel schedule: bitwise the task-list SpMM run panel by panel after one gather (max/min: also
 # bitwise the unpanelled call; sums differ from it in the last bits, the slots per wave depend on the width)
 from isplib_amd import cabi

@@ -406,11 +406,57 @@ def test_autotune_keeps_the_fastest_slice_count(gpu, oracle_mod):
     x = cases.dense(600, 64, 3)
     adj = isplib_amd.SparseTensor.from_csr(_t(rowptr, gpu), _t(col, gpu), _t(val, gpu), (600, 600))
     times = isplib_amd.iSpLibPlugin.autotune(adj, 64, "sum", candidates=(0, 8, 16))
-    assert set(times) == {0, 8, 16} and all(t > 0 for t in times.values())
+    # (a graph this small is below the stream rule: the candidates are the plain kernel and the two task lists)
+    assert set(times) == {("plain",), ("tasks", 8), ("tasks", 16)} and all(t > 0 for t in times.values())
     assert adj.storage._tuned[(600, 64, False)] == min(times, key=times.get)
     out = isplib_amd.matmul(adj, _t(x, gpu))
+    assert adj.storage._last_schedule == min(times, key=times.get)
     ref, _ = oracle_mod.spmm_fw(rowptr, col, val, x, "sum")
     assert np.all(np.abs(out.cpu().numpy() - ref) <= cases.sum_tolerance(oracle_mod, rowptr, col, val, x))
+
+
+@pytest.mark.parametrize("reduce", ("sum", "max"))
+def test_autotune_sweeps_the_schedule_that_runs_and_replays_the_persisted_choice(gpu, oracle_mod, tmp_path, reduce):
+    """on a graph the stream rule ACCEPTS (a tenth of the Reddit shape: 23 K rows, 11 M edges) the tuner
+    must time distinct stream plans (slice counts around the rule's, other hub-row chunks), the task list and the plain
+    kernel, each really forced -- `_last_schedule` is what ran --, persist (schedule, streams, slices, chunk), and a fresh
+    graph object of the same content must replay that choice from the saved table.  Result within the oracle bound."""
+    import isplib_amd
+    from isplib_amd import plugin, synth
+    rowptr, col, n = synth.dataset_like("reddit", device=gpu, scale=0.1)
+    k = 64
+    adj = isplib_amd.SparseTensor.from_csr(rowptr, col, None, (n, n), validate=False)
+    rule = plugin.stream_minmax_rule(adj.storage, n, n, k) if reduce == "max" else plugin.stream_rule(adj.storage, n, n, k)
+    assert rule is not None, "the test graph must be one the stream rule accepts"
+    plugin._tuning_db.clear()
+    times = isplib_amd.iSpLibPlugin.autotune(adj, k, reduce, candidates=(0, 4, 8))
+    streams = [c for c in times if c[0] == "stream"]
+    assert len({c[2] for c in streams}) >= 4 and len({c[3] for c in streams}) >= 2, times      # distinct slice counts AND chunks ran
+    assert ("stream",) + tuple(rule) in times and ("plain",) in times and ("tasks", 4) in times and ("tasks", 8) in times
+    assert len(set(round(t, 6) for t in times.values())) > 1
+    best = min(times, key=times.get)
+    assert adj.storage._tuned[(n, k, reduce == "max")] == best
+    # only the winner's stream plan stays on the graph
+    kept = [p for p in adj.storage._streams if adj.storage._streams[p] is not None]
+    assert all(best[0] == "stream" and p[1:4] == tuple(best[1:]) for p in kept), (best, kept)
+    x = synth.features(n, k, device=gpu, integer=reduce == "max")
+    out = isplib_amd.matmul(adj, x, reduce)
+    assert adj.storage._last_schedule == best
+    isplib_amd.iSpLibPlugin.save_tuning(tmp_path / "tune.json")
+    plugin._tuning_db.clear()
+    fresh = isplib_amd.SparseTensor.from_csr(rowptr.clone(), col.clone(), None, (n, n), validate=False)
+    assert isplib_amd.iSpLibPlugin.load_tuning(tmp_path / "tune.json") == 1
+    out2 = isplib_amd.matmul(fresh, x, reduce)
+    assert fresh.storage._last_schedule == best, "the persisted (schedule, geometry) must be what a fresh graph object runs"
+    assert torch.equal(out, out2)
+    rp, cl, xx = rowptr.cpu().numpy(), col.cpu().numpy(), x.cpu().numpy()
+    ones = np.ones(cl.size, np.float32)
+    ref, _ = oracle_mod.spmm_fw(rp, cl, ones, xx, reduce)
+    if reduce == "max":
+        assert np.array_equal(out.cpu().numpy(), ref)
+    else:
+        assert np.all(np.abs(out.cpu().numpy() - ref) <= cases.sum_tolerance(oracle_mod, rp, cl, ones, xx))
+    plugin._tuning_db.clear()
 
 
 def test_mtx_graph_tuning_file_and_generic_pipeline_through_the_package(gpu, oracle_mod, tmp_path):
@@ -432,7 +478,8 @@ def test_mtx_graph_tuning_file_and_generic_pipeline_through_the_package(gpu, ora
     plugin._tuning_db.clear()
     fresh = isplib_amd.SparseTensor.from_mtx(tmp_path / "g.mtx", device=gpu)
     assert isplib_amd.iSpLibPlugin.load_tuning(tmp_path / "tune.json") == 1
-    assert plugin.choose_slices(fresh.storage, 500, 32) == best
+    assert plugin.tuned_choice(fresh.storage, 500, 32) == best
+    assert plugin.choose_slices(fresh.storage, 500, 32) == (best[1] if best[0] == "tasks" else 0)
     x = cases.dense(500, 32, 3)
     out = isplib_amd.matmul(fresh, _t(x, gpu))
     v = fresh.csr()[2].cpu().numpy()
@@ -509,6 +556,40 @@ def test_fused_gcn_normalised_aggregation_on_the_stream_schedule(gpu, oracle_mod
             _close(bs.grad, dz.sum(0), rtol=1e-5, atol=1e-4)
     assert any(key[0] is False for key in adj.storage._streams) and any(key[0] is True for key in adj.storage._streams), \
         "both directions must have run on stream plans"
+
+
+@pytest.mark.parametrize("n,k,pitch", ((1000, 41, 48), (513, 7, None), (700, 300, None), (3, 64, 64), (2049, 32, None)))
+def test_gcn_dense_passes_match_torch(gpu, n, k, pitch):
+    """isplib_row_scale_hip / isplib_masked_scale_colsum_hip (the passes either side of the fused GCN aggregation) against the
+    ATen expressions they replace: ragged row counts (blocks of 512 rows), widths below, at and above the 256 column lanes,
+    a wider output pitch (its padding must be written, as zeros), every optional operand absent in turn; the column sums
+    twice for bitwise reproducibility."""
+    from isplib_amd import cabi
+    gen = torch.Generator(device=gpu)
+    gen.manual_seed(n * 1000 + k)
+    x = torch.randn((n, k), generator=gen, device=gpu)
+    dz = torch.randn((n, k), generator=gen, device=gpu)
+    out = torch.relu(torch.randn((n, k), generator=gen, device=gpu))
+    scale = torch.rand(n, generator=gen, device=gpu) + 0.1
+    y = cabi.row_scale(x, scale, pitch)
+    assert torch.equal(y, x * scale[:, None])
+    if pitch and pitch > k:
+        assert y.stride(0) == pitch and bool((torch.as_strided(y, (n, pitch - k), (pitch, 1), k) == 0).all())
+    wide = torch.randn((n, k + 5), generator=gen, device=gpu)[:, 2:2 + k]               # a row-strided input
+    assert torch.equal(cabi.row_scale(wide, scale), wide * scale[:, None])
+    for mask, sc in ((out, scale), (None, scale), (out, None), (None, None)):
+        g = dz if mask is None else dz * (mask > 0)
+        gy, gb = cabi.masked_scale_colsum(dz, mask, sc, pitch=pitch)
+        assert torch.equal(gy, g if sc is None else g * sc[:, None])
+        want = g.double().sum(0)
+        bound = 1e-6 * g.double().abs().sum(0) + 1e-30
+        assert bool(((gb.double() - want).abs() <= bound).all())
+        gy2, gb2 = cabi.masked_scale_colsum(dz, mask, sc, pitch=pitch)
+        assert torch.equal(gb.view(torch.int32), gb2.view(torch.int32)), "column sums must be bitwise reproducible"
+        _, only_bias = cabi.masked_scale_colsum(dz, mask, sc, want_gy=False)
+        assert torch.equal(only_bias, gb)
+        only_gy, none = cabi.masked_scale_colsum(dz, mask, sc, want_bias=False)
+        assert none is None and torch.equal(only_gy, gy)
 
 
 def test_task_epilogue_entry_point(gpu, oracle_mod):

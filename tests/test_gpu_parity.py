@@ -435,3 +435,71 @@ def test_plugin_and_handle_take_the_community_order_where_the_operand_is_beyond_
         assert torch.equal(h.spmm_backward(x, mean=False), want)
     finally:
         h.close()
+
+
+def test_empty_row_convention_switch_on_every_schedule(gpu, oracle_mod):
+    """the reference launcher pre-fills max / min outputs with lowest() / max() and nothing in its
+    tree rewrites an empty row (csrc/fusedmm.cpp:147-150); oracle and kernels write 0 by default.  With
+    isplib_hip_set_empty_row(1) ("init") every schedule -- plain, column-sliced, task list, stream, generic pipeline --
+    returns the pre-fill instead (-FLT_MAX / +FLT_MAX), positions nnz as before; every other row is bit for bit what it was,
+    and the oracle's own switch gives the same answer.  sum / mean are 0 either way."""
+    from isplib_amd import cabi
+    from isplib_amd.plan import build_stream_plan, build_task_plan
+    rowptr, col = cases.random_csr(150, 130, 9.0, seed=77, empty_rows=(0, 17, 76, 149))
+    val = cases.weights(col.size, 4)
+    x = cases.dense(130, 48, 3)
+    d = [torch.from_numpy(a).to(gpu) for a in (rowptr, col, val, x)]
+    empty = np.diff(rowptr) == 0
+    assert empty.sum() >= 4
+    table, ok = cabi.spmm_slices(d[0], d[1], 130, 4)
+    tplan = build_task_plan(d[0], d[1], 130, 4, chunk=64, short_row=4)
+    splan = build_stream_plan(d[0], d[1], d[2], 130, 3, 4, None, 4, 64, minmax=True)
+    sum_plan = build_stream_plan(d[0], d[1], d[2], 130, 3, 4, None, 4, 64)
+    assert ok and tplan is not None and splan is not None
+
+    def run_all(red):
+        outs = {"plain": cabi.spmm(d[0], d[1], d[2], d[3], red),
+                "sliced": cabi.spmm_sliced(d[0], d[1], d[2], table, 4, d[3], red),
+                "tasks": cabi.spmm_tasks(d[0], d[1], d[2], tplan, d[3], red)}
+        if red in ("max", "min"):
+            outs["stream"] = cabi.spmm_stream_minmax(d[0], col.size, splan, d[3], red)
+            outs["stream, values only"] = cabi.spmm_stream_minmax(d[0], col.size, splan, d[3], red, want_arg=False)
+        else:
+            outs["stream"] = (cabi.spmm_stream(d[0], col.size, sum_plan, d[3], red), None)
+        return outs
+
+    try:
+        for red in ("max", "min", "sum", "mean"):
+            cabi.set_empty_row("zero")
+            oracle_mod.set_empty_row("zero")
+            assert cabi.get_empty_row() == "zero"
+            ref0, arg0 = oracle_mod.spmm_fw(rowptr, col, val, x, red)
+            zero = run_all(red)
+            cabi.set_empty_row("init")
+            oracle_mod.set_empty_row("init")
+            assert cabi.get_empty_row() == "init"
+            ref1, arg1 = oracle_mod.spmm_fw(rowptr, col, val, x, red)
+            init = run_all(red)
+            if red in ("max", "min"):
+                fill = np.float32(-np.finfo(np.float32).max if red == "max" else np.finfo(np.float32).max)
+                assert np.all(ref0[empty] == 0) and np.all(ref1[empty] == fill) and np.array_equal(ref0[~empty], ref1[~empty])
+                assert np.array_equal(arg0, arg1) and np.all(arg1[empty] == col.size)
+            else:
+                assert np.array_equal(ref0, ref1) and np.all(ref1[empty] == 0)
+            for name in zero:
+                z0, a0 = zero[name]
+                z1, a1 = init[name]
+                z0, z1 = z0.cpu().numpy(), z1.cpu().numpy()
+                if red in ("max", "min"):
+                    assert np.array_equal(z0, ref0) and np.array_equal(z1, ref1), (red, name)
+                    if a0 is not None:
+                        assert np.array_equal(a0.cpu().numpy(), arg0) and np.array_equal(a1.cpu().numpy(), arg1), (red, name)
+                else:
+                    assert np.array_equal(z0, z1) and np.all(z1[empty] == 0), (red, name)
+        # the generic pipeline's max word follows the same switch
+        word = cabi.VOP["add"] | cabi.ROP["noop"] | cabi.SOP["noop"] | cabi.VSC["noop"] | cabi.AOP["max"]      # z_i = max_j (x_i + y_j)
+        st, z, zarg = cabi.fusedmm(word, d[0], d[1], d[2], torch.zeros((150, 48), device=gpu), d[3])
+        assert st == 0 and np.all(z.cpu().numpy()[empty] == -np.finfo(np.float32).max) and np.all(zarg.cpu().numpy()[empty] == col.size)
+    finally:
+        cabi.set_empty_row("zero")
+        oracle_mod.set_empty_row("zero")

@@ -390,6 +390,29 @@ def test_stream_minmax_hub_row(gpu, oracle_mod, k):
     _stream_minmax_all(gpu, oracle_mod, rowptr, col, val, x, native=True, geoms=((4, 8, 16, 64), (8, 3, 5, 200)))
 
 
+def test_stream_minmax_values_only_hub_fold_ignores_the_unwritten_index_plane(gpu, oracle_mod):
+    """Round-4 advisor: the values-only launch (z_arg = NULL) never writes the partial rows' index plane, yet the hub fold
+    read it to break ties -- the sign of a +0 / -0 tie between chunks of a hub row then depended on stale workspace memory.
+    The fold of a values-only launch now breaks ties by chunk order.  Whatever the index plane holds (zeros, ones, the
+    positions of an earlier launch), the values must be the with-positions launch's, bit for bit."""
+    from isplib_amd import cabi
+    from isplib_amd.plan import build_stream_plan
+    rowptr, col = cases.random_csr(64, 400, 6.0, seed=9, empty_rows=(0, 63), hub=(17, 12345), duplicates=True)
+    x = cases.dense(400, 64, 3, "signed_zero")
+    d_rowptr, d_col, d_x = _t(rowptr, gpu), _t(col, gpu), _t(x, gpu)
+    for (streams, s, wpg, chunk) in ((4, 8, 16, 64), (8, 3, 5, 200)):
+        plan = build_stream_plan(d_rowptr, d_col, None, 400, s, wpg, None, streams, chunk, minmax=True)
+        assert plan.n_parts > 0 and plan.n_hub > 0
+        for red in ("max", "min"):
+            want, arg = cabi.spmm_stream_minmax(d_rowptr, col.size, plan, d_x, red)
+            _check(oracle_mod, rowptr, col, np.ones(col.size, np.float32), x, red, want, arg)
+            for fill in (0x00, 0xFF, 0x7F):
+                ws = plan.workspace(minmax=True)
+                ws.view(torch.uint8).fill_(fill)
+                got, _ = cabi.spmm_stream_minmax(d_rowptr, col.size, plan, d_x, red, workspace=ws, want_arg=False)
+                assert torch.equal(got.view(torch.int32), want.view(torch.int32)), (streams, red, fill)
+
+
 def test_stream_minmax_refuses_unsorted_rows(gpu):
     """The tie rule needs rows whose columns ascend: both plan builders decline anything else (-> task list)."""
     from isplib_amd import cabi

@@ -223,6 +223,24 @@ for nb in sorted({{1, 2, max(world - 1, 1)}}):
     dist.barrier()
 sizes = [part.row_cuts[i + 1] - part.row_cuts[i] for i in range(world)]
 assert sum(sizes) == 97
+# the exchange of the max / min backward (RowPartition.minmax_backward: destinations + weighted gradients all-gathered in
+# global row order, every rank keeps what lands in its own rows); the local kernel is replaced by a NumPy statement of it
+def scatter(dest, gval, lo, n_):
+    d, g_ = dest.numpy().astype(np.int64) - lo, gval.numpy()
+    out = np.zeros((n_, g_.shape[1]), np.float32)
+    rows, cols = np.nonzero((dest.numpy() >= 0) & (d >= 0) & (d < n_))
+    np.add.at(out, (d[rows, cols], cols), g_[rows, cols])        # row-major = ascending global row: the kernel's order
+    return t(out)
+RowPartition.scatter_rows = staticmethod(scatter)
+g = cases.dense(97, 24, 7)
+r0, r1 = part.row_cuts[rank], part.row_cuts[rank + 1]
+for red in ("max", "min"):
+    ref, ref_arg = oracle.spmm_fw(rowptr, col, val, x, red)
+    _, want = oracle.spmm_minmax_bw(col, val, x, ref_arg, g)
+    got = part.minmax_backward(t(ref_arg[r0:r1].copy()), t(g[r0:r1].copy()))
+    x0, x1 = part.x_cuts[rank], part.x_cuts[rank + 1]
+    assert got.shape == (x1 - x0, 24)
+    assert np.allclose(got.numpy(), want[x0:x1], rtol=1e-6, atol=1e-6), red
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")

@@ -269,3 +269,27 @@ def test_timed_baseline_entry_computes_the_same_rows(oracle_mod):
     ref, _ = oracle_mod.spmm_fw(rowptr, col, val, x, "sum")
     secs, out = oracle_mod.spmm_sum_timed(rowptr, col, val, x, reps=2)
     assert secs.shape == (2,) and np.all(secs >= 0) and np.array_equal(out, ref)
+
+
+def test_empty_row_switch_of_the_oracle():
+    """The open convention (oracle/fusedmm_oracle.c header): an empty row of max / min is 0 by default and, with
+    oracle.set_empty_row("init"), what the reference launcher pre-filled it with (csrc/fusedmm.cpp:147-150); positions
+    are the launcher's sentinel nnz either way; every non-empty row and sum / mean are untouched by the switch."""
+    import oracle
+    rowptr = np.array([0, 0, 2, 2, 3], np.int64)
+    col = np.array([1, 2, 0], np.int64)
+    val = np.array([2.0, -1.0, 3.0], np.float32)
+    x = np.array([[1, -2], [3, 4], [5, -6]], np.float32)
+    try:
+        for red, fill in (("max", -np.finfo(np.float32).max), ("min", np.finfo(np.float32).max)):
+            oracle.set_empty_row("zero")
+            z0, a0 = oracle.spmm_fw(rowptr, col, val, x, red)
+            oracle.set_empty_row("init")
+            z1, a1 = oracle.spmm_fw(rowptr, col, val, x, red)
+            assert np.all(z0[[0, 2]] == 0) and np.all(z1[[0, 2]] == np.float32(fill))
+            assert np.array_equal(z0[[1, 3]], z1[[1, 3]]) and np.array_equal(a0, a1) and np.all(a1[[0, 2]] == 3)
+        oracle.set_empty_row("init")
+        for red in ("sum", "mean"):
+            assert np.all(oracle.spmm_fw(rowptr, col, val, x, red)[0][[0, 2]] == 0)
+    finally:
+        oracle.set_empty_row("zero")
