@@ -52,7 +52,7 @@ def parse():
     p.add_argument("--stream-geom", default="", help="debug: streams:slices:chunk for the stream schedule instead of the rule")
     p.add_argument("--chunk", type=int, default=1024, help="tasks: edges per task")
     p.add_argument("--short", type=int, default=128, help="tasks: rows shorter than this are not sliced")
-    p.add_argument("--tune", default="", help="debug: comma list of key=value for isplib_hip_tune")
+    p.add_argument("--tune", default="", help="debug: comma list of key=value for isplib_hip_tune (9, 12: isplib_hip_tune_experimental)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra", action="store_true", help="skip the other BASELINE.json configs (the `extra` array)")
     p.add_argument("--no-backward", action="store_true")
@@ -98,6 +98,15 @@ def cpu_baseline(rowptr, col, x, nnz):
                       "row blocks, NUMA first touch)",
             "ms_per_step": t * 1e3, "gathered_GBps": nnz * (12 + 4 * k) / t / 1e9, "host_cpus": os.cpu_count(),
             "oracle_dynamic16_single_node_ms": plain_ms, "torch_sparse_mm_ms": torch_ms}
+
+
+def apply_tune(cabi, spec: str) -> None:
+    """--tune key=value,...: knobs 0-8 belong to the default library (isplib_hip_tune), 9 and 12 to the experimental one."""
+    for kv in filter(None, spec.split(",")):
+        key, value = (int(v) for v in kv.split("="))
+        rc = (cabi.exp_lib().isplib_hip_tune_experimental if key >= 9 else cabi.lib().isplib_hip_tune)(key, value)
+        if rc != 0:
+            raise SystemExit(f"bench.py: --tune {kv}: unknown knob or value")
 
 
 def _time_launches(fn, reps=5, warm=2):
@@ -1037,8 +1046,7 @@ def main():
         # pointed at to fill profiles/traffic.json and the per-configuration kernel statistics)
         from isplib_amd import cabi as _cabi, synth as _synth
         os.environ["ISPLIB_BENCH_ONLY"] = a.only
-        for kv in filter(None, a.tune.split(",")):
-            _cabi.lib().isplib_hip_tune(int(kv.split("=")[0]), int(kv.split("=")[1]))
+        apply_tune(_cabi, a.tune)
         if a.only.startswith("products") or a.only == "scaling-emulated-products":
             extra = products_configs(dev, a.only)
         else:
@@ -1075,9 +1083,7 @@ def main():
     x = synth.features(n, k, device=dev)
     val = synth.edge_weights(nnz, device=dev) if a.weighted else None
     msg = cabi.MESSAGE[a.reduce]
-    for kv in filter(None, a.tune.split(",")):
-        key, value = kv.split("=")
-        cabi.lib().isplib_hip_tune(int(key), int(value))
+    apply_tune(cabi, a.tune)
 
     if not multi:
         l_rowptr, l_col, l_val, m_local, x_in = rowptr, col, val, n, x

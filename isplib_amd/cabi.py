@@ -9,6 +9,7 @@ stream.  Every function raises ``RuntimeError`` on a non-zero status.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional
 
 import torch
@@ -51,13 +52,16 @@ EXPORTS = (
     "isplib_sddmm_csr_tasks_hip", "fusedMM_csr_tasks_epilogue_hip", "fusedMM_csr_udef_hip", "fusedMM_csr_udef_tasks_hip", "isplib_pack_indices_hip",
     "isplib_suggest_slices", "isplib_graph_create", "isplib_graph_set_slices", "isplib_graph_set_values", "isplib_graph_spmm", "isplib_graph_spmm_backward",
     "isplib_graph_destroy", "isplib_suggest_slices_whole_rows", "isplib_graph_sddmm",
-    "fusedMM_csr_sweep_hip", "isplib_spmm_sweep_workspace_bytes", "isplib_spmm_sweep_resident_waves",
     "fusedMM_csr_stream_hip", "isplib_spmm_stream_workspace_bytes", "isplib_spmm_stream_geometry", "isplib_suggest_stream", "isplib_suggest_stream_weighted", "isplib_stream_plan_build_hip", "isplib_stream_plan_build_minmax_hip", "fusedMM_csr_stream_minmax_hip", "isplib_spmm_stream_minmax_geometry", "isplib_suggest_stream_minmax", "isplib_spmm_stream_minmax_workspace_bytes", "isplib_stream_plan_set_values_hip", "isplib_stream_plan_free", "isplib_spmm_minmax_bw_det_hip", "isplib_spmm_minmax_bw_workspace_bytes", "isplib_scatter_rows_det_hip",
     "isplib_row_scale_hip", "isplib_masked_scale_colsum_hip", "isplib_masked_scale_colsum_workspace_bytes",
-    "fusedMM_csr_hybrid_hip", "isplib_spmm_hybrid_geometry", "isplib_spmm_hybrid_workspace_bytes", "isplib_sddmm_stream_hip",
     "fusedMM_csr_ordered_hip", "isplib_community_order_hip", "isplib_community_order_workspace_bytes", "isplib_order_locality_hip",
     "isplib_graph_set_row_order",
 )
+
+# include/isplib_hip_experimental.h (libisplib_hip_exp.so): forms measured slower than the defaults; tests and experiment scripts only
+EXP_EXPORTS = ("fusedMM_csr_sweep_hip", "isplib_spmm_sweep_workspace_bytes", "isplib_spmm_sweep_resident_waves",
+               "fusedMM_csr_hybrid_hip", "isplib_spmm_hybrid_geometry", "isplib_spmm_hybrid_workspace_bytes", "isplib_sddmm_stream_hip",
+               "isplib_hip_tune_experimental")
 
 _i64, _f32, _vp, _i32 = ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_int32
 
@@ -212,13 +216,6 @@ def lib() -> ctypes.CDLL:
         L.isplib_stream_plan_set_values_hip.argtypes = [ctypes.POINTER(StreamPlanStruct), _vp, _vp]
         L.isplib_stream_plan_free.restype = None
         L.isplib_stream_plan_free.argtypes = [ctypes.POINTER(StreamPlanStruct)]
-        L.isplib_spmm_hybrid_geometry.restype = ctypes.c_int
-        L.isplib_spmm_hybrid_geometry.argtypes = [ctypes.c_int] + [ctypes.POINTER(ctypes.c_int)] * 4
-        L.isplib_spmm_hybrid_workspace_bytes.restype = ctypes.c_size_t
-        L.isplib_spmm_hybrid_workspace_bytes.argtypes = [ctypes.POINTER(HybridPlanStruct)]
-        L.fusedMM_csr_hybrid_hip.restype = ctypes.c_int
-        L.fusedMM_csr_hybrid_hip.argtypes = [_i32, _i64, _i64, _i64, _i64, _vp, _vp, ctypes.POINTER(HybridPlanStruct), _vp, _i64, _vp, _i64,
-                                             _vp, ctypes.c_size_t, _vp, _vp]
         L.isplib_community_order_workspace_bytes.restype = ctypes.c_size_t
         L.isplib_community_order_workspace_bytes.argtypes = [_i64, _i64]
         L.isplib_community_order_hip.restype = ctypes.c_int
@@ -230,9 +227,6 @@ def lib() -> ctypes.CDLL:
         L.isplib_graph_set_row_order.argtypes = [_vp, _vp, _vp]
         L.fusedMM_csr_ordered_hip.restype = ctypes.c_int
         L.fusedMM_csr_ordered_hip.argtypes = [_i32, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp]
-        L.isplib_sddmm_stream_hip.restype = ctypes.c_int
-        L.isplib_sddmm_stream_hip.argtypes = [_i64, _i64, _i64, _i64, _vp, _vp, ctypes.POINTER(StreamPlanStruct), _vp, _i64, _vp, _i64,
-                                              ctypes.c_int, _vp, _vp]
         L.isplib_suggest_stream.restype = ctypes.c_int
         L.isplib_suggest_stream.argtypes = [_i64, _i64, _i64, _i64, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
         L.isplib_suggest_stream_weighted.restype = ctypes.c_int
@@ -244,6 +238,35 @@ def lib() -> ctypes.CDLL:
         L.fusedMM_csr_stream_hip.restype = ctypes.c_int
         L.fusedMM_csr_stream_hip.argtypes = [_i32, _i64, _i64, _i64, _i64, _vp, _vp, ctypes.POINTER(StreamPlanStruct), _vp, _i64,
                                              _vp, _i64, _vp, ctypes.c_size_t, ctypes.POINTER(Epilogue), _vp]
+        _sigs_set = True
+    return L
+
+
+_exp = None
+
+
+def exp_lib() -> ctypes.CDLL:
+    """libisplib_hip_exp.so (include/isplib_hip_experimental.h): the sweep schedule, the LDS hot-row hybrid and the stream-plan
+    SDDMM -- built, bit-exact, measured slower than the defaults, kept for tests and experiments.  Loaded on first use."""
+    global _exp
+    if _exp is None:
+        lib()                                     # the default library first: the experimental one links against it
+        path = os.path.join(os.path.dirname(_lib.CABI_PATH), "libisplib_hip_exp.so")
+        if not os.path.exists(path):
+            raise ImportError(f"isplib_amd: '{os.path.basename(path)}' not found; build it with `make -C isplib_amd/csrc`")
+        L = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        L.isplib_hip_tune_experimental.restype = ctypes.c_int
+        L.isplib_hip_tune_experimental.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.isplib_spmm_hybrid_geometry.restype = ctypes.c_int
+        L.isplib_spmm_hybrid_geometry.argtypes = [ctypes.c_int] + [ctypes.POINTER(ctypes.c_int)] * 4
+        L.isplib_spmm_hybrid_workspace_bytes.restype = ctypes.c_size_t
+        L.isplib_spmm_hybrid_workspace_bytes.argtypes = [ctypes.POINTER(HybridPlanStruct)]
+        L.fusedMM_csr_hybrid_hip.restype = ctypes.c_int
+        L.fusedMM_csr_hybrid_hip.argtypes = [_i32, _i64, _i64, _i64, _i64, _vp, _vp, ctypes.POINTER(HybridPlanStruct), _vp, _i64, _vp, _i64,
+                                             _vp, ctypes.c_size_t, _vp, _vp]
+        L.isplib_sddmm_stream_hip.restype = ctypes.c_int
+        L.isplib_sddmm_stream_hip.argtypes = [_i64, _i64, _i64, _i64, _vp, _vp, ctypes.POINTER(StreamPlanStruct), _vp, _i64, _vp, _i64,
+                                              ctypes.c_int, _vp, _vp]
         L.isplib_spmm_sweep_resident_waves.restype = ctypes.c_int
         L.isplib_spmm_sweep_resident_waves.argtypes = [_i32, _i64, ctypes.c_int]
         L.isplib_spmm_sweep_workspace_bytes.restype = ctypes.c_size_t
@@ -251,8 +274,8 @@ def lib() -> ctypes.CDLL:
         L.fusedMM_csr_sweep_hip.restype = ctypes.c_int
         L.fusedMM_csr_sweep_hip.argtypes = [_i32, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(SweepPlanStruct),
                                             _vp, _i64, _vp, _i64, _vp, _vp, ctypes.c_size_t, ctypes.POINTER(Epilogue), _vp]
-        _sigs_set = True
-    return L
+        _exp = L
+    return _exp
 
 
 def last_error() -> str:
@@ -689,7 +712,7 @@ def sddmm_stream(rowptr, nnz: int, plan, y, g, mean: bool = False):
     rp = rowptr.data_ptr()
     ps = plan.struct()
     with torch.cuda.device(y.device):
-        st = lib().isplib_sddmm_stream_hip(m, n, k, int(nnz), ctypes.c_void_p(rp), ctypes.c_void_p(rp + 8), ctypes.byref(ps), _ptr(y), k,
+        st = exp_lib().isplib_sddmm_stream_hip(m, n, k, int(nnz), ctypes.c_void_p(rp), ctypes.c_void_p(rp + 8), ctypes.byref(ps), _ptr(y), k,
                                            _ptr(g), k, int(bool(mean)), _ptr(dval), _stream(y.device))
     _check(st, "isplib_sddmm_stream_hip")
     return dval
@@ -741,7 +764,7 @@ def fusedMM_csr_sweep_hip(imessage: int, rowptr, col, val, plan, y, z, z_arg, wo
     rp = rowptr.data_ptr()
     ps = plan.struct()
     with torch.cuda.device(y.device):
-        st = lib().fusedMM_csr_sweep_hip(int(imessage), m, n, k, col.numel(), _ptr(val), _ptr(col), _plan_col32(plan, col),
+        st = exp_lib().fusedMM_csr_sweep_hip(int(imessage), m, n, k, col.numel(), _ptr(val), _ptr(col), _plan_col32(plan, col),
                                          ctypes.c_void_p(rp), ctypes.c_void_p(rp + 8), ctypes.byref(ps), _ptr(y),
                                          y.stride(0) if n > 1 else max(k, y.stride(0)), _ptr(z),
                                          z.stride(0) if m > 1 else max(k, z.stride(0)), _ptr(z_arg), _ptr(workspace),
@@ -854,7 +877,7 @@ def stream_minmax_geometry(streams: int = 4):
 def hybrid_geometry(streams: int = 4):
     """(rows per wave, resident waves, table rows, hot-step cap per wave and slice) of the hybrid kernel (isplib_spmm_hybrid_geometry)."""
     v = [ctypes.c_int(0) for _ in range(4)]
-    _check(lib().isplib_spmm_hybrid_geometry(int(streams), *[ctypes.byref(x) for x in v]), "isplib_spmm_hybrid_geometry")
+    _check(exp_lib().isplib_spmm_hybrid_geometry(int(streams), *[ctypes.byref(x) for x in v]), "isplib_spmm_hybrid_geometry")
     return tuple(x.value for x in v)
 
 
@@ -865,7 +888,7 @@ def fusedMM_csr_hybrid_hip(imessage: int, rowptr, nnz: int, plan, y, z, workspac
     rp = rowptr.data_ptr()
     ps = plan.struct()
     with torch.cuda.device(y.device):
-        st = lib().fusedMM_csr_hybrid_hip(int(imessage), m, n, k, int(nnz), ctypes.c_void_p(rp), ctypes.c_void_p(rp + 8),
+        st = exp_lib().fusedMM_csr_hybrid_hip(int(imessage), m, n, k, int(nnz), ctypes.c_void_p(rp), ctypes.c_void_p(rp + 8),
                                           ctypes.byref(ps), _ptr(y), y.stride(0) if n > 1 else max(k, y.stride(0)), _ptr(z),
                                           z.stride(0) if m > 1 else max(k, z.stride(0)), _ptr(workspace),
                                           0 if workspace is None else workspace.numel(),
@@ -991,7 +1014,7 @@ def stream_geometry(streams: int = 4):
 
 
 def sweep_resident_waves(reduce: str, k: int, rows_per_wave: int = 16) -> int:
-    return int(lib().isplib_spmm_sweep_resident_waves(MESSAGE[reduce], int(k), int(rows_per_wave)))
+    return int(exp_lib().isplib_spmm_sweep_resident_waves(MESSAGE[reduce], int(k), int(rows_per_wave)))
 
 
 class GraphHandle:

@@ -14,7 +14,7 @@
 
 namespace isplib {
 
-int g_sddmm_panel_cols = 0;   // tuning knob (isplib_hip_tune(12, cols)): column-panel width of the task-list SDDMM; 0 = whole rows
+int g_sddmm_panel_cols = 0;   // experimental knob (isplib_hip_tune_experimental(12, cols)): column-panel width of the task-list SDDMM; 0 = whole rows
 
 // One thread per (row, feature) element of arg/grad_out; consecutive lanes hold
 // consecutive features of one row, so the reads are coalesced and each wave's

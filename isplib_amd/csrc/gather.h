@@ -397,9 +397,6 @@ template <int OP, int LPR, int NCH, int ADDR> constexpr bool pipelined_tasks() {
 
 // tuning knobs (isplib_hip_tune), defined in spmm.hip
 extern int g_force_lpr, g_addr_mode, g_tasks_per_wave, g_panel_cols, g_panel_cols_minmax, g_one_pass_kib;
-extern int g_sweep_panel;    // defined in spmm_sweep.hip
-extern int g_stream_merge_gens;   // defined in spmm_sweep.hip
-extern int g_sddmm_on_stream_plan;   // defined in spmm_sweep.hip
 extern int g_sddmm_panel_cols;       // defined in backward.hip
 
 }  // namespace isplib

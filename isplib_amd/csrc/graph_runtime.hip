@@ -16,7 +16,6 @@
 
 #include "common.h"
 
-namespace isplib { extern int g_sddmm_on_stream_plan; }   // tuning knob 11 (spmm_sweep.hip)
 
 using namespace isplib;
 
@@ -681,19 +680,8 @@ extern "C" int isplib_graph_sddmm(isplib_graph *g, int mean, int64_t k, const fl
    if (!g) return fail(ISPLIB_FAIL, "isplib_graph_sddmm: null handle");
    hipStream_t st = (hipStream_t)stream;
    Side &s = g->fwd;
-   // The forward's stream plan could serve dA too (isplib_sddmm_stream_hip: same edges, same gathers, g's rows in LDS where
-   // the SpMM keeps its accumulators) -- built, parity-tested, and SLOWER than the task list below on every shape measured
-   // (Reddit shape K=128: 4.04 ms against 3.54; K=64: 1.90 / 1.85; K=32: 1.42 / 1.07): per-edge
-   // results leave the CU through the plan's permutation, 4 bytes at a time, and the address pipeline the gathers are
-   // bound by pays for every one of them.  Opt-in for experiments: isplib_hip_tune(11, 1).
-   if (g_sddmm_on_stream_plan && k >= 4 && s.nnz < (1LL << 31)) {
-      Side::Stream *sp = nullptr;
-      const float *val_new = (s.val && weights_are_unit(s, st) != 1) ? s.val : nullptr;      // what a plan built here should carry
-      const int rc = side_stream_plan(g, s, val_new, k, ldy, st, &sp);
-      if (rc) return rc;
-      if (sp && sp->plan.perm)
-         return isplib_sddmm_stream_hip(s.m, s.n, k, s.nnz, s.rowptr, s.rowptr + 1, &sp->plan, y, ldy, gm, ldg, mean, dval, st);
-   }
+   // (The forward's stream plan could serve dA too -- isplib_sddmm_stream_hip, now in the experimental library: built,
+   // parity-tested, and slower than the task list below on every shape measured: Reddit shape K=128 4.04 ms against 3.54.)
    int slices = g->forced_slices >= 0 ? g->forced_slices : isplib_suggest_slices_whole_rows(s.m, s.n, s.nnz, k);
    if (k < 4 || k > 1024 || (double)s.n * (double)ldy * 4.0 > 3.5 * 1073741824.0) slices = 0;
    if (slices > 0) {

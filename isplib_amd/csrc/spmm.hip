@@ -534,11 +534,14 @@ extern "C" int isplib_hip_tune(int key, int value) {
    if (key == 4) { g_panel_cols = value; return ISPLIB_SUCCESS; }
    if (key == 5) { g_panel_cols_minmax = value; return ISPLIB_SUCCESS; }
    if (key == 8 && value >= 0) { g_one_pass_kib = value; return ISPLIB_SUCCESS; }
-   if (key == 9 && (value == 32 || value == 64 || value == 128)) { g_sweep_panel = value; return ISPLIB_SUCCESS; }
-   if (key == 10) { g_stream_merge_gens = value ? 1 : 0; return ISPLIB_SUCCESS; }
-   if (key == 11) { g_sddmm_on_stream_plan = value ? 1 : 0; return ISPLIB_SUCCESS; }
-   if (key == 12 && value >= 0) { g_sddmm_panel_cols = value; return ISPLIB_SUCCESS; }
-   return ISPLIB_FAIL;
+   return ISPLIB_FAIL;      // (9 and 12: isplib_hip_tune_experimental, include/isplib_hip_experimental.h; 10 and 11 are gone)
+}
+
+// not in include/isplib_hip.h: the experimental library's knob 12 (column panels of the task-list SDDMM, measured slower)
+extern "C" int isplib_internal_set_sddmm_panel_cols(int cols) {
+   if (cols < 0) return ISPLIB_FAIL;
+   g_sddmm_panel_cols = cols;
+   return ISPLIB_SUCCESS;
 }
 
 extern "C" void performDummySpMM_hip(int64_t flag, void *stream) {

@@ -114,7 +114,7 @@ class SweepPlan:
     def workspace(self, reduce: str, k: int) -> torch.Tensor:
         import ctypes
         ps = self.struct()
-        nbytes = cabi.lib().isplib_spmm_sweep_workspace_bytes(cabi.MESSAGE[reduce], ctypes.byref(ps), k)
+        nbytes = cabi.exp_lib().isplib_spmm_sweep_workspace_bytes(cabi.MESSAGE[reduce], ctypes.byref(ps), k)
         return torch.empty(nbytes, dtype=torch.uint8, device=self.wave_row.device)
 
 

@@ -1,7 +1,7 @@
 """Round-4 experiments on the Reddit-shaped graph (one MI355X), each checked before it is timed:
   mm     : max / min on the stream schedule (row pair carried in registers): slices x chunk sweep at K = 64 / 128 / 32,
            values and arg bit for bit against the task list first
-  sddmm  : task-list SDDMM in whole rows against 64-column panels (isplib_hip_tune(12, cols)), several slice counts
+  sddmm  : task-list SDDMM in whole rows against 64-column panels (isplib_hip_tune_experimental(12, cols), libisplib_hip_exp.so), several slice counts
   w128   : weighted SpMM-sum K=128: the rule's plan against 128-column slots (2 streams), alternating, same box
   k41    : K=41 at its packed 164-byte pitch against 192- / 256-byte pitches (a copy of Y), 16-lane slots
 usage: exp_round4.py mm,sddmm,w128,k41"""
@@ -96,7 +96,7 @@ if "sddmm" in what:
             for cols in (0, 64, 128):
                 if cols and k < 2 * cols:
                     continue
-                L.isplib_hip_tune(12, cols)
+                cabi.exp_lib().isplib_hip_tune_experimental(12, cols)
                 out = cabi.sddmm_tasks(rowptr, col, tp, x, g)
                 if ref is None:
                     ref = out.clone()
@@ -105,7 +105,7 @@ if "sddmm" in what:
                 ms = timeit(lambda: cabi.sddmm_tasks(rowptr, col, tp, x, g), 5, 2)
                 print(f"[sddmm] K={k} {sl:3d} slices ({tp.n_tasks} tasks) panels of {cols or k:3d}: {ms:.3f} ms  max err / sum|x||g| {err:.2e}", flush=True)
             del tp
-        L.isplib_hip_tune(12, 0)
+        cabi.exp_lib().isplib_hip_tune_experimental(12, 0)
         del x, g, ref, mag
 
 if "w128" in what:

@@ -49,8 +49,5 @@ for b in range(0, nnz, step):
 print(f"   stream vs task list: max |diff| / (1e-5 sum|x||g|) = {float((err / (1e-5 * mag + 1e-30)).max()):.3f}", flush=True)
 h = cabi.GraphHandle(rowptr, col, None, n)
 print(f"   isplib_graph_sddmm (default: task list): {clock(lambda: h.sddmm(x, g)):.3f} ms", flush=True)
-cabi.lib().isplib_hip_tune(11, 1)
-hv = h.sddmm(x, g)
-print("   isplib_graph_sddmm with isplib_hip_tune(11, 1) takes the stream plan:", bool(torch.equal(hv, got)), f"{clock(lambda: h.sddmm(x, g)):.3f} ms", flush=True)
-cabi.lib().isplib_hip_tune(11, 0)
+# (round 4 also timed isplib_graph_sddmm on the stream plan through tuning knob 11; the knob went with the code path in round 5)
 h.close()

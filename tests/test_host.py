@@ -49,6 +49,30 @@ def test_cabi_library_exports_every_declared_symbol():
     assert cabi.last_error() == ""
 
 
+def test_experimental_library_exports_its_own_header_and_nothing_of_it_is_in_the_default_one():
+    """include/isplib_hip_experimental.h <-> libisplib_hip_exp.so (the measured losers: sweep schedule, LDS hot-row hybrid,
+    stream-plan SDDMM, their knobs): every declared symbol is exported there, none of them by the default library, and the
+    default header declares none of them -- a binding of the reference's path never sees them."""
+    import re
+    from isplib_amd import _lib, cabi
+    text = open(os.path.join(ROOT, "include", "isplib_hip_experimental.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = sorted(set(re.findall(r"^\s*(?:const\s+)?(?:int|void|size_t|char)\s*\*?\s*(\w+)\s*\(", text, flags=re.M)))
+    assert sorted(cabi.EXP_EXPORTS) == declared
+    exp_path = os.path.join(os.path.dirname(_lib.CABI_PATH), "libisplib_hip_exp.so")
+    assert os.path.exists(exp_path), "libisplib_hip_exp.so not built"
+    sym = lambda path: {ln.split()[-1] for ln in subprocess.check_output(["nm", "-D", "--defined-only", path], text=True).splitlines() if " T " in ln}  # noqa: E731
+    assert not [n for n in declared if n not in sym(exp_path)]
+    core = sym(_lib.CABI_PATH)
+    assert not [n for n in declared if n in core], "an experimental entry is still exported by the default library"
+    assert not set(declared) & set(_declared_functions())
+    L = cabi.exp_lib()
+    for n in declared:
+        getattr(L, n)
+    assert L.isplib_hip_tune_experimental(9, 64) == 0 and L.isplib_hip_tune_experimental(10, 1) == cabi.FAIL
+    assert cabi.lib().isplib_hip_tune(9, 64) == cabi.FAIL, "knobs 9-12 left the default library"
+
+
 def test_cabi_argument_validation_without_gpu():
     """Status codes that are decided before any HIP call."""
     from isplib_amd import cabi
