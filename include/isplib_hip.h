@@ -406,6 +406,29 @@ int    fusedMM_csr_stream_hip(int32_t imessage /* ISPLIB_MSG_SPMM_SUM | _MEAN */
                               void *workspace, size_t workspace_bytes,
                               const isplib_epilogue *epilogue /*host, may be NULL*/, void *stream);
 
+/*
+ * The two SDDMM-fused words of the generic pipeline that graph embedding runs on -- COPY_RHS|DOT|UDEF|MUL|ADD (sigmoid embedding,
+ * attention scores: z_i = sum_j f(<x_i, y_j>) y_j) and SUBR|NORMR|UDEF|MUL|ADD (t-distribution: z_i = sum_j f(|y_j - x_i|^2)
+ * (y_j - x_i)), f from enum isplib_sop_udef -- on the stream schedule's front end: rows of x and of z resident in LDS, a slot as
+ * wide as the row (k <= 128: the reduce stage needs the whole row), four steps' dot products summed by one transposed
+ * butterfly.  Reddit shape, K=128: the task-list form (fusedMM_csr_udef_tasks_hip) takes 6.3 ms.  Same result as
+ * fusedMM_csr_udef_hip up to the order of the sums (bitwise reproducible from run to run); edge weights are not read (SOP is
+ * the user function).  Plans: isplib_stream_plan_build_fusedmm_hip (its own geometry: isplib_fusedmm_stream_geometry; streams
+ * 2 / 4 / 8 = slots of 128 / 64 / 32 columns); isplib_suggest_fusedmm_stream is the rule (0: stay on the task list);
+ * workspace: isplib_spmm_stream_workspace_bytes(plan).  k a multiple of 4, ldx and ldz multiples of 4, x and z 16-byte
+ * aligned, n < 2^24, n*ldy*4 <= 3.5 GiB.  Other words return ISPLIB_NO_OPT_IMPL.
+ */
+int    isplib_fusedmm_stream_geometry(int streams, int *rows_per_wave /*out*/, int *waves_resident /*out*/);
+int    isplib_suggest_fusedmm_stream(int32_t imessage, int64_t m, int64_t n, int64_t nnz, int64_t k, int *streams, int *slices, int *chunk);
+int    isplib_stream_plan_build_fusedmm_hip(int64_t m, int64_t n, int64_t nnz, const int64_t *rowptr, const int64_t *col,
+                                            int streams, int slices, int chunk, int waves_per_gen,
+                                            isplib_stream_plan *out /*host*/, void *stream);
+int    fusedMM_csr_udef_stream_hip(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t nnz,
+                                   const int64_t *pntrb, const int64_t *pntre, const isplib_stream_plan *plan /*host*/,
+                                   const float *x /*[dev] m x ldx*/, int64_t ldx, const float *y /*[dev] n x ldy*/, int64_t ldy,
+                                   float *z /*[dev] m x ldz*/, int64_t ldz, int sop_udef /*enum isplib_sop_udef*/, float sop_param,
+                                   void *workspace, size_t workspace_bytes, void *stream);
+
 /* The plain row-per-wave kernel of fusedMM_csr_hip with the rows taken in a caller-given ORDER (`row_order`: position ->
  * row, a permutation of [0, m), [dev] int32; NULL = fusedMM_csr_hip).  For operands larger than the Infinity Cache (the
  * ogbn-products shape: y = 2.5 GB) no schedule of this library reuses a gathered row -- unless rows that share neighbours

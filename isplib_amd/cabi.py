@@ -53,6 +53,7 @@ EXPORTS = (
     "isplib_suggest_slices", "isplib_graph_create", "isplib_graph_set_slices", "isplib_graph_set_values", "isplib_graph_spmm", "isplib_graph_spmm_backward",
     "isplib_graph_destroy", "isplib_suggest_slices_whole_rows", "isplib_graph_sddmm",
     "fusedMM_csr_stream_hip", "isplib_spmm_stream_workspace_bytes", "isplib_spmm_stream_geometry", "isplib_suggest_stream", "isplib_suggest_stream_weighted", "isplib_stream_plan_build_hip", "isplib_stream_plan_build_minmax_hip", "fusedMM_csr_stream_minmax_hip", "isplib_spmm_stream_minmax_geometry", "isplib_suggest_stream_minmax", "isplib_spmm_stream_minmax_workspace_bytes", "isplib_stream_plan_set_values_hip", "isplib_stream_plan_free", "isplib_spmm_minmax_bw_det_hip", "isplib_spmm_minmax_bw_workspace_bytes", "isplib_scatter_rows_det_hip",
+    "isplib_fusedmm_stream_geometry", "isplib_suggest_fusedmm_stream", "isplib_stream_plan_build_fusedmm_hip", "fusedMM_csr_udef_stream_hip",
     "isplib_row_scale_hip", "isplib_masked_scale_colsum_hip", "isplib_masked_scale_colsum_workspace_bytes",
     "fusedMM_csr_ordered_hip", "isplib_community_order_hip", "isplib_community_order_workspace_bytes", "isplib_order_locality_hip",
     "isplib_graph_set_row_order",
@@ -189,6 +190,16 @@ def lib() -> ctypes.CDLL:
         L.isplib_spmm_minmax_bw_workspace_bytes.argtypes = [_i64, _i64, _i64]
         L.isplib_spmm_minmax_bw_det_hip.restype = ctypes.c_int
         L.isplib_spmm_minmax_bw_det_hip.argtypes = [_i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]
+        L.isplib_fusedmm_stream_geometry.restype = ctypes.c_int
+        L.isplib_fusedmm_stream_geometry.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+        L.isplib_suggest_fusedmm_stream.restype = ctypes.c_int
+        L.isplib_suggest_fusedmm_stream.argtypes = [_i32, _i64, _i64, _i64, _i64] + [ctypes.POINTER(ctypes.c_int)] * 3
+        L.isplib_stream_plan_build_fusedmm_hip.restype = ctypes.c_int
+        L.isplib_stream_plan_build_fusedmm_hip.argtypes = [_i64, _i64, _i64, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                           ctypes.POINTER(StreamPlanStruct), _vp]
+        L.fusedMM_csr_udef_stream_hip.restype = ctypes.c_int
+        L.fusedMM_csr_udef_stream_hip.argtypes = [_i32, _i64, _i64, _i64, _i64, _vp, _vp, ctypes.POINTER(StreamPlanStruct), _vp, _i64, _vp, _i64,
+                                                  _vp, _i64, ctypes.c_int, _f32, _vp, ctypes.c_size_t, _vp]
         L.isplib_row_scale_hip.restype = ctypes.c_int
         L.isplib_row_scale_hip.argtypes = [_i64, _i64, _vp, _i64, _vp, _vp, _i64, _vp]
         L.isplib_masked_scale_colsum_workspace_bytes.restype = ctypes.c_size_t
@@ -430,6 +441,40 @@ def fusedmm(imessage: int, rowptr, col, val, x, y, sop_udef="none", sop_param: f
     if check:
         _check(st, "fusedMM_csr_udef_tasks_hip" if plan is not None else "fusedMM_csr_udef_hip")
     return st, z, arg
+
+
+def suggest_fusedmm_stream(imessage: int, m: int, n: int, nnz: int, k: int):
+    """(streams, slices, chunk) when the word should run on the stream front end (isplib_suggest_fusedmm_stream), else None."""
+    v = [ctypes.c_int(0) for _ in range(3)]
+    if not lib().isplib_suggest_fusedmm_stream(int(imessage), int(m), int(n), int(nnz), int(k), *[ctypes.byref(x) for x in v]):
+        return None
+    return tuple(int(x.value) for x in v)
+
+
+def fusedmm_stream_geometry(streams: int = 2):
+    rpw, res = ctypes.c_int(0), ctypes.c_int(0)
+    _check(lib().isplib_fusedmm_stream_geometry(int(streams), ctypes.byref(rpw), ctypes.byref(res)), "isplib_fusedmm_stream_geometry")
+    return int(rpw.value), int(res.value)
+
+
+def fusedmm_stream(imessage: int, rowptr, nnz: int, plan, x, y, sop_udef="none", sop_param: float = 0.0, check: bool = True):
+    """The two SDDMM-fused words on the stream front end (fusedMM_csr_udef_stream_hip); `plan`: a NativeStreamPlan built with
+    fusedmm=True.  Returns (status, z)."""
+    rowptr = _dev(rowptr, "rowptr", torch.int64)
+    x, y = _dev(x, "x", torch.float32), _dev(y, "y", torch.float32)
+    m, n, k = rowptr.numel() - 1, y.size(0), y.size(1)
+    z = torch.empty((m, k), dtype=torch.float32, device=y.device)
+    kind = SOP_UDEF[sop_udef] if isinstance(sop_udef, str) else int(sop_udef)
+    work = plan.workspace()
+    rp = rowptr.data_ptr()
+    ps = plan.struct()
+    with torch.cuda.device(y.device):
+        st = lib().fusedMM_csr_udef_stream_hip(int(imessage), m, n, k, int(nnz), ctypes.c_void_p(rp), ctypes.c_void_p(rp + 8), ctypes.byref(ps),
+                                               _ptr(x), k, _ptr(y), k, _ptr(z), k, kind, float(sop_param), _ptr(work), work.numel(),
+                                               _stream(y.device))
+    if check:
+        _check(st, "fusedMM_csr_udef_stream_hip")
+    return st, z
 
 
 def spmm(rowptr, col, val, y, reduce: str = "sum"):
@@ -939,12 +984,16 @@ class NativeStreamPlan:
     isplib_amd.plan.build_stream_plan; same interface as plan.StreamPlan for the boundary wrappers."""
 
     def __init__(self, rowptr, col, val, ncols: int, streams: int, slices: int, chunk: int, waves_per_gen: int = 0,
-                 minmax: bool = False):
+                 minmax: bool = False, fusedmm: bool = False):
         self._s = StreamPlanStruct()
         self.device = col.device
         m = rowptr.numel() - 1
         with torch.cuda.device(col.device):
-            if minmax:
+            if fusedmm:       # the generic FusedMM kernel's geometry (isplib_fusedmm_stream_geometry); no weights in the plan
+                _check(lib().isplib_stream_plan_build_fusedmm_hip(m, int(ncols), col.numel(), _ptr(rowptr), _ptr(col), int(streams), int(slices),
+                                                                  int(chunk), int(waves_per_gen), ctypes.byref(self._s), _stream(col.device)),
+                       "isplib_stream_plan_build_fusedmm_hip")
+            elif minmax:
                 _check(lib().isplib_stream_plan_build_minmax_hip(m, int(ncols), col.numel(), _ptr(rowptr), _ptr(col), _ptr(val),
                                                                  int(streams), int(slices), int(chunk), int(waves_per_gen), ctypes.byref(self._s),
                                                                  _stream(col.device)), "isplib_stream_plan_build_minmax_hip")

@@ -454,3 +454,15 @@ extern "C" int isplib_stream_plan_build_minmax_hip(int64_t m, int64_t n, int64_t
    }
    return stream_plan_build(m, n, nnz, rowptr, col, val, streams, rpw, resident, slices, chunk, waves_per_gen, out, stream, /* pad_row = the spare row */ rpw);
 }
+
+// A plan for fusedMM_csr_udef_stream_hip (fusedmm_stream.hip): the max / min kernel's shape -- two LDS planes per row, so half
+// the rows per wave of a sum plan, and padding words that carry the kernel's spare row -- at the generic kernel's own geometry
+// (isplib_fusedmm_stream_geometry).  No requirement on the order of a row's columns: the words are summed, not compared.
+extern "C" int isplib_stream_plan_build_fusedmm_hip(int64_t m, int64_t n, int64_t nnz, const int64_t *rowptr, const int64_t *col,
+                                                    int streams, int slices, int chunk, int waves_per_gen,
+                                                    isplib_stream_plan *out, void *stream) {
+   clear_error();
+   int rpw = 0, resident = 0;
+   if (isplib_fusedmm_stream_geometry(streams, &rpw, &resident) != ISPLIB_SUCCESS) return ISPLIB_FAIL;
+   return stream_plan_build(m, n, nnz, rowptr, col, nullptr, streams, rpw, resident, slices, chunk, waves_per_gen, out, stream, /* pad_row = the spare row */ rpw);
+}

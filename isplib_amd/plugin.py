@@ -327,8 +327,25 @@ def fusedmm(src, x: Optional[torch.Tensor], y: torch.Tensor, pattern="sigmoid_em
     else:
         word, fn = int(pattern), (sop_udef or "none")
     st = _storage_of(src, y)
+    k = y.size(1)
+    m_rows = st._rowptr.numel() - 1
+    # the two hot SDDMM-fused words on graphs with work for the whole chip: the stream front end (rows of x and z resident in
+    # LDS; include/isplib_hip.h: fusedMM_csr_udef_stream_hip) -- Reddit shape K=128: 6.3 ms on the task list below
+    geom = None
+    if x is not None and x.is_contiguous() and y.is_contiguous() and os.environ.get("ISPLIB_STREAM", "1") != "0" and os.environ.get("ISPLIB_SLICES") is None:
+        geom = cabi.suggest_fusedmm_stream(word, m_rows, y.size(0), st._col.numel(), k)
+    if geom is not None:
+        plans = st.__dict__.setdefault("_fusedmm_streams", {})
+        if geom not in plans:
+            try:
+                plans[geom] = cabi.NativeStreamPlan(st._rowptr, st._col, None, y.size(0), geom[0], geom[1], geom[2], 0, fusedmm=True)
+            except cabi.IsplibError:
+                plans[geom] = None                        # outside the builder's domain / no room: the task list serves the call
+        if plans[geom] is not None:
+            kind = sop_udef or fn
+            return cabi.fusedmm_stream(word, st._rowptr, st._col.numel(), plans[geom], x, y, sop_udef=kind, sop_param=sop_param)[1]
     # the reduce stage needs whole rows of y, so there are no column panels here: slices for the full width
-    k, plan = y.size(1), None
+    plan = None
     nbytes = y.size(0) * k * 4
     slices = int(cabi.lib().isplib_suggest_slices_whole_rows(st._rowptr.numel() - 1, y.size(0), st._col.numel(), k))
     if 4 <= k <= 1024 and slices > 0 and nbytes >= (14 << 20):

@@ -475,7 +475,7 @@ def test_sddmm_stream_status_codes(gpu):
     rowptr, col = cases.random_csr(40, 40, 5.0, seed=1)
     d_rowptr, d_col = _t(rowptr, gpu), _t(col, gpu)
     plan = build_stream_plan(d_rowptr, d_col, None, 40, 2, 4, None, 4, 64)
-    L = cabi.lib()
+    L = cabi.exp_lib()          # include/isplib_hip_experimental.h
     y, g, dval = torch.zeros((40, 8), device=gpu), torch.zeros((40, 8), device=gpu), torch.zeros(col.size, device=gpu)
     rp = d_rowptr.data_ptr()
 
@@ -544,7 +544,7 @@ def test_hybrid_epilogue_and_status_codes(gpu, oracle_mod):
     want = np.maximum(rs[:, None] * (ref + self_t) + bias[None, :], 0.0)
     mag, _ = oracle_mod.spmm_fw(rowptr, col, np.ones(col.size, np.float32), np.abs(x), "sum")
     assert np.all(np.abs(got - want) <= 1e-5 * (rs[:, None] * (mag + np.abs(self_t)) + np.abs(bias)[None, :]) + 1e-30)
-    L = cabi.lib()
+    L = cabi.exp_lib()          # include/isplib_hip_experimental.h
     y, z = _t(x, gpu), torch.zeros((n, k), device=gpu)
     ws = plan.workspace()
     rp = d_rowptr.data_ptr()
