@@ -264,6 +264,26 @@ def extra_configs(dev, rowptr, col, n, with_cpu_epoch=True):
               "task list (16 slices of whole rows) through isplib_graph_sddmm", key="reddit-sddmm-k128")
         h.close()
         del xs, gs
+    # the FusedMM paper's graph-embedding word (sigmoid of the dot product, then aggregate) on the same graph --
+    # through the plug-in's fusedmm(): the stream front end where isplib_suggest_fusedmm_stream accepts the shape
+    for pat in ("sigmoid_embedding", "tdist_embedding"):
+        fkey = f"reddit-fusedmm-{pat.split('_')[0]}-k128"
+        if not only or only == fkey:
+            import isplib_amd
+            adj_f = isplib_amd.SparseTensor.from_csr(rowptr, col, None, (n, n), validate=False)
+            sc = 1.0 / 128 ** 0.5
+            xs, ys = synth.features(n, 128, seed=3, device=dev) * sc, synth.features(n, 128, seed=5, device=dev) * sc
+            ms = _time_launches(lambda: isplib_amd.fusedmm(adj_f, xs, ys, pat))
+            rule = cabi.suggest_fusedmm_stream(cabi.PATTERNS[pat][0], n, n, nnz, 128)
+            b_alg = synth.algorithmic_bytes(n, n, nnz, 128, False) + n * 128 * 4        # + the left operand x, read once
+            rec = measured.get(fkey)
+            out.append({"config": f"generic FusedMM word, {pat} (z_i = sum_j f(x_i, y_j) y_j), reddit-like graph, K=128", "ms": ms,
+                        "edges_per_s": nnz / (ms * 1e-3),
+                        "schedule": ("stream front end (fusedMM_csr_udef_stream_hip): %d streams, %d slices, chunk %d" % rule) if rule else "task list",
+                        "roofline": {"bound": "hbm", "achieved": b_alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                     "frac": b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "kernel_avg_ms": ms, "algorithmic_bytes_per_launch": b_alg,
+                                     "traffic": None if not rec else rec.get("fabric_bytes_per_launch")}})
+            del adj_f, xs, ys
     del w, col32
     if only and not only.startswith("products") and only not in ("gcn-epoch", "scaling-emulated-reddit"):
         return out
@@ -427,25 +447,25 @@ def products_configs(dev, only=""):
         search_ms = (time.perf_counter() - t0) * 1e3
         graph = ("Chung-Lu graph (BASELINE's generator: no community structure)" if tag == "chunglu" else
                  "degree-corrected SBM of the same N, nnz and degree law, 2,449 blocks, 80 % of the edges inside")
-        runs = [("plain row-per-wave kernel, rows in index order", None, f"products-{tag}-sum-k256-plain")]
+        runs = [("plain row-per-wave kernel, rows in index order, two 128-column panels (operand beyond the Infinity Cache)", None, f"products-{tag}-sum-k256-plain")]
         if order is not None:
             runs.append(("plain row-per-wave kernel, rows in the community order (label propagation, found once in "
                          f"{search_ms:.0f} ms; bit-identical result)", order, f"products-{tag}-sum-k256-ordered"))
-        plain_result = None
         for sched, o, key in runs:
             if only and only != key:
                 continue
             ms = _time_launches(lambda: cabi.fusedMM_csr_ordered_hip(cabi.MSG_SPMM_SUM, p_rowptr, p_col, None, o, px, pz))
             identical = None
-            if o is None and len(runs) > 1 and not only:
-                plain_result = pz.clone()                         # (outside the timed launches) what the ordered run must reproduce
-            elif o is not None:
-                if plain_result is None:                          # --only <ordered key>: the plain launch once, untimed
-                    cabi.fusedMM_csr_ordered_hip(cabi.MSG_SPMM_SUM, p_rowptr, p_col, None, None, px, pz)
-                    plain_result = pz.clone()
-                    cabi.fusedMM_csr_ordered_hip(cabi.MSG_SPMM_SUM, p_rowptr, p_col, None, o, px, pz)
-                identical = bool(torch.equal(pz, plain_result))
-                plain_result = None
+            if o is not None:
+                # (outside the timed launches) the ordered run must reproduce, bit for bit, the rows in INDEX order computed the
+                # same way -- one 256-column pass per row: isplib_hip_tune(0, 64); the index-order default above runs 128-column
+                # panels since round 5, whose sums are associated differently
+                ordered_result = pz.clone()
+                cabi.lib().isplib_hip_tune(0, 64)
+                cabi.fusedMM_csr_ordered_hip(cabi.MSG_SPMM_SUM, p_rowptr, p_col, None, None, px, pz)
+                cabi.lib().isplib_hip_tune(0, 0)
+                identical = bool(torch.equal(pz, ordered_result))
+                del ordered_result
                 if not identical:
                     raise SystemExit(f"bench.py: {key}: the community-ordered launch does not reproduce the index-order result bit for bit")
             b_alg = synth.algorithmic_bytes(pn, pn, e, k, False)
@@ -462,13 +482,13 @@ def products_configs(dev, only=""):
                         "order_search": ("a community order was kept" if order is not None else
                                          f"looked for a community order ({search_ms:.0f} ms, once): none worth keeping, index order")})
         if tag == "chunglu" and (not only or only == "scaling-emulated-products"):
-            plain_ms = next((o_["ms"] for o_ in out if "index order" in o_.get("schedule", "") and "Chung-Lu" in o_["config"]), None)
+            plain_ms = next((o_["ms"] for o_ in out if "index order" in o_.get("schedule", "") and "Chung-Lu" in o_.get("config", "")), None)
             del px, pz
             torch.cuda.empty_cache()
             out.append({"config": "scaling_emulated, config 4: products-like SpMM-sum K=256, unit weights, 1-D row partition over 2 / 4 / 8 emulated ranks",
                         "scaling_emulated": scaling_emulated(dev, p_rowptr, p_col, pn, k, f"products-like Chung-Lu (N={pn}, nnz={e})", plain_ms)})
             px = pz = None
-        del p_rowptr, p_col, px, pz, order, plain_result
+        del p_rowptr, p_col, px, pz, order
     return out
 
 

@@ -435,7 +435,10 @@ int    fusedMM_csr_udef_stream_hip(int32_t imessage, int64_t m, int64_t n, int64
  * are worked on at the same time on the same XCD: the workgroups of an XCD walk a contiguous range of positions, so a
  * community-grouped order (isplib_amd/reorder.py: label propagation, once per graph) turns the gathers of a community's
  * rows into hits of that XCD's L2.  Nothing is moved: y is gathered and z written where they are, every row is computed
- * by the same code in the same edge order -- the result is bit for bit that of fusedMM_csr_hip for any order.
+ * by the same code in the same edge order -- the result is bit for bit the same for any order.  (row_order == NULL on an
+ * operand beyond the Infinity Cache, n * ldy * 4 > 256 MiB, runs k > 128 in 128-column panels -- two rows per gather: 9 % faster
+ * on the ogbn-products shape, the sums of a row associated over two slots instead of one; isplib_hip_tune(0, 64) keeps the
+ * index-order launch on the one-pass form a given order runs.)
  * No reference counterpart (the reference's CPU kernel walks rows in index order, csrc/fusedmm.cpp:198). */
 int    fusedMM_csr_ordered_hip(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t nnz, const float *val,
                                const int64_t *indx, const int64_t *pntrb, const int64_t *pntre,

@@ -12,7 +12,8 @@
 //     kernel's LDS budget, so plans have its shape: half the rows per wave of a sum plan plus the spare row that padding
 //     words point at (x = 0, gathered y = 0: whatever a padding step computes lands in a row nobody writes out);
 //   * four steps at a time: their four partial dot products (or squared distances) are summed over the slot's lanes by ONE
-//     transposed butterfly (gather.h), the scalar stage runs once on the lanes that end up owning a sum, four cross-lane reads
+//     transposed butterfly (gather.h), the scalar stage runs once on the lanes that end up owning a sum (reciprocals by v_rcp_f32),
+//     four cross-lane reads
 //     hand every lane its step's scalar, and only then are the four gathered rows scaled into the accumulator and their
 //     gathers re-issued (28-32 in flight instead of 32).
 // Every row is accumulated by the one wave that owns it, in stream order: no atomics, bitwise reproducible.  Hub rows cut
@@ -21,11 +22,13 @@
 
 namespace isplib {
 
+// (reciprocals by v_rcp_f32, 1 ulp: an IEEE division is ten vector instructions in a loop that is bound by them -- the ISA of the
+// first form of this kernel had 39 per step against the SpMM's 13 -- and the results are held to 1e-4 of the largest |z| anyway)
 __device__ __forceinline__ float sop_menu(int kind, float s, float p) {
    switch (kind) {
-      case ISPLIB_SOP_SIGMOID: return 1.0f / (1.0f + __expf(-s));
-      case ISPLIB_SOP_ONE_MINUS_SIGMOID: return 1.0f - 1.0f / (1.0f + __expf(-s));
-      case ISPLIB_SOP_TDIST: return 1.0f / (1.0f + s);
+      case ISPLIB_SOP_SIGMOID: return __builtin_amdgcn_rcpf(1.0f + __expf(-s));
+      case ISPLIB_SOP_ONE_MINUS_SIGMOID: return 1.0f - __builtin_amdgcn_rcpf(1.0f + __expf(-s));
+      case ISPLIB_SOP_TDIST: return __builtin_amdgcn_rcpf(1.0f + s);
       case ISPLIB_SOP_SCALE: return p * s;
       case ISPLIB_SOP_EXP: return __expf(s);
       case ISPLIB_SOP_LEAKY_EXP: return __expf(s > 0.0f ? s : p * s);
@@ -98,8 +101,7 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, 2 * (NVMAX + 1), WGS>(
    for (int u = 0; u < U; u++) issue(u, w1);
    load_words(64 * NBW, w1);
    load_words(128 * NBW, w2);
-   unsigned curx = (unsigned)(g * PER * PANEL), curz = curx;        // the rows whose x / accumulator the registers hold
-   float4 xv = *reinterpret_cast<const float4 *>(lane_x + curx);
+   unsigned curz = (unsigned)(g * PER * PANEL);           // the row whose accumulator the registers hold
    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
    auto flush = [&]() {
       float4 *p = reinterpret_cast<float4 *>(lane_z + curz);
@@ -112,13 +114,16 @@ __global__ __launch_bounds__(256, (stream_wgs_per_cu<LPR, 2 * (NVMAX + 1), WGS>(
 #pragma unroll
       for (int u0 = 0; u0 < U; u0 += 4) {
          float d[4];
+         // x_i of each of the four steps straight from its LDS row (one ds_read_b128 per step, issued together: the LDS pipe is
+         // otherwise idle).  Keeping the row in registers and re-reading it when the stream turns to another row -- what the
+         // accumulator does below -- cost a compare, a branch and four register copies per step here; the read costs none.
+         float4 xq[4];
+#pragma unroll
+         for (int q = 0; q < 4; q++) xq[q] = *reinterpret_cast<const float4 *>(lane_x + la[u0 + q]);
 #pragma unroll
          for (int q = 0; q < 4; q++) {
             const int u = u0 + q;
-            if (la[u] != curx) {                          // per lane: the slot's stream has turned to another row
-               curx = la[u];
-               xv = *reinterpret_cast<const float4 *>(lane_x + curx);
-            }
+            const float4 xv = xq[q];
             float y0 = __int_as_float(t[u][0]), y1 = __int_as_float(t[u][1]), y2 = __int_as_float(t[u][2]), y3 = __int_as_float(t[u][3]);
             if (PAT == 2) {                               // T = y - x replaces y in the registers of the gather
                y0 -= xv.x; y1 -= xv.y; y2 -= xv.z; y3 -= xv.w;
@@ -206,7 +211,7 @@ extern "C" int isplib_fusedmm_stream_geometry(int streams, int *rows_per_wave, i
 
 extern "C" int isplib_suggest_fusedmm_stream(int32_t imessage, int64_t m, int64_t n, int64_t nnz, int64_t k, int *streams, int *slices, int *chunk) {
    // the SpMM's reuse rule on this kernel's geometry (half the rows per wave of a sum plan: twice the generations, each sweeping y
-   // once per XCD): edges per generation and XCD >= 3 x rows of y; slices of ~1.9 MB of y's full width; rows cut at ~0.3 of a stream's share
+   // once per XCD): edges per generation and XCD >= 3 x rows of y; slices of ~3.8 MB of y at full width (Reddit shape, K=128: 15 / 31 / 63 / 94 slices 4.45 / 4.27 / 4.46 / 4.62 ms; K=64: 7 / 15 / 31 / 62: 2.14 / 2.10 / 2.21 / 2.34); rows cut at ~0.85 of a stream.s share
    clear_error();
    if (!stream_pattern(imessage) || m <= 0 || n <= 0 || nnz < (1LL << 22) || nnz >= (1LL << 31) || k < 4 || k > 128 || (k % 4) != 0 || n >= (1LL << 24)) return 0;
    if (!stream_domain_ok(n, k, nnz)) return 0;
@@ -216,7 +221,7 @@ extern "C" int isplib_suggest_fusedmm_stream(int32_t imessage, int64_t m, int64_
    const int64_t per_gen = (int64_t)rpw * resident;
    const int64_t gens = (m + per_gen - 1) / per_gen;
    if ((double)nnz / (double)gens / 8.0 < 3.0 * (double)n) return 0;
-   int sl = (int)((double)n * (1024.0 / st) / 1.9e6 + 0.5);
+   int sl = (int)((double)n * (1024.0 / st) / 3.8e6 + 0.5);
    sl = sl < 1 ? 1 : (sl > 512 ? 512 : sl);
    int64_t ch = (int64_t)((double)nnz / ((double)gens * resident * st) / 1.2);
    ch = ch < 256 ? 256 : (ch > (1 << 20) ? (1 << 20) : ch);
@@ -242,7 +247,7 @@ extern "C" int fusedMM_csr_udef_stream_hip(int32_t imessage, int64_t m, int64_t 
    if (plan->streams != 2 && plan->streams != 4 && plan->streams != 8) return fail(ISPLIB_FAIL, "fusedMM_csr_udef_stream_hip: bad plan geometry (streams 2, 4 or 8)");
    if (plan->gens < 1 || plan->waves_per_gen < 1 || plan->rows_per_wave != gen_stream_geom(plan->streams).nvmax)
       return fail(ISPLIB_FAIL, "fusedMM_csr_udef_stream_hip: bad plan geometry (a plan of isplib_stream_plan_build_fusedmm_hip is required)");
-   if (k < 4 || (k % 4) != 0 || k > 1024 / plan->streams)
+   if (k < 4 || (k % 4) != 0 || k > 256 / plan->streams)
       return fail(ISPLIB_FAIL, "fusedMM_csr_udef_stream_hip: k must be a multiple of 4 within the plan's slot width (256 / streams columns); use fusedMM_csr_udef_tasks_hip");
    if (ldy < k || ldz < k || ldx < k || (ldx % 4) != 0 || (ldz % 4) != 0 || ((uintptr_t)x & 15) != 0 || ((uintptr_t)z & 15) != 0)
       return fail(ISPLIB_FAIL, "fusedMM_csr_udef_stream_hip: ldx, ldz multiples of 4 and >= k, x and z 16-byte aligned");

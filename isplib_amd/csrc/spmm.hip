@@ -43,6 +43,10 @@ struct SpmmArgs {
    int64_t *z_arg;         // may be null
    int mean;               // OP_ADD only: divide by max(deg,1)
    int empty_init;         // max / min: an empty row holds the launcher's init value (-+FLT_MAX) instead of 0
+   int auto_panels;        // plain mode, index order, dense operand beyond the Infinity Cache: 128-column panels (launch_vec)
+#ifdef ISPLIB_EXP_NT_REMOTE
+   const unsigned long long *nt_mask;   // experiment: one bit per stored entry, 1 = gather with the non-temporal policy
+#endif
    int long_row;           // rows with more edges are split across the workgroup
    unsigned nblk;          // number of row blocks
    unsigned ybytes;        // n*ldy*4 when it fits the buffer-descriptor path, else 0
@@ -82,6 +86,14 @@ __device__ __forceinline__ void write_row(const SpmmArgs &a, int64_t row, int64_
 #pragma unroll
    for (int j = 0; j < NCH; j++) {
       if (!cok[j]) continue;
+#ifdef ISPLIB_EXP_NT_STORE
+      // experiment (scripts/exp_products_nt.py): finished rows leave with the non-temporal policy -- written once, never read here
+      if (VEC == 4 && vfirst[j] == 0 && ((uintptr_t)(zr + ccol[j]) & 15) == 0) {
+         typedef float f4v_t __attribute__((ext_vector_type(4)));
+         const f4v_t t = {acc[j][0], acc[j][VEC > 1 ? 1 : 0], acc[j][VEC > 2 ? 2 : 0], acc[j][VEC > 3 ? 3 : 0]};
+         __builtin_nontemporal_store(t, reinterpret_cast<f4v_t *>(zr + ccol[j]));
+      } else
+#endif
       store_tail<VEC>(zr + ccol[j], acc[j], vfirst[j]);
       if (OP != OP_ADD && a.z_arg) {
          int64_t *ar = a.z_arg + (size_t)row * (size_t)a.ldz + ccol[j];
@@ -386,6 +398,12 @@ template <int OP, int VEC>
 static int launch_vec(const SpmmArgs &a, hipStream_t st) {
    int64_t width = (a.k + VEC - 1) / VEC;   // vector columns (ragged K: the last one is shifted back)
    if (g_force_lpr > 0 && g_force_lpr < width) width = g_force_lpr;   // narrower slots: K swept in grid.y panels
+   // Operands beyond every cache, rows in index order (no community order was given or found): two rows per gather instruction
+   // in 128-column panels instead of one 256-column row -- round 5, ogbn-products shape, K=256: Chung-Lu 19.5 -> 17.8 ms, SBM twin
+   // in index order 18.4 -> 17.8 (64-column panels: the same again).  NOT when the rows come in a community order: the panels
+   // then halve what a community's rows of y keep of the L2 per byte of index stream (8.94 -> 9.73 ms).  The panel form sums a
+   // row's edges over two slots, so its last bits differ from the one-pass form's: isplib_hip_tune(0, 64) keeps one pass.
+   else if (g_force_lpr == 0 && a.auto_panels && width > 32) width = 32;
    if (width <= 8) return launch_cfg<OP, VEC, 8, 1>(a, st);
    if (width <= 16) return launch_cfg<OP, VEC, 16, 1>(a, st);
    if (width <= 32) return launch_cfg<OP, VEC, 32, 1>(a, st);
@@ -406,6 +424,11 @@ static int launch_op(const SpmmArgs &a, hipStream_t st) {
 }  // namespace isplib
 
 using namespace isplib;
+
+#ifdef ISPLIB_EXP_NT_REMOTE
+static const unsigned long long *g_exp_nt_mask = nullptr;
+extern "C" void isplib_debug_set_nt_mask(const unsigned long long *mask) { g_exp_nt_mask = mask; }   // experiment builds only
+#endif
 
 static int spmm_entry(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t nnz, const float *val,
                       const int64_t *indx, const int64_t *pntrb, const int64_t *pntre, const float *y, int64_t ldy,
@@ -446,6 +469,10 @@ static int spmm_entry(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t
    a.sliceptr = nullptr; a.slices = 1; a.slice_first = 0; a.slice_count = 0; a.combine = 0;
    a.part_val = nullptr; a.part_idx = nullptr;
    a.row_order = row_order;
+   a.auto_panels = (!row_order && !sliceptr && (double)n * (double)ldy * 4.0 > 256.0 * 1048576.0) ? 1 : 0;
+#ifdef ISPLIB_EXP_NT_REMOTE
+   a.nt_mask = g_exp_nt_mask;
+#endif
    if (sliceptr) {
       if (slices < 1 || slices > ISPLIB_MAX_SLICES) return fail(ISPLIB_FAIL, "fusedMM_csr_sliced_hip: slices must be in [1, 4096]");
       const size_t need = isplib_spmm_sliced_workspace_bytes(imessage, m, k, slices);

@@ -631,14 +631,20 @@ def test_config4_products_k256_against_the_oracle(gpu, oracle_mod, graph):
     rowptr, col, n = (synth.dataset_like if graph == "chunglu" else synth.sbm_like)("products", device=gpu)
     k = 256
     x = synth.features(n, k, device=gpu)
-    plain, _ = cabi.spmm_ordered(rowptr, col, None, None, x, "sum")
+    plain, _ = cabi.spmm_ordered(rowptr, col, None, None, x, "sum")        # index order: two 128-column panels (beyond the caches)
     order = reorder.useful_order(rowptr, col)
     if graph == "sbm":
         assert order is not None, "the SBM twin has community structure: the search must keep an order"
     if order is not None:
+        # the community order runs one 256-column pass per row: bit for bit the index-order rows computed the same way
         ordered, _ = cabi.spmm_ordered(rowptr, col, None, order, x, "sum")
-        assert torch.equal(ordered, plain)
-        del ordered
+        cabi.lib().isplib_hip_tune(0, 64)
+        try:
+            one_pass, _ = cabi.spmm_ordered(rowptr, col, None, None, x, "sum")
+        finally:
+            cabi.lib().isplib_hip_tune(0, 0)
+        assert torch.equal(ordered, one_pass)
+        del one_pass
     gen = torch.Generator(device=gpu)
     gen.manual_seed(5)
     rows = torch.sort(torch.randperm(n, generator=gen, device=gpu)[:300000]).values
@@ -650,4 +656,6 @@ def test_config4_products_k256_against_the_oracle(gpu, oracle_mod, graph):
     rp, cl, xx = _host(s_rowptr, s_col, x)
     ref, _ = oracle_mod.spmm_fw(rp, cl, np.ones(cl.size, np.float32), xx, "sum")
     exact = _exact_spmm_fp64(s_rowptr, s_col, None, x)
-    _assert_relative_1e5(f"products ({graph}) sum K=256, 300,000 sampled rows", plain[rows].cpu().numpy(), ref, exact)
+    _assert_relative_1e5(f"products ({graph}) sum K=256, index order (panels), 300,000 sampled rows", plain[rows].cpu().numpy(), ref, exact)
+    if order is not None:
+        _assert_relative_1e5(f"products ({graph}) sum K=256, community order (one pass), 300,000 sampled rows", ordered[rows].cpu().numpy(), ref, exact)
