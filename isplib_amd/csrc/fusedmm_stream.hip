@@ -211,7 +211,11 @@ extern "C" int isplib_fusedmm_stream_geometry(int streams, int *rows_per_wave, i
 
 extern "C" int isplib_suggest_fusedmm_stream(int32_t imessage, int64_t m, int64_t n, int64_t nnz, int64_t k, int *streams, int *slices, int *chunk) {
    // the SpMM's reuse rule on this kernel's geometry (half the rows per wave of a sum plan: twice the generations, each sweeping y
-   // once per XCD): edges per generation and XCD >= 3 x rows of y; slices of ~3.8 MB of y at full width (Reddit shape, K=128: 15 / 31 / 63 / 94 slices 4.45 / 4.27 / 4.46 / 4.62 ms; K=64: 7 / 15 / 31 / 62: 2.14 / 2.10 / 2.21 / 2.34); rows cut at ~0.85 of a stream.s share
+   // once per XCD): edges per generation and XCD >= 3 x rows of y.  Slices of ~2.6 MB of y on 128-column slots, ~3.8 MB on the
+   // narrower ones; rows cut at ~0.4 of a stream's share.  Reddit shape, round 5, sigmoid word, ms (task list: 5.55 / 2.74 / 1.52):
+   //   K=128: 7 / 15 / 31 / 46 / 62 slices 4.89 / 4.14 / 3.94 / 3.79 / 3.85; chunk 1457 / 2914 / 5828 (31 slices): 3.78 / 3.94 / 4.14
+   //   K=64 : 4 / 8 / 16 / 24 / 32 slices 2.10 / 1.91 / 1.88 / 1.92 / 1.96;  chunk 1457 / 2914 / 5828: 1.87 / 1.88 / 2.17
+   //   K=32 : 2 / 4 / 8 / 12 / 16 slices 1.08 / 1.04 / 1.04 / 1.07 / 1.08;   chunk 1457 / 2914 / 5828: 1.02 / 1.04 / 1.31
    clear_error();
    if (!stream_pattern(imessage) || m <= 0 || n <= 0 || nnz < (1LL << 22) || nnz >= (1LL << 31) || k < 4 || k > 128 || (k % 4) != 0 || n >= (1LL << 24)) return 0;
    if (!stream_domain_ok(n, k, nnz)) return 0;
@@ -221,9 +225,9 @@ extern "C" int isplib_suggest_fusedmm_stream(int32_t imessage, int64_t m, int64_
    const int64_t per_gen = (int64_t)rpw * resident;
    const int64_t gens = (m + per_gen - 1) / per_gen;
    if ((double)nnz / (double)gens / 8.0 < 3.0 * (double)n) return 0;
-   int sl = (int)((double)n * (1024.0 / st) / 3.8e6 + 0.5);
+   int sl = (int)((double)n * (1024.0 / st) / (st == 2 ? 2.6e6 : 3.8e6) + 0.5);
    sl = sl < 1 ? 1 : (sl > 512 ? 512 : sl);
-   int64_t ch = (int64_t)((double)nnz / ((double)gens * resident * st) / 1.2);
+   int64_t ch = (int64_t)((double)nnz / ((double)gens * resident * st) / 2.4);
    ch = ch < 256 ? 256 : (ch > (1 << 20) ? (1 << 20) : ch);
    if (streams) *streams = st;
    if (slices) *slices = sl;
