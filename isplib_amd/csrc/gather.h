@@ -161,23 +161,12 @@ __device__ __forceinline__ void buf_step(const __amdgpu_buffer_rsrc_t rsrc, unsi
 #pragma unroll
    for (int u = 0; u < UU; u++) {
       const int ei = (s + u * G + g) & 63;
-#ifdef ISPLIB_EXP_NT_REMOTE
-      const unsigned off_raw = (unsigned)__shfl((int)off_l, ei);
-      const unsigned off = off_raw & ~1u;
-      // one row per gather instruction (G == 1): the bit is the same in every lane -- a scalar branch picks the cache policy
-      const bool nt = G == 1 && (__builtin_amdgcn_readfirstlane((int)off_raw) & 1);
-#else
       const unsigned off = (unsigned)__shfl((int)off_l, ei);
-#endif
       if (HAS_VAL) vv[u] = __shfl(v_l, ei);
 #pragma unroll
       for (int j = 0; j < NCH; j++) {
          // masked edge: off = BUF_OOB, + cbyte (< 2^24) cannot wrap; masked column: OR-ed past the limit
          const unsigned o = (off + cbyte[j]) | poison[j];
-#ifdef ISPLIB_EXP_NT_REMOTE
-         if (nt) t[u][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)o, 0, ISPLIB_EXP_NT_REMOTE);
-         else
-#endif
          t[u][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)o, 0, 0);
       }
    }
@@ -220,16 +209,6 @@ __device__ __forceinline__ void buf_step(const __amdgpu_buffer_rsrc_t rsrc, unsi
    }
 }
 
-#ifdef ISPLIB_EXP_NT_REMOTE
-// experiment (scripts/exp_products_nt.py): one bit per stored entry, "this gather is not worth keeping in the L2" -- carried in
-// bit 0 of the row's byte offset (rows are at least 4-byte aligned: the bit is free) and turned into the non-temporal cache
-// policy of the gather that uses it.  Only argument structs that have the mask take part.
-template <class A> __device__ __forceinline__ auto exp_nt_bit(const A &a, int64_t p, int) -> decltype(a.nt_mask, 0u) {
-   return a.nt_mask ? (unsigned)((a.nt_mask[p >> 6] >> (p & 63)) & 1ull) : 0u;
-}
-template <class A> __device__ __forceinline__ unsigned exp_nt_bit(const A &, int64_t, long) { return 0u; }
-#endif
-
 // metadata of the 64 edges [p0, p0 + 64) n [.., re): byte offset of the dense row (past the descriptor when masked), weight
 template <bool HAS_VAL, class Args>
 __device__ __forceinline__ void load_edge_batch(const Args &a, int64_t p0, int64_t re, unsigned ldyb, unsigned &off_l, float &v_l) {
@@ -238,9 +217,6 @@ __device__ __forceinline__ void load_edge_batch(const Args &a, int64_t p0, int64
    v_l = 0.0f;
    if (p < re) {
       off_l = (a.indx32 ? (unsigned)a.indx32[p] : (unsigned)a.indx[p]) * ldyb;
-#ifdef ISPLIB_EXP_NT_REMOTE
-      off_l |= exp_nt_bit(a, p, 0);
-#endif
       if (HAS_VAL) v_l = a.val[p];
    }
 }

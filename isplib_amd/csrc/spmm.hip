@@ -44,9 +44,6 @@ struct SpmmArgs {
    int mean;               // OP_ADD only: divide by max(deg,1)
    int empty_init;         // max / min: an empty row holds the launcher's init value (-+FLT_MAX) instead of 0
    int auto_panels;        // plain mode, index order, dense operand beyond the Infinity Cache: 128-column panels (launch_vec)
-#ifdef ISPLIB_EXP_NT_REMOTE
-   const unsigned long long *nt_mask;   // experiment: one bit per stored entry, 1 = gather with the non-temporal policy
-#endif
    int long_row;           // rows with more edges are split across the workgroup
    unsigned nblk;          // number of row blocks
    unsigned ybytes;        // n*ldy*4 when it fits the buffer-descriptor path, else 0
@@ -86,14 +83,6 @@ __device__ __forceinline__ void write_row(const SpmmArgs &a, int64_t row, int64_
 #pragma unroll
    for (int j = 0; j < NCH; j++) {
       if (!cok[j]) continue;
-#ifdef ISPLIB_EXP_NT_STORE
-      // experiment (scripts/exp_products_nt.py): finished rows leave with the non-temporal policy -- written once, never read here
-      if (VEC == 4 && vfirst[j] == 0 && ((uintptr_t)(zr + ccol[j]) & 15) == 0) {
-         typedef float f4v_t __attribute__((ext_vector_type(4)));
-         const f4v_t t = {acc[j][0], acc[j][VEC > 1 ? 1 : 0], acc[j][VEC > 2 ? 2 : 0], acc[j][VEC > 3 ? 3 : 0]};
-         __builtin_nontemporal_store(t, reinterpret_cast<f4v_t *>(zr + ccol[j]));
-      } else
-#endif
       store_tail<VEC>(zr + ccol[j], acc[j], vfirst[j]);
       if (OP != OP_ADD && a.z_arg) {
          int64_t *ar = a.z_arg + (size_t)row * (size_t)a.ldz + ccol[j];
@@ -425,11 +414,6 @@ static int launch_op(const SpmmArgs &a, hipStream_t st) {
 
 using namespace isplib;
 
-#ifdef ISPLIB_EXP_NT_REMOTE
-static const unsigned long long *g_exp_nt_mask = nullptr;
-extern "C" void isplib_debug_set_nt_mask(const unsigned long long *mask) { g_exp_nt_mask = mask; }   // experiment builds only
-#endif
-
 static int spmm_entry(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t nnz, const float *val,
                       const int64_t *indx, const int64_t *pntrb, const int64_t *pntre, const float *y, int64_t ldy,
                       float beta, float *z, int64_t ldz, int64_t *z_arg, const int64_t *sliceptr, int slices,
@@ -470,9 +454,6 @@ static int spmm_entry(int32_t imessage, int64_t m, int64_t n, int64_t k, int64_t
    a.part_val = nullptr; a.part_idx = nullptr;
    a.row_order = row_order;
    a.auto_panels = (!row_order && !sliceptr && (double)n * (double)ldy * 4.0 > 256.0 * 1048576.0) ? 1 : 0;
-#ifdef ISPLIB_EXP_NT_REMOTE
-   a.nt_mask = g_exp_nt_mask;
-#endif
    if (sliceptr) {
       if (slices < 1 || slices > ISPLIB_MAX_SLICES) return fail(ISPLIB_FAIL, "fusedMM_csr_sliced_hip: slices must be in [1, 4096]");
       const size_t need = isplib_spmm_sliced_workspace_bytes(imessage, m, k, slices);

@@ -417,7 +417,15 @@ def test_plugin_and_handle_take_the_community_order_where_the_operand_is_beyond_
     n, k = 300000, 256
     rowptr, col = synth.sbm_csr(n, 6000000, 300, 0.8, 2000, 1.0, 4, device=gpu)
     x = synth.features(n, k, device=gpu)
-    want, _ = cabi.spmm(rowptr, col, None, x, "sum")
+    # the index-order rows in the one-pass form a community order runs (isplib_hip_tune(0, 64): the index-order DEFAULT for an
+    # operand beyond the Infinity Cache is two 128-column panels since round 5, whose sums are associated differently)
+    cabi.lib().isplib_hip_tune(0, 64)
+    try:
+        want, _ = cabi.spmm(rowptr, col, None, x, "sum")
+    finally:
+        cabi.lib().isplib_hip_tune(0, 0)
+    panels, _ = cabi.spmm(rowptr, col, None, x, "sum")
+    assert torch.allclose(panels, want, rtol=1e-5, atol=1e-4) and not torch.equal(panels, want), "the default index-order launch runs panels here"
     adj = isplib_amd.SparseTensor.from_csr(rowptr, col, None, (n, n))
     xg = x.clone().requires_grad_(True)
     out = isplib_amd.matmul(adj, xg, "sum")
