@@ -569,7 +569,30 @@ def dist_extra_configs(dev, rank, world, rowptr, col, n, guard=None):
                           "partitioned by nnz (6 aggregations = 6 all-gathers + local SpMM, dense layers on the local rows, "
                           "weight gradients all-reduced, Adam)",
                 "ms": over_ranks(statistics.mean(times)) * 1e3, "epochs_timed": len(times), "n_gpus": world})
-    del x, y, mask, model, opt, graph
+    del x, y, mask, model, opt
+    # config 3 under the partition (round 5): mean / max / min, K=64, U(0,1) weights -- ONE all-gather + the local SpMM on the schedule
+    # the single-GPU rules pick for the rank's shard (RowPartition.spmm_auto); max / min return values and GLOBAL positions
+    w_full = synth.edge_weights(col.numel(), device=dev)
+    part3 = RowPartition(rowptr, col, w_full, n, rank, world, cuts=graph.fwd.row_cuts)
+    del w_full, graph
+    x3 = synth.features(n, 64, device=dev, integer=True)[part3.x_cuts[rank]: part3.x_cuts[rank + 1]].contiguous()
+    for red in ("mean", "max", "min"):
+        part3.spmm_auto(x3, red)                              # plans, buffers
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            res3 = part3.spmm_auto(x3, red)
+        torch.cuda.synchronize()
+        ms3 = over_ranks((time.perf_counter() - t0) / 5) * 1e3
+        vals3 = res3[0] if isinstance(res3, tuple) else res3
+        check = torch.tensor([float(vals3.double().sum())], dtype=torch.float64, device=dev)
+        dist.all_reduce(check)                                # a checksum over all ranks' rows, for comparing runs at different N
+        out.append({"config": f"config 3 on {world} GPUs: reddit-like SpMM-{red} K=64, U(0,1) weights, 1-D row partition: one all-gather(X) + the local SpMM"
+                              + (" (+ global arg positions)" if red != "mean" else ""),
+                    "ms": ms3, "edges_per_s": col.numel() / (ms3 * 1e-3), "local_schedule_rank0": part3.local_ops(64, red)[0],
+                    "sum_of_all_outputs": float(check), "n_gpus": world})
+    del part3, x3
     torch.cuda.empty_cache()
 
     # config 4

@@ -1000,3 +1000,11 @@ def test_exchange_schedules_park_local_kernel_errors_until_their_collectives_are
     part._raise_parked()                             # nothing parked any more
     part._kernel(ran.append, "d")
     assert ran == ["a", "d"]
+    # round-4 advisor: an error parked by an exchange whose waits raised before _raise_parked must not be what the NEXT exchange
+    # reports (and must not make it skip its kernels): every schedule starts with a clean slate
+    part._parked = RuntimeError("stale error of an earlier exchange")
+    x = torch.zeros((part.max_rows, 4))
+    out = torch.zeros((part.rows, 4))
+    with pytest.raises(Exception) as info:           # (no GPU here: the schedule's own first kernel call fails -- THAT is what surfaces)
+        part.spmm_pipelined(x, out, ([(0, 4)], [torch.zeros((part.max_rows, 4))], [torch.zeros((part.ncols_padded, 4))], object(), None), "sum")
+    assert "stale" not in str(info.value) and part._parked is None
