@@ -8,6 +8,7 @@ with `matmul` = isplib_amd.matmul, i.e. what torch_sparse.matmul becomes after i
 
     python scripts/gcn_epoch.py [--epochs 10] [--scale 1.0] [--hidden 32] [--model gcn|sage|gin] [--aggr sum|mean|max]
 
+--model sage also runs on the 1-D row partition (N > 1 ranks: DistGraph.matmul(x, aggr) with autograd for sum / mean / max / min).
 --model sage / gin restate the other two callers (tests/cpu/graphSAGE-sparse.py:65-78, tests/cpu/gin-sparse.py:59-78):
 they aggregate at the INPUT width (use --features 608, the padded Reddit width), 5 SpMM per epoch (the
 input features need no gradient, so layer 1 has no backward SpMM).
@@ -140,8 +141,8 @@ def main():
     y = torch.randint(0, a.classes, (n,), device=dev)
     train_mask = torch.rand(n, device=dev) < 0.66
     n_train = int(train_mask.sum())
-    if a.model != "gcn" and world > 1:
-        raise SystemExit("--model sage/gin: single GPU only")
+    if a.model == "gin" and world > 1:
+        raise SystemExit("--model gin: single GPU only (BatchNorm statistics are not synchronised here)")
     if a.model == "sage":
         model = SAGENet(a.features, a.hidden, a.classes, a.aggr).to(dev)
     elif a.model == "gin":
@@ -158,8 +159,8 @@ def main():
         x, y, train_mask = x[r0:r1].contiguous(), y[r0:r1], train_mask[r0:r1]
         del rowptr, col
 
-        def matmul(g, m, reduce):
-            return g.matmul(m)
+        def matmul(g, m, reduce):                    # every reduction has autograd under the partition (round 5)
+            return g.matmul(m, reduce)
     else:
         adj_t = isplib_amd.SparseTensor.from_csr(rowptr, col, None, (n, n), validate=False)
         isplib_amd.iSpLibPlugin.patch_pyg()
