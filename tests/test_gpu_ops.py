@@ -12,6 +12,7 @@ import torch
 from tests import cases
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "spmm_ref_layer.npz")
 
 
@@ -364,6 +365,67 @@ def test_two_epoch_gcn_loss_trajectory(gpu, oracle_mod):
     got = run(gpu, lambda m: isplib_amd.matmul(adj, m, "sum"))
     ref = run("cpu", OracleAgg.apply)
     assert np.allclose(got, ref, rtol=1e-4), (got, ref)
+
+
+@pytest.mark.parametrize("model,aggr", (("sage", "mean"), ("sage", "max"), ("sage", "min"), ("sage", "sum"), ("gin", "sum")))
+def test_two_epoch_sage_and_gin_loss_trajectories(gpu, oracle_mod, model, aggr):
+    """The reference's other two callers (tests/cpu/graphSAGE-sparse.py:65-78, aggr sum | mean | max; tests/cpu/gin-sparse.py:59-78)
+    as scripts/gcn_epoch.py restates them, trained for 2 epochs through the patched matmul on the HIP path, against the same
+    two epochs on the CPU with the ORACLE doing every aggregation and the oracle's restatements of the reference's backward
+    formulas (csrc/fusedmm.cpp:285, :375, :410-451) doing every gradient: losses within 1e-4 relative.  Weighted graph, so the
+    mean backward's intended weight pairing and the max / min positions are all exercised inside a training loop."""
+    import importlib.util
+    import isplib_amd
+    spec = importlib.util.spec_from_file_location("gcn_epoch", os.path.join(ROOT, "scripts", "gcn_epoch.py"))
+    ge = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ge)
+    n, f, h, c = 220, 16, 24, 5
+    rowptr, col = cases.random_csr(n, n, 7.0, seed=41, empty_rows=(3, 100), hub=(7, 150))
+    val = (np.abs(cases.weights(col.size, 9)) + np.float32(0.1)).astype(np.float32)
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((n, f)).astype(np.float32)
+    y = torch.from_numpy(rng.integers(0, c, n))
+
+    class OracleAgg(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, m, red):
+            out, arg = oracle_mod.spmm_fw(rowptr, col, val, m.detach().numpy(), red)
+            ctx.red, ctx.arg, ctx.m = red, arg, m.detach().numpy()
+            return torch.from_numpy(out)
+
+        @staticmethod
+        def backward(ctx, go):
+            g = np.ascontiguousarray(go.numpy())
+            if ctx.red == "sum":
+                return torch.from_numpy(oracle_mod.spmm_sum_bw(rowptr, col, val, n, g)), None
+            if ctx.red == "mean":
+                return torch.from_numpy(oracle_mod.spmm_mean_bw(rowptr, col, val, n, g)), None
+            return torch.from_numpy(oracle_mod.spmm_minmax_bw(col, val, ctx.m, ctx.arg, g)[1]), None
+
+    def make():
+        torch.manual_seed(7)
+        return (ge.SAGENet(f, h, c, aggr) if model == "sage" else ge.GINNet(f, h, c))
+
+    def run(net, xs, ys, adj, agg):
+        opt = torch.optim.Adam(net.parameters(), lr=0.01, weight_decay=5e-4)
+        net.eval() if model == "sage" else net.train()      # (SAGE: dropout off, identical arithmetic; GIN: BatchNorm in training mode)
+        losses = []
+        for _ in range(2):
+            opt.zero_grad()
+            loss = torch.nn.functional.nll_loss(net(xs, adj, agg), ys)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        return losses
+
+    ref = run(make(), torch.from_numpy(x), y, None, lambda a_, m_, r_: OracleAgg.apply(m_, r_))
+    adj = isplib_amd.SparseTensor.from_csr(_t(rowptr, gpu), _t(col, gpu), _t(val, gpu), (n, n))
+    isplib_amd.iSpLibPlugin.patch_pyg()
+    try:
+        got = run(make().to(gpu), _t(x, gpu), y.to(gpu), adj, lambda a_, m_, r_: torch.sparse.mm(a_, m_, r_))
+    finally:
+        isplib_amd.iSpLibPlugin.unpatch_pyg()
+    assert np.allclose(got, ref, rtol=1e-4), (model, aggr, got, ref)
 
 
 def test_boundary_calls_are_hipgraph_capturable(gpu, oracle_mod):
