@@ -145,6 +145,27 @@ def main():
             splan.close()
         if native and mplan is not None:
             mplan.close()
+        # ---- round 5: the two SDDMM-fused FusedMM words on the stream front end against the oracle's generic pipeline ----
+        if k % 4 == 0 and 4 <= k <= 128 and col.size:
+            xl = cases.dense(m, k, int(rng.integers(1 << 30)), "integer" if integer else "uniform")
+            st_f = 8 if k <= 32 else (4 if k <= 64 else 2)
+            fplan = cabi.NativeStreamPlan(d_rowptr, d_col, None, n, st_f, int(rng.choice([1, 2, 5, 9])), int(rng.choice([64, 300, 2048])),
+                                          int(rng.integers(1, 9)), fusedmm=True)
+            d_xl, d_xc2 = t(xl), t(np.ascontiguousarray(x))
+            for pat in ("sigmoid_embedding", "tdist_embedding"):
+                word = cabi.PATTERNS[pat][0]
+                fn = "scale" if integer else ("sigmoid" if pat == "sigmoid_embedding" else "tdist")
+                sc = np.float32(1.0) if integer else np.float32(1.0 / np.sqrt(k))
+                _, zref, _ = oracle.fusedmm_general(word, rowptr, col, None, xl * sc, x * sc, cabi.SOP_UDEF[fn], 0.25)
+                _, zf = cabi.fusedmm_stream(word, d_rowptr, col.size, fplan, d_xl * float(sc), d_xc2 * float(sc), sop_udef=fn, sop_param=0.25)
+                zf = zf.cpu().numpy()
+                # (integer operands with the SCALE function are exact until a hub row's sum passes 2^24: held to 1e-6 there)
+                ok = bool(np.all(np.abs(zf - zref) <= (1e-6 if integer else 1e-4) * np.abs(zref).max() + 1e-7))
+                if not ok:
+                    bad += 1
+                    print(f"MISMATCH case {case}: fusedmm_stream/{pat} m={m} n={n} k={k} deg={deg} hub={hub} integer={integer} "
+                          f"plan: {fplan.streams} streams, {fplan.slices} slices, {fplan.gens} generation(s)", flush=True)
+            fplan.close()
         # ---- the backward side on the same graph: transpose operands, dX of sum / mean, SDDMM dA, max/min scatter ----
         if a.backward and col.size:
             g = cases.dense(m, k, int(rng.integers(1 << 30)), "integer" if integer else "uniform")
