@@ -57,7 +57,8 @@ def parse():
     p.add_argument("--no-extra", action="store_true", help="skip the other BASELINE.json configs (the `extra` array)")
     p.add_argument("--no-backward", action="store_true")
     p.add_argument("--only", default="", help="profiling: run ONE configuration of the `extra` array, named by its key in "
-                   "profiles/traffic.json (reddit-{mean,max,min}-k64-weighted, reddit-sum-k128-weighted, reddit-sddmm-k128, "
+                   "profiles/traffic.json (reddit-{mean,max,min}-k64-weighted, reddit-sum-k128-weighted, reddit-sum-k{32,41}-unit, "
+                   "reddit-sddmm-k128, reddit-fusedmm-{sigmoid,tdist}-k128, gcn-epoch, scaling-emulated-{reddit,products}, "
                    "products-{chunglu,sbm}-sum-k256-{plain,ordered}), and print it instead of the metric line")
     return p.parse_args()
 
