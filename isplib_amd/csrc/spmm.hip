@@ -392,7 +392,7 @@ static int launch_vec(const SpmmArgs &a, hipStream_t st) {
    // in index order 18.4 -> 17.8 (64-column panels: the same again).  NOT when the rows come in a community order: the panels
    // then halve what a community's rows of y keep of the L2 per byte of index stream (8.94 -> 9.73 ms).  The panel form sums a
    // row's edges over two slots, so its last bits differ from the one-pass form's: isplib_hip_tune(0, 64) keeps one pass.
-   else if (g_force_lpr == 0 && a.auto_panels && width > 32) width = 32;
+   else if (VEC == 4 && g_force_lpr == 0 && a.auto_panels && width > 32) width = 32;      // (measured on 16-byte lanes only)
    if (width <= 8) return launch_cfg<OP, VEC, 8, 1>(a, st);
    if (width <= 16) return launch_cfg<OP, VEC, 16, 1>(a, st);
    if (width <= 32) return launch_cfg<OP, VEC, 32, 1>(a, st);
