@@ -1060,7 +1060,13 @@ def main():
     # until the driver kills it, and once the north_star form has been measured its result is printed whatever happens later
     guard = None
     if world > 1 or os.environ.get("ISPLIB_BENCH_FORCE_DIST") == "1":
-        guard = Guard(rank, world)
+        # stdout of rank 0 is the ONE JSON line.  RCCL writes a five-line version banner to file descriptor 1 when the first
+        # communicator comes up (seen on the one-rank rehearsal over RCCL, round 5), and any other native library may do the like:
+        # from here on descriptor 1 IS stderr, and the line goes out through a private copy of the original descriptor.
+        sys.stdout.flush()
+        line_out = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+        guard = Guard(rank, world, out=line_out)
         guard.arm("start-up, graph, plans and the north_star form (one all-gather + local SpMM)", _env_seconds("ISPLIB_BENCH_T_SAFE", 360))
     t_candidate = _env_seconds("ISPLIB_BENCH_T_CANDIDATE", 60)      # one optional exchange schedule: validation + timing
     t_total = _env_seconds("ISPLIB_BENCH_DEADLINE", 480)            # everything, seconds since this rank started

@@ -39,3 +39,24 @@ def test_scaling_emulated_block_has_every_rank_and_the_exchange_model(gpu):
         assert abs(direct - shard / 153e9 * 1e3) < 1e-9 and abs(p["exchange_model_ms"]["ring"] - (p["ranks"] - 1) * direct) < 1e-9
         assert abs(p["step_model_ms"]["direct, no overlap"] - (p["local_spmm_ms_max"] + direct)) < 1e-9
         assert abs(p["compute_speedup_over_one_gpu"] - 1.0 / p["local_spmm_ms_max"]) < 1e-9
+
+
+def test_one_rank_rccl_rehearsal_prints_exactly_one_line_on_stdout(gpu):
+    """The N > 1 code walked by ONE rank over real RCCL (ISPLIB_BENCH_FORCE_DIST=1 under torch.distributed.run).  RCCL writes
+    a version banner to file descriptor 1 when its first communicator comes up; rank 0's stdout must still be the one JSON
+    line and nothing else (bench.py hands descriptor 1 to stderr and keeps a private copy for the line)."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, ISPLIB_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for name in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(name, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29653", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--scale", "0.05"]
+    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, proc.stdout[:1000]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and "REHEARSAL" in rec["data"] and rec["value"] > 0
+    assert "process group up: backend=nccl" in proc.stderr
