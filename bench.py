@@ -101,6 +101,21 @@ def cpu_baseline(rowptr, col, x, nnz):
             "oracle_dynamic16_single_node_ms": plain_ms, "torch_sparse_mm_ms": torch_ms}
 
 
+GATHER_CLOCKS_PER_KIB = 19.5    # profiles/r05_ubench_gather_paths.txt: 19.0-19.9 clocks per 1-KiB gather per CU, VGPR or LDS-DMA alike
+
+
+def gather_ceiling(dev, nnz: int, k: int, kernel_ms: float) -> dict:
+    """Time the address pipelines of the chip need for nnz gathers of k floats at the rate of the gather-only microbenchmark
+    (scripts/ubench/gather_paths.hip, an L2-resident table): a floor for any kernel that gathers every row it needs once per
+    edge, whatever its schedule."""
+    prop = torch.cuda.get_device_properties(dev)
+    cus = prop.multi_processor_count
+    mhz = getattr(prop, "clock_rate", 2400000) / 1000.0
+    ms = nnz * k * 4 / 1024.0 * GATHER_CLOCKS_PER_KIB / (cus * mhz * 1e6) * 1e3
+    return {"ms": ms, "frac": ms / kernel_ms if kernel_ms else None, "clocks_per_KiB_gather_per_CU": GATHER_CLOCKS_PER_KIB, "cus": cus,
+            "clock_MHz": mhz, "source": "profiles/r05_ubench_gather_paths.txt (gather-only microbenchmark, all L2 hits)"}
+
+
 def apply_tune(cabi, spec: str) -> None:
     """--tune key=value,...: knobs 0-8 belong to the default library (isplib_hip_tune), 9 and 12 to the experimental one."""
     for kv in filter(None, spec.split(",")):
@@ -1354,6 +1369,9 @@ def main():
                 "frac_of_measured_copy": None if not copy_gbps else achieved / copy_gbps,
                 "algorithmic_bytes_per_launch": b_alg,
                 "gather_model_GBps": synth.gather_bytes(m_local, l_col.numel(), k) / (kern_avg_ms * 1e-3) / 1e9,
+                # a second, kernel-independent ceiling (secondary: `frac` above is the HBM roofline): what the CUs' address pipelines
+                # need for this launch's gathers when every one is an L2 hit and nothing else runs
+                "gather_ceiling": gather_ceiling(dev, l_col.numel(), k, kern_avg_ms),
             },
         }
         if multi:

@@ -60,3 +60,39 @@ def test_one_rank_rccl_rehearsal_prints_exactly_one_line_on_stdout(gpu):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 1 and "REHEARSAL" in rec["data"] and rec["value"] > 0
     assert "process group up: backend=nccl" in proc.stderr
+
+
+def test_default_line_carries_the_contract_fields(gpu):
+    """The JSON line of `python bench.py` (one GPU): every field the driver's contract names, the `roofline` and
+    `cpu_baseline` objects, and the secondary gather ceiling -- on a scaled graph so that the oracle's leg takes seconds."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for name in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "ISPLIB_BENCH_FORCE_DIST"):
+        env.pop(name, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--scale", "0.05", "--no-extra"]
+    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, proc.stdout[:1000]
+    rec = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in rec, key
+    assert rec["metric"] == "edges_aggregated_per_sec" and rec["unit"] == "edges/s" and rec["higher_is_better"] is True
+    assert (rec["n_gpus"], rec["steps"], rec["warmup"]) == (1, 4, 2) and rec["vs_baseline"] is None and rec["dtype"] == "f32"
+    assert "workload" in rec["config"] and "SCALED" in rec["config"]["workload"] and "model" not in rec["config"]
+    roof = rec["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in roof, key
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12 and 0 < roof["frac"] < 1
+    assert abs(roof["achieved"] - roof["algorithmic_bytes_per_launch"] / (roof["kernel_avg_ms"] * 1e-3) / 1e9) < 1e-6 * roof["achieved"]
+    ceil = roof["gather_ceiling"]
+    assert ceil["cus"] > 0 and ceil["ms"] > 0 and abs(ceil["frac"] - ceil["ms"] / roof["kernel_avg_ms"]) < 1e-12
+    cpu = rec["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in cpu, key
+    assert cpu["kind"] in ("port", "reference") and cpu["unit"] == "edges/s" and cpu["cores"] >= 1 and cpu["value"] > 0
+    assert abs(rec["value"] - int(rec["config"]["workload"].split("nnz=")[1].split(")")[0]) / (rec["ms_per_step"] * 1e-3)) < 1e-6 * rec["value"]
