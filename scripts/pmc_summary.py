@@ -8,7 +8,7 @@ for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
         short = name.split("(")[0][-60:]
         acc[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for kname, ctrs in acc.items():
-    if not any(s in kname for s in ("spmm", "sddmm", "minmax", "combine", "slices", "finalize", "colptr", "hub_fold", "stream", "sweep")):
+    if not any(s in kname for s in ("spmm", "sddmm", "minmax", "combine", "slices", "finalize", "colptr", "hub_fold", "stream", "sweep", "gather_kernel")):
         continue
     print(kname)
     for c, v in sorted(ctrs.items()):
