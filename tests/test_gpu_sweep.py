@@ -612,3 +612,34 @@ def test_stream_entries_can_be_captured_in_a_hip_graph(gpu, oracle_mod):
         _check(oracle_mod, rowptr, col, val, host_x, "sum", got[0], None)
         _check(oracle_mod, rowptr, col, val, host_x, "max", got[1], got[3])
         assert torch.equal(got[1].view(torch.int32), got[2].view(torch.int32))
+
+
+def test_long_row_of_repeated_terms_stays_within_the_bound_of_the_oracle_or_of_the_exact_sum(gpu, oracle_mod):
+    """A row of 1,269 stored entries over TWO columns with unit weights: every term has the sign of its column's value, so any
+    sequential fp32 sum -- the oracle's included -- is ~3x the 1e-5 x sum |a||x| bound away from the exact sum (found by
+    scripts/fuzz_parity.py, profiles/r05_fuzz_long.txt).  What parity asks of a schedule on such a row: within the bound of the
+    ORACLE (a plan that keeps the row in one piece adds in the oracle's order) or of the exact fp64 sum (a plan that cuts it)."""
+    from isplib_amd import cabi
+    from isplib_amd.plan import build_stream_plan
+    m, n, k = 82, 2, 256
+    rowptr, col = cases.random_csr(m, n, 2, seed=1, hub=(26, 1269), duplicates=True)
+    x = cases.dense(n, k, 8, "uniform")
+    ones = np.ones(col.size, np.float32)
+    row_ids = np.repeat(np.arange(m), np.diff(rowptr))
+    exact = np.zeros((m, k))
+    np.add.at(exact, row_ids, x.astype(np.float64)[col])
+    ref, _ = oracle_mod.spmm_fw(rowptr, col, ones, x, "sum")
+    tol = cases.sum_tolerance(oracle_mod, rowptr, col, ones, x)
+    assert np.max(np.abs(ref - exact) / tol) > 1.5, "the case must put the fp32 oracle itself outside the bound of the exact sum"
+    d_rowptr, d_col, d_x = _t(rowptr, gpu), _t(col, gpu), _t(x, gpu)
+    outs = {}
+    for chunk in (2048, 300, 64):
+        plan = build_stream_plan(d_rowptr, d_col, None, n, 5, 6, None, 4, chunk)
+        outs[f"stream, chunk {chunk}"] = cabi.spmm_stream(d_rowptr, col.size, plan, d_x, "sum").cpu().numpy()
+    plain = torch.empty((m, k), device=gpu)
+    cabi.fusedMM_csr_hip(cabi.MSG_SPMM_SUM, d_rowptr, d_col, None, d_x, plain, None)
+    outs["plain"] = plain.cpu().numpy()
+    for name, o in outs.items():
+        near_exact = np.all(np.abs(o - exact) <= tol)
+        near_oracle = np.all(np.abs(o - ref) <= tol)
+        assert near_exact or near_oracle, (name, float(np.max(np.abs(o - exact) / tol)), float(np.max(np.abs(o - ref) / tol)))
