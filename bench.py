@@ -1208,6 +1208,20 @@ def main():
             swork = None if splan is None else splan.workspace()
         if splan is None and a.schedule == "stream":
             raise SystemExit("--schedule stream: the stream schedule does not apply to this shape (isplib_suggest_stream)")
+    # max / min: the stream schedule's own kernel and plan geometry where its rule accepts the shape (column-sorted rows), as the
+    # plug-in runs them; one GPU only (the N > 1 exploration below is written around the sum / mean schedules)
+    mplan = mwork = None
+    if a.schedule in ("auto", "stream") and a.reduce in ("max", "min") and not multi:
+        from isplib_amd.plan import build_stream_plan_native as _native
+        geom_mm = tuple(int(v) for v in a.stream_geom.split(":")) if a.stream_geom else \
+            cabi.suggest_stream_minmax(m_local, x_in.size(0), l_col.numel(), k)
+        if geom_mm is not None:
+            mplan = _native(l_rowptr, l_col, x_in.size(0), geom_mm[1], geom_mm[0], geom_mm[2], minmax=True)
+            if mplan is not None and l_val is not None:
+                mplan.set_values(l_val)
+            mwork = None if mplan is None else mplan.workspace(minmax=True)
+        if mplan is None and a.schedule == "stream":
+            raise SystemExit("--schedule stream: the max / min stream schedule does not apply to this shape (isplib_suggest_stream_minmax)")
     if a.schedule in ("auto", "stream"):
         a.schedule = "tasks"            # what everything the stream schedule does not serve falls back to
     use_stream = splan is not None and not multi     # N > 1: decided by a short measurement below
@@ -1239,6 +1253,9 @@ def main():
     use_tasks = tplan is not None and not multi      # N > 1: decided by a short measurement below
 
     def spmm(rp, cl, vl, tb, xin, o, ar, tp=None, sp=None):
+        if mplan is not None and sp is None and tp is None and rp is l_rowptr:
+            cabi.fusedMM_csr_stream_minmax_hip(msg, rp, cl.numel(), mplan, xin, o, ar, mwork)
+            return
         sp = splan if (sp is None and tp is None and rp is l_rowptr and use_stream) else sp
         if sp is not None:
             cabi.fusedMM_csr_stream_hip(msg, rp, cl.numel(), sp, xin, o, swork if sp is splan else swork_t)
@@ -1323,7 +1340,10 @@ def main():
             except Exception:  # noqa: BLE001
                 traffic = None
         overlapped = multi and chosen not in ("gather+spmm", "gather+stream")
-        if chosen.startswith("pipelined stream"):
+        if mplan is not None:
+            kernel_label = (f"spmm_stream_minmax_kernel x {mplan.gens} generation(s) + sweep_hub_fold_kernel, "
+                            f"{-(-k // (256 // mplan.streams))} pass(es) of {256 // mplan.streams} columns per launch")
+        elif chosen.startswith("pipelined stream"):
             kernel_label = f"spmm_stream_kernel + sweep_hub_fold_kernel per column panel ({chosen}), exchange included in the events"
         elif stream_now:
             pw = 256 // splan.streams
@@ -1349,7 +1369,10 @@ def main():
                 "workload": f"{a.workload}-like graph ({a.generator}, N={n}, nnz={nnz}), SpMM-{a.reduce} forward, K={k}, fp32"
                             + (", U(0,1) weights" if a.weighted else ", unit weights")
                             + ("" if a.scale == 1.0 else f", SCALED x{a.scale} (debug)"),
-                "schedule": (f"stream: {splan.streams} streams x {splan.rows_per_wave // splan.streams} rows per wave, {splan.slices} column slices, "
+                "schedule": (f"stream (max / min kernel): {mplan.streams} streams x {mplan.rows_per_wave // mplan.streams} rows per wave, {mplan.slices} column slices, "
+                             f"{mplan.gens} generation(s) of {mplan.waves_per_gen} waves, rows > {mplan.chunk} edges dealt to {mplan.n_parts} virtual rows"
+                             if mplan is not None else
+                             f"stream: {splan.streams} streams x {splan.rows_per_wave // splan.streams} rows per wave, {splan.slices} column slices, "
                              f"{splan.gens} generation(s) of {splan.waves_per_gen} waves, rows > {splan.chunk} edges dealt to {splan.n_parts} virtual rows"
                              if stream_now else
                              f"stream schedule per column panel ({chosen})" if chosen.startswith("pipelined stream") else
