@@ -195,6 +195,64 @@ def scaling_emulated(dev, rowptr, col, n, k, label, one_gpu_ms=None, ranks=(2, 4
     return rec
 
 
+def epoch_emulated(dev, ge, rowptr, col, n, x, y, mask, one_gpu_ms, ranks=(2, 4, 8), sample=2):
+    """config 5's epoch on the 1-D row partition, rank by rank on ONE GPU -- no RCCL call, not a multi-GPU measurement.  For P in
+    `ranks`, `sample` of the P ranks (the first and the last: the partition is nnz-balanced, the ranks differ by their row counts)
+    build their DistGraph exactly as `scripts/gcn_epoch.py` does under torchrun, the one all-gather of every aggregation is
+    replaced by a local fill of the padded gather buffer (every slot gets this rank's shard: the same bytes are written), the
+    all-reduce of the dense gradients is skipped, and the epoch (forward, loss, backward, Adam, second forward) is timed.  The
+    exchange is MODELLED: six all-gathers of the rank's [rows, 32 | 41] shard with every peer on its own xGMI link."""
+    import torch.nn.functional as F
+    from isplib_amd.dist import DistGraph
+    feats, hidden, classes = x.size(1), 32, 41
+    n_train = int(mask.sum())
+    rec = {"what": "EMULATED ON ONE GPU, NO RCCL: the partitioned epoch of scripts/gcn_epoch.py timed rank by rank on this device with the "
+                   "all-gathers replaced by local fills; the exchange is a model (xGMI 153 GB/s per link), not a measurement",
+           "one_gpu_ms": one_gpu_ms, "points": []}
+
+    def fill(x_shard, buf):                              # what all_gather_into_tensor leaves behind, in bytes written
+        buf.view(-1, x_shard.size(0), x_shard.size(1))[:] = x_shard.unsqueeze(0)
+        return None
+
+    for world in ranks:
+        per_rank = []
+        for rank in sorted({0, world - 1} if sample >= 2 else {0}):
+            g = DistGraph(rowptr, col, None, n, rank, world)
+            g.fwd.all_gather = fill
+            g.bwd.all_gather = fill
+            r0, r1 = g.row0, g.row0 + g.rows
+            xr, yr, mr = x[r0:r1].contiguous(), y[r0:r1], mask[r0:r1]
+            torch.manual_seed(0)
+            model = ge.Net(feats, hidden, classes).to(dev)
+            opt = torch.optim.Adam(model.parameters(), lr=0.01, weight_decay=5e-4)
+            mm = lambda gg, m_, red: gg.matmul(m_, red)  # noqa: E731
+            times = []
+            for epoch in range(5):                       # epoch 0 builds the shard's plans; not timed
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                model.train()
+                opt.zero_grad()
+                o = model(xr, g, mm)
+                loss = F.nll_loss(o[mr], yr[mr], reduction="sum") / n_train
+                loss.backward()
+                opt.step()
+                model(xr, g, mm).argmax(1)
+                torch.cuda.synchronize()
+                if epoch:
+                    times.append(time.perf_counter() - t0)
+            shard_rows = g.fwd.max_rows
+            per_rank.append({"rank": rank, "rows": g.rows, "nnz": g.fwd.nnz, "epoch_ms": round(statistics.mean(times) * 1e3, 4)})
+            del g, model, opt, xr
+            torch.cuda.empty_cache()
+        compute_ms = max(r["epoch_ms"] for r in per_rank)
+        gather_ms = sum(shard_rows * k_ * 4 / (XGMI_LINK_GBPS * 1e9) * 1e3 for k_ in (hidden, classes) * 3)
+        rec["points"].append({"ranks": world, "epoch_compute_ms_max_of_sampled_ranks": compute_ms, "ranks_sampled": [r["rank"] for r in per_rank],
+                              "six_all_gathers_model_ms_direct": gather_ms, "epoch_model_ms_no_overlap": compute_ms + gather_ms,
+                              "speedup_over_one_gpu_model": None if not one_gpu_ms else one_gpu_ms / (compute_ms + gather_ms),
+                              "per_rank": per_rank})
+    return rec
+
+
 def extra_configs(dev, rowptr, col, n, with_cpu_epoch=True):
     """The other configurations of BASELINE.json under the same clock as the headline (N = 1, outside its timed region):
     config 3 (Reddit-shaped mean / max / min, K=64, weighted), config 2 with weights, config 4's shape on one GPU
@@ -392,6 +450,10 @@ def gcn_epoch_config(dev, rowptr, col, n, with_cpu_epoch):
                                    "what": "GCNConv(normalize=True) epoch: every aggregation is torch.ops.isplib.gcn_norm_spmm (self loop, "
                                            "D^-1/2 on both sides, bias, ReLU fused; backward prologue one HIP pass)"}
     del model_n, opt_n
+    try:
+        rec["scaling_emulated"] = epoch_emulated(dev, ge, rowptr, col, n, x, y, mask, gpu_epoch_ms)
+    except Exception as e_:  # noqa: BLE001 - an emulation must never cost the line its measured epoch
+        rec["scaling_emulated"] = {"error": f"{type(e_).__name__}: {e_}"}
     if with_cpu_epoch:
         # the same epoch on the host cores with the oracle doing every aggregation (the reference's CPU mode `isplib`,
         # tests/cpu/gcn-sparse.py:29-36,83-92): A is symmetric with unit weights here, so A^T dY is the same call

@@ -96,3 +96,28 @@ def test_default_line_carries_the_contract_fields(gpu):
         assert key in cpu, key
     assert cpu["kind"] in ("port", "reference") and cpu["unit"] == "edges/s" and cpu["cores"] >= 1 and cpu["value"] > 0
     assert abs(rec["value"] - int(rec["config"]["workload"].split("nnz=")[1].split(")")[0]) / (rec["ms_per_step"] * 1e-3)) < 1e-6 * rec["value"]
+
+
+def test_epoch_emulated_block_times_sampled_ranks_and_models_the_exchange(gpu):
+    """config 5's `scaling_emulated` (the partitioned GCN epoch rank by rank on one GPU, all-gathers replaced by local fills):
+    bookkeeping on a small graph -- the sampled ranks are the first and the last of every P, their rows / nnz are the
+    partition's, the exchange model is six shard transfers on one xGMI link each, and the emulation is labelled as such."""
+    from isplib_amd import synth
+    from isplib_amd.dist import RowPartition
+    bench = _bench()
+    rowptr, col, n = synth.dataset_like("reddit", device=gpu, scale=0.02)
+    rec = bench.gcn_epoch_config(gpu, rowptr, col, n, with_cpu_epoch=False)
+    assert rec["ms"] > 0 and rec["normalize_true_fused"]["ms"] > 0
+    emu = rec["scaling_emulated"]
+    assert "error" not in emu and "EMULATED" in emu["what"] and "NO RCCL" in emu["what"]
+    assert [p["ranks"] for p in emu["points"]] == [2, 4, 8]
+    for p in emu["points"]:
+        world = p["ranks"]
+        assert p["ranks_sampled"] == [0, world - 1] and len(p["per_rank"]) == 2
+        for r in p["per_rank"]:
+            part = RowPartition(rowptr, col, None, n, r["rank"], world)
+            assert (r["rows"], r["nnz"]) == (part.rows, part.nnz) and r["epoch_ms"] > 0
+        shard_rows = RowPartition(rowptr, col, None, n, 0, world).max_rows
+        model = 3 * (32 + 41) * shard_rows * 4 / 153e9 * 1e3
+        assert abs(p["six_all_gathers_model_ms_direct"] - model) < 1e-9
+        assert abs(p["epoch_model_ms_no_overlap"] - (p["epoch_compute_ms_max_of_sampled_ranks"] + model)) < 1e-9
